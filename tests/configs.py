@@ -1,0 +1,49 @@
+"""Model configurations and synthetic-input recipes shared by the golden generator
+(tools/oracle/make_golden.py), the tests and bench.py.  Data only; no reference code."""
+import torch
+
+_TINY = dict(modalities_name=["rgb", "lidar"], modalities_ch=[3, 3], init_values=1e-6, patch_size=16,
+             embed_dim=64, depth=4, num_heads=2, mlp_ratio=4, drop_path_rate=0.3, drop_multimodal_path=0,
+             conv_inplane=16, n_points=4, deform_num_heads=2, cffn_ratio=0.25, deform_ratio=0.5, with_cp=True,
+             interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]], global_attn_indexes=[1, 3], window_size=14,
+             arch={"depths": [1, 1, 1, 1], "channels": [32, 64, 128, 256]}, pretrained_size=256)
+
+# CFG-L = segmentation/configs/DELIVER/Segformer_MMSAM_adapter_large_DELIVER_1024x1024_ss_RGBLIDAR.py:30-56
+_VITL = dict(img_size=1024, modalities_name=["rgb", "lidar"], modalities_ch=[3, 3], init_values=1e-6,
+             gamma_init_values=1e-6, patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4,
+             drop_path_rate=0.3, drop_multimodal_path=0, conv_inplane=48, n_points=4, deform_num_heads=16,
+             cffn_ratio=0.25, deform_ratio=0.5, with_cp=True,
+             interaction_indexes=[[0, 5], [6, 11], [12, 17], [18, 23]], global_attn_indexes=[5, 11, 17, 23],
+             window_size=14, arch="small")
+
+# BASELINE.json configs[0]: ViT-B SAM encoder + adapter, 512x512
+_VITB = dict(_VITL, img_size=512, embed_dim=768, depth=12, num_heads=12, deform_num_heads=12,
+             interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]], global_attn_indexes=[2, 5, 8, 11])
+
+CONFIGS = {
+    "tiny224": dict(kwargs=dict(_TINY, img_size=224), batch=1, seed=1, in_seed=5),
+    "tiny256": dict(kwargs=dict(_TINY, img_size=256), batch=1, seed=2, in_seed=6),
+    "tiny320": dict(kwargs=dict(_TINY, img_size=320), batch=1, seed=3, in_seed=7),
+    "vitb512": dict(kwargs=_VITB, batch=1, seed=4, in_seed=8),
+    "vitl1024": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9),
+}
+
+
+def make_input(cfg, batch=None, seed=None):
+    """Synthetic RGB+LiDAR tensor: RGB ~ N(0,1); aux = sparse 5% U(0,1)."""
+    b = batch or cfg["batch"]
+    s = cfg["kwargs"]["img_size"]
+    g = torch.Generator().manual_seed(cfg["in_seed"] if seed is None else seed)
+    x = torch.randn(b, 6, s, s, generator=g)
+    m = torch.rand(b, 3, s, s, generator=g) < 0.05
+    x[:, 3:] = m.float() * torch.rand(b, 3, s, s, generator=g)
+    return x
+
+
+def weights_checksum(sd):
+    return float(sum(v.double().abs().sum().item() for k, v in sorted(sd.items())))
+
+
+def probe_index(numel, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (n,), generator=g)

@@ -1,0 +1,222 @@
+"""Import harness for the *reference* backbone (runs ONLY where /root/reference exists).
+
+This is the build's own stub code: it installs permissive stand-ins for the
+third-party packages the reference imports but this image lacks (mmcv, mmseg,
+mmdet, timm, cv2, ...), then imports the reference's registered backbone class
+`SAMAdapterbimodalMixModNewInTwinConvNEW` from
+`segmentation/mmseg_custom/models/backbones/image_encoder_adapter_bimodal_mix_mod_new_in_twin_convnext_new.py:27-28`
+UNMODIFIED, with the native MSDA op replaced by the reference's own
+`ms_deform_attn_core_pytorch` (`segmentation/ops/functions/ms_deform_attn_func.py:53-75`),
+which the reference's `ops/test.py:26-75` declares equivalent to its CUDA kernel.
+
+No reference source or bytecode is copied anywhere; golden *vectors* produced through
+this harness are committed under tests/golden/ by tools/oracle/make_golden.py.
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import tempfile
+import types
+from unittest import mock
+
+REF_ROOT = "/root/reference"
+SEG = os.path.join(REF_ROOT, "segmentation")
+
+_MOCK_ROOTS = ("mmdet", "mmcv", "mmseg", "mmcls", "timm", "cv2", "torchvision",
+               "yapf", "termcolor", "pavi", "matplotlib", "tensorboard")
+
+
+def available() -> bool:
+    return os.path.isdir(SEG)
+
+
+class _Registry:
+    def __init__(self, name="reg"):
+        self.name = name
+        self.scope = name
+        self.module_dict = {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            key = name if isinstance(name, str) else cls.__name__
+            self.module_dict[key] = cls
+            return cls
+        if module is not None:
+            return deco(module)
+        if isinstance(name, type):  # used as bare decorator
+            cls, name = name, None
+            return deco(cls)
+        return deco
+
+    def get(self, key):
+        return self.module_dict.get(key)
+
+    def build(self, cfg, *a, **k):
+        cfg = dict(cfg)
+        t = cfg.pop("type")
+        return self.module_dict[t](**cfg)
+
+
+class _MockLoader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = mock.MagicMock(name=spec.name)
+        m.__name__ = spec.name
+        m.__path__ = []
+        m.__spec__ = spec
+        m.__loader__ = self
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+class _MockFinder(importlib.abc.MetaPathFinder):
+    def find_spec(self, fullname, path=None, target=None):
+        root = fullname.split(".")[0]
+        if root in _MOCK_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, _MockLoader(), is_package=True)
+        return None
+
+
+def _mk(name, **attrs):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+_installed = False
+
+
+def install():
+    """Install stubs and return the reference backbone class."""
+    global _installed
+    import torch
+    import torch.nn as nn
+    if not available():
+        raise RuntimeError("reference tree not present; goldens can only be generated in the build container")
+    sys.dont_write_bytecode = True
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    if not _installed:
+        sys.meta_path.insert(0, _MockFinder())
+        os.chdir(SEG)
+        sys.path.insert(0, SEG)
+
+        # addict.Dict (real recursive attribute dict)
+        class Dict(dict):
+            def __getattr__(self, k):
+                try:
+                    return self[k]
+                except KeyError:
+                    raise AttributeError(k)
+
+            def __setattr__(self, k, v):
+                self[k] = v
+        _mk("addict", Dict=Dict)
+
+        # registries
+        import mmseg.models.builder as b  # mock module
+        b.BACKBONES = _Registry("backbone")
+        b.HEADS = _Registry("head")
+        b.SEGMENTORS = _Registry("segmentor")
+        b.LOSSES = _Registry("loss")
+
+        # timm.models.layers: three real symbols
+        class DropPath(nn.Module):
+            def __init__(self, drop_prob=0.0):
+                super().__init__()
+                self.drop_prob = drop_prob
+
+            def forward(self, x):
+                if self.drop_prob == 0.0 or not self.training:
+                    return x
+                keep = 1 - self.drop_prob
+                shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+                r = x.new_empty(shape).bernoulli_(keep)
+                return x * r / keep
+
+        def to_2tuple(x):
+            return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+        import timm.models.layers as tl
+        tl.DropPath = DropPath
+        tl.trunc_normal_ = nn.init.trunc_normal_
+        tl.to_2tuple = to_2tuple
+
+        import mmcv.utils as mu
+        mu.TORCH_VERSION = torch.__version__
+        mu._BatchNorm = torch.nn.modules.batchnorm._BatchNorm
+        import mmcv.runner as mr
+        mr.HOOKS = _Registry("hooks")
+        mr.OPTIMIZER_BUILDERS = _Registry("ob")
+        mr.DefaultOptimizerConstructor = object
+        mr.EpochBasedRunner = object
+        mr.TextLoggerHook = object
+        import mmcv.runner.builder as mrb
+        mrb.RUNNERS = _Registry("runners")
+        import mmcv.runner.hooks as mrh
+        mrh.HOOKS = mr.HOOKS
+        mrh.Hook = object
+        mrh.OptimizerHook = object
+
+        # bypass heavyweight package __init__s of mmseg_custom
+        for pkg, rel in (("mmseg_custom", "mmseg_custom"),
+                         ("mmseg_custom.models", "mmseg_custom/models"),
+                         ("mmseg_custom.models.backbones", "mmseg_custom/models/backbones"),
+                         ("mmseg_custom.models.backbones.base", "mmseg_custom/models/backbones/base")):
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(SEG, rel)]
+            sys.modules[pkg] = m
+        sys.modules["MultiScaleDeformableAttention"] = types.ModuleType("MultiScaleDeformableAttention")
+        _installed = True
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod = importlib.import_module(
+            "mmseg_custom.models.backbones.image_encoder_adapter_bimodal_mix_mod_new_in_twin_convnext_new")
+    import ops.modules.ms_deform_attn as msda_mod
+    from ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+
+    class _Shim:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, w, step):
+            return ms_deform_attn_core_pytorch(value, shapes, loc, w)
+    msda_mod.MSDeformAttnFunction = _Shim
+    return mod.SAMAdapterbimodalMixModNewInTwinConvNEW
+
+
+def ref_functions():
+    """Reference free functions used for per-op goldens."""
+    install()
+    from ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    ie = importlib.import_module("mmseg_custom.models.backbones.base.image_encoder")
+    am = importlib.import_module(
+        "mmseg_custom.models.backbones.adapter_modules_multimodal_mix_mod_new_in_twin_convnext_new")
+    return dict(msda_core=ms_deform_attn_core_pytorch,
+                window_partition=ie.window_partition, window_unpartition=ie.window_unpartition,
+                get_rel_pos=ie.get_rel_pos, add_decomposed_rel_pos=ie.add_decomposed_rel_pos,
+                deform_inputs=am.deform_inputs, image_encoder=ie, adapter_modules=am)
+
+
+def build_reference(**cfg):
+    """Construct the reference backbone (eval mode). `checkpoint` is pointed at a dummy
+    local file because TwinConvNeXt.init_weights (base/twin_convnext.py:403-443) insists
+    on loading one."""
+    import contextlib
+    import io
+    import torch
+    cls = install()
+    tmp = os.path.join(tempfile.gettempdir(), "mmsa_dummy_convnext.pth")
+    if not os.path.exists(tmp):
+        torch.save({"state_dict": {"dummy.key": torch.zeros(1)}}, tmp)
+    cfg = dict(cfg)
+    cfg.setdefault("checkpoint", tmp)
+    cfg.setdefault("pretrained", None)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = cls(**cfg)
+    model.eval()
+    return model
