@@ -1,0 +1,139 @@
+/* mmsa.h -- C ABI of libmmsa_hip.so: the MI355X (gfx950) kernels of the MM-SAM-Adapter image-encoder forward.
+ *
+ * Drop-in boundary.  The reference's only native interface on this path is the pybind11 module
+ * `MultiScaleDeformableAttention` (segmentation/ops/src/vision.cpp:13-16) whose forward entry
+ * `ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)`
+ * (segmentation/ops/src/ms_deform_attn.h:20-39 -> cuda/ms_deform_attn_cuda.cu:20-80) is replaced by
+ * `mmsa_ms_deform_attn_forward` below.  Every other arithmetic op of the path is a stock PyTorch/ATen call in
+ * the reference (F.linear, F.conv2d, F.layer_norm, softmax, F.interpolate ...); the remaining entries are the
+ * hand-written kernels that take their place (file:line of the replaced call site is given per entry).
+ *
+ * Conventions
+ *  - plain C, no torch types; every pointer is a DEVICE pointer unless stated; `long` is 64-bit.
+ *  - the caller owns all memory (inputs, outputs, workspaces); the library never allocates or frees.
+ *  - every call enqueues work on `stream` (a hipStream_t) and returns immediately; no host sync inside, so the
+ *    whole forward can be captured into a HIP graph.
+ *  - return 0 on success, negative on error; `mmsa_last_error()` returns a thread-local message.  Shapes,
+ *    alignment and strides are validated on the host BEFORE anything is launched.
+ *  - activations are fp32, token-major / NHWC: a [rows, channels] matrix with a row stride `ld*` in elements.
+ *  - GEMM weights are bf16 hi/lo planes ("split3": x = hi + lo, three MFMA products, fp32 accumulate), produced
+ *    once by `mmsa_split_planes`.
+ */
+#ifndef MMSA_H
+#define MMSA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmsa_stream_t; /* hipStream_t */
+
+int mmsa_version(void);
+const char* mmsa_last_error(void);
+
+/* HIP events on the launch stream (for bench.py; torch.cuda.Event only sees torch's current stream). */
+int mmsa_event_create(void** ev);
+int mmsa_event_record(void* ev, mmsa_stream_t stream);
+int mmsa_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int mmsa_event_destroy(void* ev);
+
+/* activation codes of the fused epilogues */
+enum { MMSA_ACT_NONE = 0, MMSA_ACT_GELU = 1, MMSA_ACT_RELU = 2, MMSA_ACT_RELU6 = 3, MMSA_ACT_HSWISH = 4, MMSA_ACT_SIGMOID = 5 };
+
+/* --- reference native op ------------------------------------------------------------------------------------
+ * ms_deform_attn_forward (vision.cpp:14).  value [N,S,M,D], spatial_shapes int64 [L,2] (H,W), level_start_index
+ * int64 [L], sampling_loc [N,Lq,M,L,P,2] (x,y in [0,1]), attn_weight [N,Lq,M,L,P]; out [N,Lq,M*D] (overwritten).
+ * Error behaviour mirrors ms_deform_attn_cuda.cu:52: batch % min(batch, im2col_step) must be 0. */
+int mmsa_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const float* sampling_loc, const float* attn_weight, float* out, int batch,
+                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                int num_point, int im2col_step, mmsa_stream_t stream);
+
+/* Fused hot-path form of MSDeformAttn.forward's middle part (ops/modules/ms_deform_attn.py:105-127): takes the raw
+ * output `raw` [N*Lq, ldraw] of the concatenated sampling_offsets|attention_weights projection
+ * (columns [0, M*L*P*2) offsets, then M*L*P logits), the per-query reference points [Lq,2], does softmax over L*P,
+ * loc = ref + off/(W_l,H_l), and the sampling gather.  out [N*Lq, ldo]. */
+int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                    const float* raw, long ldraw, const float* ref_points, float* out, long ldo, int batch,
+                    int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
+                    mmsa_stream_t stream);
+
+/* --- GEMM (replaces F.linear / 1x1 conv / patchify conv / ConvTranspose2d 2x2 s2) ---------------------------
+ * C = beta*resid + colscale[n] * alpha * act(A[M,K] W[N,K]^T + bias[n]); batch > 1 = strided batched (strides in
+ * elements; strideW / strideBias may be 0 to share).  K % 32 == 0.  resid_mod > 0: residual row = row % resid_mod
+ * (broadcast over the batch, e.g. pos_embed).  out_mode 1 = 2x2 pixel-shuffle store for ConvTranspose2d(k=2,s=2)
+ * (BK:55,324): row (b,h,w), column (i,j,co) -> row (b,2h+i,2w+j), column co; resid uses the destination index.
+ * Call sites replaced: IE:488,499,162-167; TC:107-111,297-304,328-335; AM:947-950,447-451,87-89,121-126,286-290;
+ * ops/modules/ms_deform_attn.py:103,107-110,129; BK:324. */
+int mmsa_gemm_split3(const float* A, long lda, long strideA, const uint16_t* Whi, const uint16_t* Wlo, long strideW,
+                     const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,
+                     long strideR, int resid_mod, float beta, float* C, long ldc, long strideC, int M, int N, int K,
+                     int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, mmsa_stream_t stream);
+
+/* fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad], zero padded. */
+int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* hi, uint16_t* lo,
+                      mmsa_stream_t stream);
+
+/* --- attention (IE:465-501 incl. window_partition/unpartition IE:504-551 and rel-pos IE:587-623) -------------
+ * qkv [B*H*W, ldq] = q|k|v, channel = head*head_dim + c; qkv_bias [3*D]; rp from mmsa_relpos_bias;
+ * window_size 0 = global.  out [B*H*W, ldo]. head_dim in {32, 64}. */
+int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo, int B,
+                   int H, int W, int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
+
+/* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
+ * get_rel_pos(...)  (IE:554-584), (KH,KW,QS) = (ws,ws,ws) for windowed blocks or (H,W,max) for global ones. */
+int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp, int B, int H, int W,
+                     int heads, int head_dim, int window_size, mmsa_stream_t stream);
+
+/* --- normalisation / reductions ------------------------------------------------------------------------------
+ * Row LayerNorm (biased variance): y = (x-mean)/sqrt(var+eps)*w + b; optional y2 = x + y.  map_mode 1 scatters
+ * token (b,h,w) of an [B,map_H,map_W] grid to row (b,h/2,w/2), column block (h&1)*2+(w&1) (the im2col layout of
+ * the ConvNeXt 2x2 s2 downsample conv, TC:328-335).  Replaces nn.LayerNorm / LN2d / WithBias_LayerNorm:
+ * IE:367,377; AM:479-487,519-520,51-74; mmpretrain_custom/models/utils/norm.py:51-90. */
+int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps, float* y, long ldy,
+                        float* y2, long ldy2, int rows, int C, int map_mode, int map_H, int map_W, mmsa_stream_t stream);
+
+/* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
+int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C, double* out,
+                  mmsa_stream_t stream);
+
+/* GFFM LayerNorm(H*W) statistics + FFRM gate (AM:241,265 and AM:158-162), see csrc/norm.hip. */
+int mmsa_ffrm_finalize(const double* stats, int B, int HW, int C, float mean_w, float mean_b, const float* Wc,
+                       const float* gn_w, const float* gn_b, float* mean_o, float* rstd_o, float* mult_o,
+                       mmsa_stream_t stream);
+int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rstd, const float* mult, const float* w,
+                    const float* bias, float* y, long ldy, int B, int HW, int C, mmsa_stream_t stream);
+
+/* --- convolutions on NHWC maps (stride 1, same padding) and patch gather ------------------------------------
+ * dwconv: weights tap-major [k*k, C]; replaces TC:69-70,102; AM:288; AM:459,464-469.
+ * gconv: weights [G][k*k][cin_g][cout_g]; replaces AM:87-88,123-124.
+ * im2col_nchw: out[(b,ph,pw)][(c,kh,kw)] from NCHW input channels [c0, c0+Cin) (IE:658-663, TC:297-304). */
+int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y, long ldy,
+                     long ystrideB, int B, int H, int W, int C, int k, int act, mmsa_stream_t stream);
+int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
+                    int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);
+int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, int W, int p, float* out, int Kpad,
+                     mmsa_stream_t stream);
+
+/* --- modality-fusion neck pieces (AM:75-109, 234-267, 110-132, 176-221) ------------------------------------- */
+int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, float* G, int B, int P, int c,
+                 int nblk, mmsa_stream_t stream);
+int mmsa_chanattn_build(const float* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
+                        const float* temp, const float* Wp, uint16_t* hi, uint16_t* lo, int B, int c, int cpad,
+                        int heads, mmsa_stream_t stream);
+int mmsa_gffm_build(const float* E, uint16_t* xhi, uint16_t* xlo, uint16_t* yhi, uint16_t* ylo, int B, int c,
+                    int cpad, mmsa_stream_t stream);
+int mmsa_gelu_gate(const float* x, long ldx, float* y, long ldy, long rows, int C, mmsa_stream_t stream);
+int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int B, int H, int W, int C, mmsa_stream_t stream);
+int mmsa_ca_apply(const float* z, long ldz, const float* att, long lda, float* out, long ldo, int B, int H, int W,
+                  int C, mmsa_stream_t stream);
+
+/* --- tail (BK:316-337): out NCHW [B,C,Hc,Wc] = (cmap + bilinear(xtok)) * bn_scale + bn_shift; cmap image b starts at b*cstrideB --- */
+int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok, long ldx, const float* bn_scale,
+                   const float* bn_shift, float* out, int B, int Hc, int Wc, int Hx, int Wx, int C,
+                   mmsa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSA_H */

@@ -1,0 +1,413 @@
+// SAM ViT attention with decomposed relative position bias, for gfx950.
+//
+// Reference: Attention.forward IE:465-501 (scores = (q*scale) k^T + rel_h[q,kh] + rel_w[q,kw], softmax over ALL
+// keys incl. the zero-padded window tokens, then @v), window_partition / window_unpartition IE:504-551 and
+// add_decomposed_rel_pos IE:587-623 (bias from the UNSCALED q).
+//
+// One flash-style kernel serves both block kinds:
+//   * global blocks (window_size 0): one key set of H*W tokens per image (the reference materialises the
+//     [heads, 4096, 4096] score tensor; here it never leaves registers);
+//   * windowed blocks: key set = the ws*ws tokens of one window.  Window partition, the 64->70 zero padding,
+//     unpartition and the crop are pure index arithmetic in the load/store paths (no copies).  Pad tokens are
+//     zeros AFTER norm1, so their k and v equal the qkv bias (IE:401-407,519-520): they are synthesised from the
+//     bias vector instead of being run through the qkv GEMM, and they ARE attended to (no mask), like the reference.
+//
+// MFMA mapping (v_mfma_f32_16x16x32_bf16, split3 operands hi/lo):  S^T = K Q^T is computed "swapped" so a lane
+// owns one query column: softmax statistics are per-lane scalars (+2 shuffles across the 4 lane groups), and the
+// exponentiated tile is directly the B operand of O^T = V^T P^T (no LDS round trip, no transposes of P).  V^T
+// fragments come from row-major V in LDS through ds_read_b64_tr_b16.  A wave owns 32 queries (2 sub-tiles), a
+// workgroup 128; keys stream through LDS in blocks of 64 with register prefetch of the next block.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#define LDS_AS __attribute__((address_space(3)))
+
+struct AttnArgs {
+  const float* qkv; long ldq;    // [B*T, 3*D]: q | k | v, channel = head*HD + c   (IE:488 memory order)
+  const float* qkv_bias;         // [3*D]
+  const float* rp;               // [B, heads, T, KH+KW] rel-pos bias terms (relpos kernel below)
+  float* out; long ldo;          // [B*T, D], channel = head*HD + c (IE:498)
+  int B, H, W, heads, D;
+  int ws;                        // 0: global attention; >0: window size
+  int nWw;                       // windows per row (ceil(W/ws))
+  int Nk;                        // keys (= queries) per group: H*W or ws*ws
+  int KH, KW;                    // bias table extents (H,W) or (ws,ws)
+  int KHs, KWs;                  // odd LDS row strides for the bias tables
+  unsigned magicKW;              // ceil(2^24 / KW): j / KW == (j * magic) >> 24 for the j used here
+  float scale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
+  constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
+  constexpr int DT = HD / 16;            // output d tiles
+  constexpr int VSTR = (HD == 64) ? 160 : 96;  // V row stride in bytes (bank-conflict-free tr reads)
+  constexpr int KPL = NCH * 64 * 16;     // bytes per K plane
+  constexpr int VPL = 64 * VSTR;         // bytes per V plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Khi = smem;
+  unsigned char* Klo = Khi + KPL;
+  unsigned char* Vhi = Klo + KPL;
+  unsigned char* Vlo = Vhi + VPL;
+  float* bh = reinterpret_cast<float*>(Vlo + VPL);
+  float* bw = bh + 128 * a.KHs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, G = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int T = a.H * a.W;
+  const int nqb = (a.Nk + 127) / 128;
+  const int grp = blockIdx.x / nqb;
+  const int q0 = (blockIdx.x % nqb) * 128;
+  const int wi = a.ws ? grp / a.nWw : 0, wj = a.ws ? grp % a.nWw : 0;
+
+  // group index j -> token (or -1 for a zero-pad token, -2 for "does not exist")
+  auto token_of = [&](int j) -> int {
+    if (j >= a.Nk) return -2;
+    if (a.ws == 0) return j;
+    const int r = j / a.ws, c = j - r * a.ws;
+    const int hh = wi * a.ws + r, ww = wj * a.ws + c;
+    return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
+  };
+
+  const float* qkv_b = a.qkv + (long)b * T * a.ldq + head * HD;
+  const float* kbias = a.qkv_bias + a.D + head * HD;
+  const float* vbias = a.qkv_bias + 2 * a.D + head * HD;
+
+  // ---- bias tables for the block's 128 queries -> LDS
+  {
+    const int ncol = a.KH + a.KW;
+    const float* rpb = a.rp + ((long)b * a.heads + head) * T * ncol;
+    for (int i = tid; i < 128 * ncol; i += 256) {
+      const int ql = i / ncol, cidx = i - ql * ncol;
+      const int tq = token_of(q0 + ql);
+      const float v = tq >= 0 ? rpb[(long)tq * ncol + cidx] : 0.f;
+      if (cidx < a.KH) bh[ql * a.KHs + cidx] = v;
+      else bw[ql * a.KWs + (cidx - a.KH)] = v;
+    }
+  }
+
+  // ---- Q fragments (B operand: B[k = 8G + j][col = query l15]) for the wave's two 16-query sub-tiles
+  bf16x8 qh[2][KS], ql_[2][KS];
+  int tq_sub[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int jq = q0 + wave * 32 + sub * 16 + l15;
+    const int tq = token_of(jq);
+    tq_sub[sub] = tq;
+    const float* qp = qkv_b + (long)(tq >= 0 ? tq : 0) * a.ldq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float4 v0 = *reinterpret_cast<const float4*>(qp + ks * 32 + 8 * G);
+      float4 v1 = *reinterpret_cast<const float4*>(qp + ks * 32 + 8 * G + 4);
+      v0.x *= a.scale; v0.y *= a.scale; v0.z *= a.scale; v0.w *= a.scale;
+      v1.x *= a.scale; v1.y *= a.scale; v1.z *= a.scale; v1.w *= a.scale;
+      uint2 h0, l0, h1, l1;
+      split4(v0, h0, l0);
+      split4(v1, h1, l1);
+      uint4 hh4 = make_uint4(h0.x, h0.y, h1.x, h1.y), ll4 = make_uint4(l0.x, l0.y, l1.x, l1.y);
+      qh[sub][ks] = __builtin_bit_cast(bf16x8, hh4);
+      ql_[sub][ks] = __builtin_bit_cast(bf16x8, ll4);
+    }
+  }
+
+  // ---- K/V staging: thread -> (key = tid/4, quarter = tid%4), HD/4 floats of K and of V
+  constexpr int NF4 = HD / 16;  // float4 per thread per operand
+  const int skey = tid >> 2, squart = tid & 3;
+  float4 rk[NF4], rv[NF4];
+#define LOAD_KV(kb_)                                                        \
+  do {                                                                      \
+    const int tk_ = token_of((kb_) * 64 + skey);                            \
+    _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                       \
+      const int c = squart * (HD / 4) + 4 * i;                              \
+      if (tk_ >= 0) {                                                       \
+        const float* p = qkv_b + (long)tk_ * a.ldq + c;                     \
+        rk[i] = *reinterpret_cast<const float4*>(p + a.D);                  \
+        rv[i] = *reinterpret_cast<const float4*>(p + 2 * a.D);              \
+      } else if (tk_ == -1) {                                               \
+        rk[i] = *reinterpret_cast<const float4*>(kbias + c);                \
+        rv[i] = *reinterpret_cast<const float4*>(vbias + c);                \
+      } else {                                                              \
+        rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);                            \
+        rv[i] = rk[i];                                                      \
+      }                                                                     \
+    }                                                                       \
+  } while (0)
+#define STORE_KV()                                                          \
+  do {                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                       \
+      const int c = squart * (HD / 4) + 4 * i;                              \
+      uint2 h, l;                                                           \
+      split4(rk[i], h, l);                                                  \
+      const int ko = (c >> 3) * (64 * 16) + skey * 16 + (c & 7) * 2;        \
+      *reinterpret_cast<uint2*>(Khi + ko) = h;                              \
+      *reinterpret_cast<uint2*>(Klo + ko) = l;                              \
+      split4(rv[i], h, l);                                                  \
+      const int vo = skey * VSTR + c * 2;                                   \
+      *reinterpret_cast<uint2*>(Vhi + vo) = h;                              \
+      *reinterpret_cast<uint2*>(Vlo + vo) = l;                              \
+    }                                                                       \
+  } while (0)
+
+  f32x4 o[2][DT];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[s][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};
+  float l_run[2] = {0.f, 0.f};
+
+  const int nkb = (a.Nk + 63) / 64;
+  LOAD_KV(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();  // previous block fully consumed (also orders the bias-table fill on kb == 0)
+    STORE_KV();
+    __syncthreads();
+    if (kb + 1 < nkb) LOAD_KV(kb + 1);
+
+    // ---- S^T tiles: [t = key tile][sub]; lane holds keys 16t + 4G + r (r = reg), query column l15
+    f32x4 s[2][4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[sub][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (ks * 4 + G) * (64 * 16) + (16 * t + l15) * 16;
+        const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(Khi + off);
+        const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(Klo + off);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[sub][ks], s[sub][t], 0, 0, 0);
+          s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql_[sub][ks], s[sub][t], 0, 0, 0);
+          s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[sub][ks], s[sub][t], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- bias, mask, online softmax
+    bf16x8 ph[2][2], pl[2][2];  // [sub][k-step of 32 keys]
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int qloc = wave * 32 + sub * 16 + l15;
+      const float* bhq = bh + qloc * a.KHs;
+      const float* bwq = bw + qloc * a.KWs;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kb * 64 + 16 * t + 4 * G + r;
+          float v;
+          if (j < a.Nk) {
+            const int kh = (int)(((unsigned)j * a.magicKW) >> 24);
+            const int kw = j - kh * a.KW;
+            v = s[sub][t][r] + bhq[kh] + bwq[kw];
+          } else {
+            v = -INFINITY;
+          }
+          s[sub][t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[sub], mx);
+      const float alpha = __expf(m_run[sub] - m_new);
+      m_run[sub] = m_new;
+      float psum = 0.f;
+      unsigned short hbits[16], lbits[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[sub][t][r] - m_new);
+          psum += p;
+          split_bf16(p, hbits[t * 4 + r], lbits[t * 4 + r]);
+        }
+      l_run[sub] = l_run[sub] * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        o[sub][d][0] *= alpha; o[sub][d][1] *= alpha; o[sub][d][2] *= alpha; o[sub][d][3] *= alpha;
+      }
+      // MFMA k-slot (G, j): j < 4 -> key 16*(2*s2) + 4G + j ; j >= 4 -> key 16*(2*s2+1) + 4G + (j-4)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          vh[j] = (short)hbits[(2 * s2 + (j >> 2)) * 4 + (j & 3)];
+          vl[j] = (short)lbits[(2 * s2 + (j >> 2)) * 4 + (j & 3)];
+        }
+        ph[sub][s2] = vh;
+        pl[sub][s2] = vl;
+      }
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        // lane i = 4q'+p of a 16-lane group addresses row q' (key), columns 4p..4p+3 of the 4x16 block
+        const int row0 = 32 * s2 + 4 * G + (l15 >> 2);
+        const int voff = row0 * VSTR + (16 * d + 4 * (l15 & 3)) * 2;
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + 16 * VSTR));
+        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
+        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + 16 * VSTR));
+        const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[sub][s2], o[sub][d], 0, 0, 0);
+          o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[sub][s2], o[sub][d], 0, 0, 0);
+          o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[sub][s2], o[sub][d], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][16d + 4G .. +3] / l  -> out[token(q)][head*HD + ...]
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    float l = l_run[sub];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int tq = tq_sub[sub];
+    if (tq >= 0) {
+      float* op = a.out + ((long)b * T + tq) * a.ldo + head * HD + 4 * G;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const float4 v = make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv);
+        *reinterpret_cast<float4*>(op + 16 * d) = v;
+      }
+    }
+  }
+}
+
+extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo,
+                              int B, int H, int W, int heads, int head_dim, int window_size, float scale,
+                              hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv && qkv_bias && rp && out, "attention: null pointer");
+  MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0 && window_size >= 0, "attention: bad shape");
+  MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "attention: head_dim %d not supported (32 or 64)", head_dim);
+  const int D = heads * head_dim;
+  MMSA_CHECK_ARG(ldq >= 3L * D && (ldq & 3) == 0 && ldo >= D && (ldo & 3) == 0, "attention: bad leading dimensions");
+  MMSA_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)qkv_bias)) & 15) == 0, "attention: pointers must be 16-byte aligned");
+  AttnArgs a;
+  a.qkv = qkv; a.ldq = ldq; a.qkv_bias = qkv_bias; a.rp = rp; a.out = out; a.ldo = ldo;
+  a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
+  int ngroups;
+  if (window_size > 0) {
+    a.nWw = cdiv(W, window_size);
+    ngroups = cdiv(H, window_size) * a.nWw;
+    a.Nk = window_size * window_size;
+    a.KH = a.KW = window_size;
+  } else {
+    a.nWw = 1;
+    ngroups = 1;
+    a.Nk = H * W;
+    a.KH = H;
+    a.KW = W;
+  }
+  a.KHs = a.KH | 1;
+  a.KWs = a.KW | 1;
+  a.magicKW = (unsigned)(((1u << 24) + a.KW - 1) / a.KW);
+  for (int j = 0; j < a.Nk; ++j) {  // the kernel's multiply-shift division must be exact for every key index
+    if ((int)(((unsigned long long)(unsigned)j * a.magicKW) >> 24) != j / a.KW || (unsigned long long)j * a.magicKW >= (1ull << 32)) {
+      mmsa_set_error("attention: key grid too large for the in-kernel index arithmetic (Nk=%d KW=%d)", a.Nk, a.KW);
+      return MMSA_ERR_ARG;
+    }
+  }
+  const int VSTR = head_dim == 64 ? 160 : 96;
+  const size_t smem = 2 * (head_dim / 8) * 64 * 16 + 2 * 64 * VSTR + (size_t)128 * (a.KHs + a.KWs) * sizeof(float);
+  MMSA_CHECK_ARG(smem <= 160 * 1024, "attention: bias tables do not fit LDS (KH=%d KW=%d)", a.KH, a.KW);
+  dim3 grid(ngroups * cdiv(a.Nk, 128), heads, B);
+  if (head_dim == 64) {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), smem, stream, a);
+  } else {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_kernel<32>, grid, dim3(256), smem, stream, a);
+  }
+  MMSA_CHECK_LAUNCH("attention");
+  return MMSA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rel-pos bias terms (add_decomposed_rel_pos IE:609-617), exact fp32:
+//   rp[b,head,tok,kh]      = sum_c q[tok,c] * Rh[qh(tok), kh, c]
+//   rp[b,head,tok,KH + kw] = sum_c q[tok,c] * Rw[qw(tok), kw, c]
+// with (qh,qw) = token coords in its window (windowed blocks) or in the image (global blocks).
+// Rh/Rw are the gathered tables get_rel_pos(q,k,rel_pos)[q,k,:] (IE:554-584), built once at pack time.
+// Block = one image row (H-term) or one image column (W-term) of tokens x one head.
+template <int HD>
+__global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ qkv, long ldq, const float* __restrict__ Rh,
+                                                     const float* __restrict__ Rw, float* __restrict__ rp,
+                                                     int H, int W, int heads, int ws, int KH, int KW) {
+  constexpr int RS = HD + 4;
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int T = H * W;
+  const bool isH = (int)blockIdx.x < H;
+  const int line = isH ? blockIdx.x : blockIdx.x - H;   // image row (H-term) or column (W-term)
+  const int L = isH ? W : H;                             // tokens on the line
+  const int KK = isH ? KH : KW;
+  const int qidx = ws ? line % ws : line;
+  const float* tab = (isH ? Rh : Rw) + (long)qidx * KK * HD;
+  float* sT = smf;                 // [KK][RS]
+  float* sQ = smf + (long)KK * RS; // [<=64][RS]
+  for (int i = threadIdx.x; i < KK * (HD / 4); i += 256) {
+    const int k = i / (HD / 4), c = (i % (HD / 4)) * 4;
+    *reinterpret_cast<float4*>(sT + k * RS + c) = *reinterpret_cast<const float4*>(tab + (long)k * HD + c);
+  }
+  const int ncol = KH + KW;
+  float* rpb = rp + ((long)b * heads + head) * T * ncol + (isH ? 0 : KH);
+  for (int t0 = 0; t0 < L; t0 += 64) {
+    const int nt = min(64, L - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * (HD / 4); i += 256) {
+      const int t = i / (HD / 4), c = (i % (HD / 4)) * 4;
+      const int tok = isH ? line * W + (t0 + t) : (t0 + t) * W + line;
+      *reinterpret_cast<float4*>(sQ + t * RS + c) =
+          *reinterpret_cast<const float4*>(qkv + ((long)b * T + tok) * ldq + head * HD + c);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * KK; i += 256) {
+      const int t = i / KK, k = i - t * KK;
+      const float* qv = sQ + t * RS;
+      const float* tv = sT + k * RS;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(qv + c);
+        const float4 y = *reinterpret_cast<const float4*>(tv + c);
+        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+      const int tok = isH ? line * W + (t0 + t) : (t0 + t) * W + line;
+      rpb[(long)tok * ncol + k] = acc;
+    }
+  }
+}
+
+extern "C" int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp,
+                                int B, int H, int W, int heads, int head_dim, int window_size, hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv && Rh && Rw && rp, "relpos_bias: null pointer");
+  MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "relpos_bias: head_dim %d not supported", head_dim);
+  MMSA_CHECK_ARG((ldq & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)Rh) | ((uintptr_t)Rw)) & 15) == 0, "relpos_bias: alignment");
+  const int KH = window_size ? window_size : H, KW = window_size ? window_size : W;
+  const int KKmax = KH > KW ? KH : KW;
+  const size_t smem = (size_t)(KKmax + 64) * (head_dim + 4) * sizeof(float);
+  MMSA_CHECK_ARG(smem <= 64 * 1024, "relpos_bias: table slice does not fit LDS (K=%d)", KKmax);
+  dim3 grid(H + W, heads, B);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(relpos_kernel<64>, grid, dim3(256), smem, stream, qkv, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW);
+  else
+    hipLaunchKernelGGL(relpos_kernel<32>, grid, dim3(256), smem, stream, qkv, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW);
+  MMSA_CHECK_LAUNCH("relpos_bias");
+  return MMSA_OK;
+}

@@ -1,0 +1,88 @@
+// Shared helpers for the mmsa HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define MMSA_OK 0
+#define MMSA_ERR_ARG (-1)
+#define MMSA_ERR_LAUNCH (-2)
+
+extern "C" const char* mmsa_last_error(void);
+void mmsa_set_error(const char* fmt, ...);
+
+#define MMSA_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      mmsa_set_error(__VA_ARGS__);           \
+      return MMSA_ERR_ARG;                   \
+    }                                        \
+  } while (0)
+
+#define MMSA_CHECK_LAUNCH(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      mmsa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return MMSA_ERR_LAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B operand (8 bf16 = 4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 accumulator
+
+// ---- bf16 hi/lo split of an fp32 value ("split3" operands): x ~= hi + lo with ~16 mantissa bits.
+// Round-to-nearest-even on the raw bits; inputs are finite activations/weights (NaN not preserved).
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+  hi = f32_to_bf16_rn(x);
+  lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+}
+
+// split 4 floats -> 4 hi (packed in 2 dwords) + 4 lo
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+  split_bf16(v.x, h0, l0);
+  split_bf16(v.y, h1, l1);
+  split_bf16(v.z, h2, l2);
+  split_bf16(v.w, h3, l3);
+  hi.x = (unsigned)h0 | ((unsigned)h1 << 16);
+  hi.y = (unsigned)h2 | ((unsigned)h3 << 16);
+  lo.x = (unsigned)l0 | ((unsigned)l1 << 16);
+  lo.y = (unsigned)l2 | ((unsigned)l3 << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activation codes shared by the GEMM epilogue and the conv kernels
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_HSWISH = 4, ACT_SIGMOID = 5 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));  // exact-erf GELU (nn.GELU default)
+    case ACT_RELU: return fmaxf(x, 0.0f);
+    case ACT_RELU6: return fminf(fmaxf(x, 0.0f), 6.0f);
+    case ACT_HSWISH: return x * (fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) / 6.0f);
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    default: return x;
+  }
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

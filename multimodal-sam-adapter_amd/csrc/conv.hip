@@ -1,0 +1,138 @@
+// Spatial convolutions of the encoder path on NHWC fp32 maps (stride 1, "same" padding) and the
+// NCHW -> patch-matrix gather that turns the strided patchify convolutions into GEMMs.
+//   dwconv_nhwc : depthwise k x k (ConvNeXt 7x7 TC:69-70,102; MobileNetV2 dw3x3 AM:288; ConvFFN DWConv AM:459).
+//   gconv_nhwc  : grouped conv with cin_g -> cout_g channels per group (GFE qkv1 1x1/g32 AM:87, qkv2 3x3/g32
+//                 AM:88, gated-MLP dwconv 3x3 groups=C with 2->2 channels per group AM:123-124).
+//   im2col_nchw : patch matrix for PatchEmbed 16x16 s16 (IE:658-663) and the ConvNeXt stem 4x4 s4 (TC:297-304),
+//                 K order = (c, kh, kw) = the reference weight's flattened order, zero padded to Kpad.
+// These are fp32 VALU kernels (exact fp32 like the reference), 16-byte channel vectors per lane.
+#include "common.h"
+
+// weights repacked tap-major: w[(kh*k+kw)*C + c]
+__global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restrict__ x, long ldx, long xstrideB,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, long ldy, long ystrideB,
+                                                          int B, int H, int W, int C, int k, int act) {
+  const int c4n = C >> 2;
+  const long total = (long)B * H * W * c4n;
+  const int pad = k >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long t = i / c4n;
+    const int ww = (int)(t % W);
+    t /= W;
+    const int hh = (int)(t % H);
+    const int b = (int)(t / H);
+    const float* xb = x + (long)b * xstrideB;
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < k; ++kh) {
+      const int ih = hh + kh - pad;
+      if (ih < 0 || ih >= H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int iw = ww + kw - pad;
+        if (iw < 0 || iw >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(xb + ((long)ih * W + iw) * ldx + c);
+        const float4 f = *reinterpret_cast<const float4*>(w + (long)(kh * k + kw) * C + c);
+        acc.x += v.x * f.x; acc.y += v.y * f.y; acc.z += v.z * f.z; acc.w += v.w * f.w;
+      }
+    }
+    acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+    *reinterpret_cast<float4*>(y + (long)b * ystrideB + ((long)hh * W + ww) * ldy + c) = acc;
+  }
+}
+
+extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
+                                float* y, long ldy, long ystrideB, int B, int H, int W, int C, int k, int act,
+                                hipStream_t stream) {
+  MMSA_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
+  MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "dwconv_nhwc: odd kernel <= 7 expected, got %d", k);
+  MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (xstrideB & 3) == 0 && (ystrideB & 3) == 0, "dwconv_nhwc: C/ld must be multiples of 4");
+  const long total = (long)B * H * W * (C >> 2);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, B, H, W, C, k, act);
+  MMSA_CHECK_LAUNCH("dwconv_nhwc");
+  return MMSA_OK;
+}
+
+// Grouped conv.  Weights repacked as w[g][tap][ci][co] (co fastest).  One lane per (pixel, output channel);
+// lanes of a wavefront cover consecutive output channels -> coalesced weight reads and stores, broadcast-ish
+// activation reads (all output channels of a group read the same cin_g inputs).
+__global__ __launch_bounds__(256) void gconv_nhwc_kernel(const float* __restrict__ x, long ldx,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ y, long ldy,
+                                                         int B, int H, int W, int G, int cin_g, int cout_g, int k, int act) {
+  const int Cout = G * cout_g;
+  const long total = (long)B * H * W * Cout;
+  const int pad = k >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int oc = (int)(i % Cout);
+    long t = i / Cout;
+    const int ww = (int)(t % W);
+    t /= W;
+    const int hh = (int)(t % H);
+    const int b = (int)(t / H);
+    const int g = oc / cout_g, co = oc - g * cout_g;
+    const float* wg = w + (long)g * k * k * cin_g * cout_g + co;
+    float acc = bias ? bias[oc] : 0.f;
+    for (int kh = 0; kh < k; ++kh) {
+      const int ih = hh + kh - pad;
+      if (ih < 0 || ih >= H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int iw = ww + kw - pad;
+        if (iw < 0 || iw >= W) continue;
+        const float* xp = x + (((long)b * H + ih) * W + iw) * ldx + g * cin_g;
+        const float* wp = wg + (long)(kh * k + kw) * cin_g * cout_g;
+        for (int ci = 0; ci < cin_g; ++ci) acc += xp[ci] * wp[(long)ci * cout_g];
+      }
+    }
+    y[(((long)b * H + hh) * W + ww) * ldy + oc] = apply_act(acc, act);
+  }
+}
+
+extern "C" int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                               int B, int H, int W, int G, int cin_g, int cout_g, int k, int act, hipStream_t stream) {
+  MMSA_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && G > 0 && cin_g > 0 && cout_g > 0, "gconv_nhwc: bad args");
+  MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "gconv_nhwc: odd kernel <= 7 expected, got %d", k);
+  const long total = (long)B * H * W * G * cout_g;
+  int blocks = cdiv(total, 256);
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL(gconv_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, B, H, W, G, cin_g, cout_g, k, act);
+  MMSA_CHECK_LAUNCH("gconv_nhwc");
+  return MMSA_OK;
+}
+
+// out[(b,ph,pw)][(c,kh,kw)] = x[b, c0 + c, ph*p + kh, pw*p + kw]; columns >= Cin*p*p are zero.
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, int Ctot, int c0, int Cin,
+                                                          int H, int W, int p, float* __restrict__ out, int Kpad, long total) {
+  const int Hp = H / p, Wp = W / p;
+  const int Kreal = Cin * p * p;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % Kpad);
+    long t = i / Kpad;
+    float v = 0.f;
+    if (kk < Kreal) {
+      const int pw = (int)(t % Wp);
+      const long t2 = t / Wp;
+      const int ph = (int)(t2 % Hp);
+      const int b = (int)(t2 / Hp);
+      const int kw = kk % p;
+      const int kh = (kk / p) % p;
+      const int c = kk / (p * p);
+      v = x[(((long)b * Ctot + c0 + c) * H + ph * p + kh) * W + pw * p + kw];
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, int W, int p,
+                                float* out, int Kpad, hipStream_t stream) {
+  MMSA_CHECK_ARG(x && out && B > 0 && Cin > 0 && c0 >= 0 && c0 + Cin <= Ctot && p > 0, "im2col_nchw: bad args");
+  MMSA_CHECK_ARG(H % p == 0 && W % p == 0 && Kpad >= Cin * p * p, "im2col_nchw: H,W must be multiples of the patch; Kpad >= Cin*p*p");
+  const long total = (long)B * (H / p) * (W / p) * Kpad;
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(blocks), dim3(256), 0, stream, x, Ctot, c0, Cin, H, W, p, out, Kpad, total);
+  MMSA_CHECK_LAUNCH("im2col_nchw");
+  return MMSA_OK;
+}

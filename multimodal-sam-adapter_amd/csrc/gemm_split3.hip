@@ -1,0 +1,266 @@
+// split3 GEMM for gfx950:  C[M,N] = epilogue( A[M,K] (fp32) x W[N,K]^T (bf16 hi/lo planes) )
+//
+// Every Linear / 1x1-conv / patchify-conv / conv-transpose of the encoder path goes through this
+// kernel (reference call sites: IE:488,499,162-167 qkv/proj/MLP; TC:107-111 pointwise convs;
+// AM:947-950 fc1-4; OPS/modules/ms_deform_attn.py:103-129 value/offset/output projections;
+// BK:55,324 `up`).  The reference computes these in fp32; single-pass bf16 misses the 1e-3 parity
+// gate, so each operand is split x = hi + lo (two bf16, ~16 mantissa bits) and three
+// MFMA products hi*hi + hi*lo + lo*hi are accumulated in fp32.
+//
+// Tiling: 128x128 block tile, BK = 32 (= one v_mfma_f32_16x16x32_bf16 k-step), 4 waves (2x2), each
+// wave 64x64 = 4x4 MFMA tiles x 3 products.  The MFMA "A" operand is the WEIGHT tile and the "B"
+// operand the ACTIVATION tile, so a lane's 4 accumulator registers are 4 consecutive output columns
+// -> 16-byte epilogue loads/stores.  Activations are split to hi/lo while being staged to LDS;
+// weights are pre-split at pack time.  LDS image per plane: [k-chunk g=0..3][row 0..127][8 bf16], which
+// makes every ds_read_b128 fragment read bank-conflict free (16 lanes x 16 B = one 256-B bank row).
+// Two LDS stages + register prefetch: one barrier per k-tile.
+#include "common.h"
+
+struct GemmArgs {
+  const float* A; long lda; long strideA;
+  const unsigned short* Whi; const unsigned short* Wlo; long strideW;
+  const float* bias; long strideBias;
+  const float* colscale;
+  const float* resid; long ldr; long strideR; int resid_mod; float beta;
+  float* C; long ldc; long strideC;
+  int M, N, K;
+  int act; float alpha;
+  int out_mode; int ps_H, ps_W, ps_C;   // out_mode 1: 2x2 pixel-shuffle store (conv-transpose 2x2 s2)
+};
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define PLANE_BYTES (4 * 128 * 16)     // 8 KiB per bf16 plane per stage
+#define STAGE_BYTES (4 * PLANE_BYTES)  // Ahi, Alo, Whi, Wlo
+
+__global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int bz = blockIdx.z;
+
+  const float* A = a.A + (long)bz * a.strideA;
+  const unsigned short* Whi = a.Whi + (long)bz * a.strideW;
+  const unsigned short* Wlo = a.Wlo + (long)bz * a.strideW;
+  const int K = a.K;
+
+  // ---- global load assignment
+  // activations: 4 x float4 per thread: row = (tid>>3) + 32*i, float col = (tid&7)*4
+  const int a_c4 = (tid & 7) * 4;
+  auto a_row_ptr = [&](int i) {
+    int r = m0 + (tid >> 3) + 32 * i;
+    r = r < a.M ? r : a.M - 1;
+    return A + (long)r * a.lda + a_c4;
+  };
+  const float* a_ptr0 = a_row_ptr(0);
+  const float* a_ptr1 = a_row_ptr(1);
+  const float* a_ptr2 = a_row_ptr(2);
+  const float* a_ptr3 = a_row_ptr(3);
+  const int a_lds_off = ((tid & 7) >> 1) * 2048 + (tid >> 3) * 16 + (tid & 1) * 8;  // + 32*16*i
+  // weights: 2 x uint4 per plane per thread: row = (tid>>2) + 64*i, chunk = tid&3
+  auto w_row_off = [&](int i) {
+    int r = n0 + (tid >> 2) + 64 * i;
+    r = r < a.N ? r : a.N - 1;
+    return (long)r * K + (tid & 3) * 8;
+  };
+  const unsigned short* w_hi_ptr0 = Whi + w_row_off(0);
+  const unsigned short* w_hi_ptr1 = Whi + w_row_off(1);
+  const unsigned short* w_lo_ptr0 = Wlo + w_row_off(0);
+  const unsigned short* w_lo_ptr1 = Wlo + w_row_off(1);
+  const int w_lds_off = (tid & 3) * 2048 + (tid >> 2) * 16;  // + 64*16*i
+
+  float4 ra0, ra1, ra2, ra3;
+  uint4 rwh0, rwh1, rwl0, rwl1;
+
+#define LOAD_GLOBAL(k0)                                                   \
+  do {                                                                    \
+    ra0 = *reinterpret_cast<const float4*>(a_ptr0 + (k0));                \
+    ra1 = *reinterpret_cast<const float4*>(a_ptr1 + (k0));                \
+    ra2 = *reinterpret_cast<const float4*>(a_ptr2 + (k0));                \
+    ra3 = *reinterpret_cast<const float4*>(a_ptr3 + (k0));                \
+    rwh0 = *reinterpret_cast<const uint4*>(w_hi_ptr0 + (k0));             \
+    rwh1 = *reinterpret_cast<const uint4*>(w_hi_ptr1 + (k0));             \
+    rwl0 = *reinterpret_cast<const uint4*>(w_lo_ptr0 + (k0));             \
+    rwl1 = *reinterpret_cast<const uint4*>(w_lo_ptr1 + (k0));             \
+  } while (0)
+
+#define STORE_A(base, reg, i)                                                               \
+  do {                                                                                      \
+    uint2 hi_, lo_;                                                                         \
+    split4(reg, hi_, lo_);                                                                  \
+    *reinterpret_cast<uint2*>((base) + 0 * PLANE_BYTES + a_lds_off + (i) * 512) = hi_;      \
+    *reinterpret_cast<uint2*>((base) + 1 * PLANE_BYTES + a_lds_off + (i) * 512) = lo_;      \
+  } while (0)
+
+#define STORE_LDS(stage_)                                                              \
+  do {                                                                                 \
+    unsigned char* sb_ = smem + (stage_) * STAGE_BYTES;                                \
+    STORE_A(sb_, ra0, 0); STORE_A(sb_, ra1, 1); STORE_A(sb_, ra2, 2); STORE_A(sb_, ra3, 3); \
+    *reinterpret_cast<uint4*>(sb_ + 2 * PLANE_BYTES + w_lds_off) = rwh0;               \
+    *reinterpret_cast<uint4*>(sb_ + 2 * PLANE_BYTES + w_lds_off + 1024) = rwh1;        \
+    *reinterpret_cast<uint4*>(sb_ + 3 * PLANE_BYTES + w_lds_off) = rwl0;               \
+    *reinterpret_cast<uint4*>(sb_ + 3 * PLANE_BYTES + w_lds_off + 1024) = rwl1;        \
+  } while (0)
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frag_a_off = g * 2048 + (wm * 64 + l15) * 16;  // + mi*256
+  const int frag_w_off = g * 2048 + (wn * 64 + l15) * 16;  // + ni*256
+
+  const int nk = K / BK;
+  LOAD_GLOBAL(0);
+  STORE_LDS(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) LOAD_GLOBAL((kt + 1) * BK);
+    const unsigned char* base = smem + stage * STAGE_BYTES;
+    bf16x8 ah[4], al[4], wh[4], wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(base + 0 * PLANE_BYTES + frag_a_off + i * 256);
+      al[i] = *reinterpret_cast<const bf16x8*>(base + 1 * PLANE_BYTES + frag_a_off + i * 256);
+      wh[i] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_BYTES + frag_w_off + i * 256);
+      wl[i] = *reinterpret_cast<const bf16x8*>(base + 3 * PLANE_BYTES + frag_w_off + i * 256);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+      }
+    if (kt + 1 < nk) STORE_LDS(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. +3]
+  const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
+  const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
+  float* C = a.C + (long)bz * a.strideC;
+  const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + l15;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+      if (n >= a.N) continue;
+      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+      long drow = m;
+      int dcol = n;
+      if (a.out_mode == 1) {
+        const int ij = n / a.ps_C;
+        dcol = n - ij * a.ps_C;
+        const int w_ = m % a.ps_W;
+        const int t_ = m / a.ps_W;
+        const int h_ = t_ % a.ps_H;
+        const int b_ = t_ / a.ps_H;
+        drow = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
+      }
+      const long rrow = a.resid_mod > 0 ? (drow % a.resid_mod) : drow;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r < a.N) {
+          float x = v[r];
+          if (bias) x += bias[n + r];
+          x = apply_act(x, a.act);
+          x *= a.alpha;
+          if (a.colscale) x *= a.colscale[dcol + r];
+          v[r] = x;
+        }
+      }
+      if (vec_ok && n + 3 < a.N) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (resid) {
+          const float4 rr = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
+          o.x += a.beta * rr.x; o.y += a.beta * rr.y; o.z += a.beta * rr.z; o.w += a.beta * rr.w;
+        }
+        *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < a.N) {
+            float x = v[r];
+            if (resid) x += a.beta * resid[rrow * a.ldr + dcol + r];
+            C[drow * a.ldc + dcol + r] = x;
+          }
+        }
+      }
+    }
+  }
+}
+
+// C-ABI entry: see include/mmsa.h for the contract.
+extern "C" int mmsa_gemm_split3(const float* A, long lda, long strideA,
+                                const unsigned short* Whi, const unsigned short* Wlo, long strideW,
+                                const float* bias, long strideBias, const float* colscale,
+                                const float* resid, long ldr, long strideR, int resid_mod, float beta,
+                                float* C, long ldc, long strideC,
+                                int M, int N, int K, int batch, int act, float alpha,
+                                int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream) {
+  MMSA_CHECK_ARG(A && Whi && Wlo && C, "gemm_split3: null pointer");
+  MMSA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_split3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  MMSA_CHECK_ARG(K % BK == 0, "gemm_split3: K=%d must be a multiple of %d (producers pad)", K, BK);
+  MMSA_CHECK_ARG((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "gemm_split3: A must be 16-byte aligned with lda%%4==0 (lda=%ld)", lda);
+  MMSA_CHECK_ARG(lda >= K, "gemm_split3: lda=%ld < K=%d", lda, K);
+  MMSA_CHECK_ARG((((uintptr_t)Whi) & 15) == 0 && (((uintptr_t)Wlo) & 15) == 0, "gemm_split3: weight planes must be 16-byte aligned");
+  MMSA_CHECK_ARG((((uintptr_t)C) & 15) == 0 && (!resid || (((uintptr_t)resid) & 15) == 0), "gemm_split3: C/resid must be 16-byte aligned");
+  MMSA_CHECK_ARG(act >= ACT_NONE && act <= ACT_SIGMOID, "gemm_split3: bad act %d", act);
+  if (out_mode == 1) {
+    MMSA_CHECK_ARG(ps_H > 0 && ps_W > 0 && ps_C > 0 && N == 4 * ps_C && M % (ps_H * ps_W) == 0 && (ps_C & 3) == 0,
+                   "gemm_split3: pixel-shuffle store needs N==4*C, M%%(H*W)==0");
+    MMSA_CHECK_ARG(ldc >= ps_C, "gemm_split3: ldc < C");
+  } else {
+    MMSA_CHECK_ARG(out_mode == 0, "gemm_split3: bad out_mode %d", out_mode);
+    MMSA_CHECK_ARG(ldc >= N, "gemm_split3: ldc=%ld < N=%d", ldc, N);
+  }
+  GemmArgs a;
+  a.A = A; a.lda = lda; a.strideA = strideA;
+  a.Whi = Whi; a.Wlo = Wlo; a.strideW = strideW;
+  a.bias = bias; a.strideBias = strideBias; a.colscale = colscale;
+  a.resid = resid; a.ldr = ldr; a.strideR = strideR; a.resid_mod = resid_mod; a.beta = beta;
+  a.C = C; a.ldc = ldc; a.strideC = strideC;
+  a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
+  a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
+  dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
+  hipLaunchKernelGGL(gemm_split3_kernel, grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  MMSA_CHECK_LAUNCH("gemm_split3");
+  return MMSA_OK;
+}
+
+// ---- weight pre-pack: fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad] (zero padded)
+__global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
+                                    unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const long total = (long)rows * cols_pad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+    unsigned short h = 0, l = 0;
+    if (c < cols) split_bf16(src[(long)r * ld + c], h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+
+extern "C" int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad,
+                                 unsigned short* hi, unsigned short* lo, hipStream_t stream) {
+  MMSA_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && cols_pad >= cols, "split_planes: bad args");
+  const long total = (long)rows * cols_pad;
+  int blocks = cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, hi, lo);
+  MMSA_CHECK_LAUNCH("split_planes");
+  return MMSA_OK;
+}

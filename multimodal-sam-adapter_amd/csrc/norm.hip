@@ -1,0 +1,255 @@
+// Normalisation and reduction kernels (HBM-bound; 16-byte vector access, wavefront reductions).
+//   layernorm_rows : per-token LayerNorm over channels.  Covers nn.LayerNorm(eps 1e-6) of the ViT blocks
+//                    (IE:367,377), injector/extractor norms (AM:479-487,519-520), ConvNeXt LN2d in NHWC
+//                    (mmpretrain_custom/models/utils/norm.py:51-90; TC:103-106,329,377) and the
+//                    WithBias_LayerNorm of GFE (AM:51-74, eps 1e-5, biased variance).
+//   colstats       : per-(batch, channel) sums over the H*W rows of an NHWC map (for GFFM's
+//                    nn.LayerNorm(H*W) AM:241,265; F.normalize over HW AM:100-101; avg-pool AM:159).
+//   lnhw_apply     : GFFM LayerNorm over the spatial axis + FFRM recalibration, fused apply pass.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b, float eps,
+    float* __restrict__ y, long ldy, float* __restrict__ y2, long ldy2, int rows, int C,
+    int map_mode, int map_H, int map_W) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      v[i] = *reinterpret_cast<const float4*>(xr + c);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  long orow = row;
+  long ocol = 0;
+  if (map_mode == 1) {  // 2x2 patchify: token (b,h,w) -> row (b,h/2,w/2), column block (h&1)*2+(w&1)
+    const int ww = row % map_W;
+    const int t = row / map_W;
+    const int hh = t % map_H;
+    const int bb = t / map_H;
+    orow = ((long)bb * (map_H / 2) + (hh >> 1)) * (map_W / 2) + (ww >> 1);
+    ocol = (long)(((hh & 1) << 1) | (ww & 1)) * C;
+  }
+  float* yr = y + orow * ldy + ocol;
+  float* y2r = y2 ? y2 + (long)row * ldy2 : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      const float4 bb = *reinterpret_cast<const float4*>(b + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+      o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+      o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+      *reinterpret_cast<float4*>(yr + c) = o;
+      if (y2r) {
+        o.x += v[i].x; o.y += v[i].y; o.z += v[i].z; o.w += v[i].w;
+        *reinterpret_cast<float4*>(y2r + c) = o;
+      }
+    }
+  }
+}
+
+extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps,
+                                   float* y, long ldy, float* y2, long ldy2, int rows, int C,
+                                   int map_mode, int map_H, int map_W, hipStream_t stream) {
+  MMSA_CHECK_ARG(x && w && b && y && rows > 0 && C > 0, "layernorm_rows: bad args");
+  MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy2 & 3) == 0, "layernorm_rows: C/ld must be multiples of 4");
+  MMSA_CHECK_ARG(C <= 4096, "layernorm_rows: C=%d > 4096", C);
+  MMSA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)b) | ((uintptr_t)y2)) & 15) == 0, "layernorm_rows: pointers must be 16-byte aligned");
+  if (map_mode == 1) MMSA_CHECK_ARG(map_H > 0 && map_W > 0 && (map_H & 1) == 0 && (map_W & 1) == 0 && rows % (map_H * map_W) == 0 && y2 == nullptr,
+                                    "layernorm_rows: patchify map needs even H,W");
+  dim3 grid(cdiv(rows, 4)), block(256);
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, rows, C, map_mode, map_H, map_W)
+  if (C <= 256) LN_LAUNCH(1);
+  else if (C <= 512) LN_LAUNCH(2);
+  else if (C <= 1024) LN_LAUNCH(4);
+  else if (C <= 2048) LN_LAUNCH(8);
+  else LN_LAUNCH(16);
+#undef LN_LAUNCH
+  MMSA_CHECK_LAUNCH("layernorm_rows");
+  return MMSA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// colstats: out[b][0][c] = sum_p x, out[b][1][c] = sum_p x^2, out[b][2][c] = sum_p wrow[p]*x   (double)
+// grid (ceil(C/64), ceil(HW/ROWS_PER_BLOCK), B), block 256 = 64 channels x 4 row lanes.
+#define CS_ROWS 512
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, long ldx, long strideB,
+                                                       const float* __restrict__ wrow, int HW, int C,
+                                                       double* __restrict__ out) {
+  __shared__ double red[3][4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int p0 = blockIdx.y * CS_ROWS;
+  const int p1 = min(p0 + CS_ROWS, HW);
+  const float* xb = x + (long)blockIdx.z * strideB;
+  double d1 = 0.0, d2 = 0.0, d3 = 0.0;
+  if (c < C) {
+    for (int pb = p0 + rg; pb < p1; pb += 4 * 32) {
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) {
+        const int p = pb + 4 * k;
+        if (p < p1) {
+          const float v = xb[(long)p * ldx + c];
+          s1 += v;
+          s2 += v * v;
+          if (wrow) s3 += wrow[p] * v;
+        }
+      }
+      d1 += (double)s1; d2 += (double)s2; d3 += (double)s3;
+    }
+  }
+  red[0][rg][cl] = d1; red[1][rg][cl] = d2; red[2][rg][cl] = d3;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double* o = out + (long)blockIdx.z * 3 * C;
+    atomicAdd(o + c, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    atomicAdd(o + C + c, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    if (wrow) atomicAdd(o + 2 * C + c, red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl]);
+  }
+}
+
+extern "C" int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C,
+                             double* out, hipStream_t stream) {
+  MMSA_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "colstats: bad args");
+  if (hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)B * C, stream) != hipSuccess) {
+    mmsa_set_error("colstats: memset failed");
+    return MMSA_ERR_LAUNCH;
+  }
+  dim3 grid(cdiv(C, 64), cdiv(HW, CS_ROWS), B);
+  hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, stream, x, ldx, strideB, wrow, HW, C, out);
+  MMSA_CHECK_LAUNCH("colstats");
+  return MMSA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FFRM finalize (one block per batch image).  From the column stats of the GFFM output F (before its
+// LayerNorm over HW) derive, per channel:  mean, rstd of the spatial LayerNorm (eps 1e-5, AM:241,265) and the
+// FFRM gate (AM:158-162):  avg = mean_p(LN(F))  [analytic: rstd*(sum_p w[p]F/HW - mean*mean(w)) + mean(b)],
+// z = Wc . avg (1x1 conv, no bias), GroupNorm(32) over channels (spatial 1x1), ReLU, sigmoid, mult = 1 + a.
+__global__ __launch_bounds__(256) void ffrm_finalize_kernel(const double* __restrict__ stats, int HW, int C,
+                                                            float mean_w, float mean_b,
+                                                            const float* __restrict__ Wc, const float* __restrict__ gn_w,
+                                                            const float* __restrict__ gn_b,
+                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                            float* __restrict__ mult_o) {
+  extern __shared__ float sm[];  // avg[C], z[C], gmean[32], grstd[32]
+  float* avg = sm;
+  float* z = sm + C;
+  float* gmean = z + C;
+  float* grstd = gmean + 32;
+  const int b = blockIdx.x;
+  const double* st = stats + (long)b * 3 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double m = st[c] / HW;
+    double var = st[C + c] / HW - m * m;
+    if (var < 0) var = 0;
+    const double rs = 1.0 / sqrt(var + 1e-5);
+    mean_o[(long)b * C + c] = (float)m;
+    rstd_o[(long)b * C + c] = (float)rs;
+    avg[c] = (float)(rs * (st[2 * C + c] / HW - m * (double)mean_w) + (double)mean_b);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = wv; o < C; o += 4) {
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += Wc[(long)o * C + i] * avg[i];
+    s = wave_sum(s);
+    if (lane == 0) z[o] = s;
+  }
+  __syncthreads();
+  const int cg = C / 32;
+  if (threadIdx.x < 32) {
+    float m = 0.f;
+    for (int i = 0; i < cg; ++i) m += z[threadIdx.x * cg + i];
+    m /= cg;
+    float v = 0.f;
+    for (int i = 0; i < cg; ++i) {
+      const float d = z[threadIdx.x * cg + i] - m;
+      v += d * d;
+    }
+    gmean[threadIdx.x] = m;
+    grstd[threadIdx.x] = 1.0f / sqrtf(v / cg + 1e-5f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gi = c / cg;
+    float t = (z[c] - gmean[gi]) * grstd[gi] * gn_w[c] + gn_b[c];
+    t = fmaxf(t, 0.f);
+    mult_o[(long)b * C + c] = 1.0f + 1.0f / (1.0f + expf(-t));
+  }
+}
+
+extern "C" int mmsa_ffrm_finalize(const double* stats, int B, int HW, int C, float mean_w, float mean_b,
+                                  const float* Wc, const float* gn_w, const float* gn_b,
+                                  float* mean_o, float* rstd_o, float* mult_o, hipStream_t stream) {
+  MMSA_CHECK_ARG(stats && Wc && gn_w && gn_b && mean_o && rstd_o && mult_o, "ffrm_finalize: null pointer");
+  MMSA_CHECK_ARG(C % 32 == 0 && C <= 8192, "ffrm_finalize: C=%d must be a multiple of 32", C);
+  hipLaunchKernelGGL(ffrm_finalize_kernel, dim3(B), dim3(256), (2 * C + 64) * sizeof(float), stream, stats, HW, C, mean_w,
+                     mean_b, Wc, gn_w, gn_b, mean_o, rstd_o, mult_o);
+  MMSA_CHECK_LAUNCH("ffrm_finalize");
+  return MMSA_OK;
+}
+
+// y[b,p,c] = ((x[b,p,c]-mean[b,c])*rstd[b,c]*w[p] + bias[p]) * mult[b,c]
+__global__ __launch_bounds__(256) void lnhw_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ mult,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ y, long ldy, int HW, int C, long total4) {
+  const int c4n = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long row = i / c4n;
+    const int p = (int)(row % HW);
+    const int b = (int)(row / HW);
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+    const float4 m = *reinterpret_cast<const float4*>(mean + (long)b * C + c);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + (long)b * C + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mult + (long)b * C + c);
+    const float wp = w[p], bp = bias[p];
+    float4 o;
+    o.x = ((v.x - m.x) * r.x * wp + bp) * mu.x;
+    o.y = ((v.y - m.y) * r.y * wp + bp) * mu.y;
+    o.z = ((v.z - m.z) * r.z * wp + bp) * mu.z;
+    o.w = ((v.w - m.w) * r.w * wp + bp) * mu.w;
+    *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+  }
+}
+
+extern "C" int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rstd, const float* mult,
+                               const float* w, const float* bias, float* y, long ldy, int B, int HW, int C,
+                               hipStream_t stream) {
+  MMSA_CHECK_ARG(x && mean && rstd && mult && w && bias && y, "lnhw_apply: null pointer");
+  MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0, "lnhw_apply: C/ld must be multiples of 4");
+  const long total4 = (long)B * HW * (C >> 2);
+  int blocks = cdiv(total4, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(lnhw_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, mean, rstd, mult, w, bias, y, ldy, HW, C, total4);
+  MMSA_CHECK_LAUNCH("lnhw_apply");
+  return MMSA_OK;
+}

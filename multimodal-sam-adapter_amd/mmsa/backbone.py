@@ -1,0 +1,621 @@
+"""Drop-in backbone `SAMAdapterbimodalMixModNewInTwinConvNEW` (BK:27-349) running on the MI355X HIP library.
+
+Same class name, constructor kwargs (CFG-L:30-56), `forward(x[B,6,H,W]) -> ([f1,f2,f3,f4] NCHW fp32, None)`,
+`init_weights(pretrained)` and state_dict keys as the reference, so mmseg's EncoderDecoder, the Segformer head,
+the configs and the checkpoint loader see the same plugin.  Inference (eval) semantics only: DropPath / Dropout /
+activation checkpointing are identities, SyncBatchNorm uses running statistics.
+
+All arithmetic is done by hand-written HIP kernels through the C ABI (mmsa.ops); torch allocates device buffers
+and provides the stream.  Activations are fp32, token-major (NHWC) end to end; only the four outputs are written
+NCHW by the fused tail kernel.  There is no CPU / PyTorch fallback."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .params import CONVNEXT_ARCH, build_tree
+
+_VIT_DEFAULTS = dict(img_size=1024, patch_size=16, in_chans=3, embed_dim=1024, depth=24, mlp_ratio=4.0,
+                     qkv_bias=True, use_abs_pos=True, use_rel_pos=True, rel_pos_zero_init=True, window_size=14,
+                     global_attn_indexes=[5, 11, 17, 23], pretrained_size=1024, fix=False)
+
+
+class Workspace:
+    """Named, grow-only device buffers (stable addresses once warmed up -> HIP-graph capturable)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, rows, cols, dtype=torch.float32, zero=False):
+        n = rows * cols
+        b = self.bufs.get(name)
+        if b is None or b.numel() < n or b.dtype != dtype:
+            b = torch.zeros(n, dtype=dtype, device=self.device) if zero else torch.empty(n, dtype=dtype, device=self.device)
+            self.bufs[name] = b
+        return b[:n].view(rows, cols)
+
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self.bufs.values())
+
+
+class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
+    def __init__(self, pretrain_size=1024, num_heads=12, conv_inplane=64, n_points=4,
+                 modalities_name=['rgb', 'depth', 'lidar', 'event'], modalities_ch=[3, 3, 3, 1],
+                 deform_num_heads=6, init_values=0., gamma_init_values=0., interaction_indexes=None, with_cffn=True,
+                 cffn_ratio=0.25, deform_ratio=1.0, add_vit_feature=True, pretrained=None,
+                 use_extra_extractor=True, with_cp=True, drop_path_rate=0.4, drop_rate=0., drop_multimodal_path=0.2,
+                 arch='base', checkpoint='check', *args, **kwargs):
+        super().__init__()
+        vit = dict(_VIT_DEFAULTS)
+        for k in list(kwargs):
+            if k in vit:
+                vit[k] = kwargs.pop(k)
+        # remaining kwargs (e.g. conv_drop_path_rate of the *withcp variant, norm_layer, act_layer) are
+        # training-only or fixed by the architecture and are accepted like BK:34 does with *args/**kwargs.
+        if 'rgb' not in modalities_name or len(modalities_name) != 2:
+            raise NotImplementedError("mmsa: the MI355X path implements the bimodal (rgb + one auxiliary modality) encoder; "
+                                      f"got modalities_name={modalities_name}")
+        if list(modalities_ch) != [3, 3]:
+            raise NotImplementedError("mmsa: TwinConvNeXt takes two 3-channel streams (TC:296-316)")
+        if not (with_cffn and use_extra_extractor and add_vit_feature and vit["use_rel_pos"] and vit["use_abs_pos"] and vit["qkv_bias"]):
+            raise NotImplementedError("mmsa: only the shipped configuration family (cffn, extra extractors, vit features, "
+                                      "abs+rel pos, qkv bias) is implemented")
+        if interaction_indexes is None:
+            raise ValueError("interaction_indexes is required")
+        D = vit["embed_dim"]
+        self.cfg = dict(embed_dim=D, depth=vit["depth"], num_heads=num_heads, mlp_ratio=vit["mlp_ratio"],
+                        patch_size=vit["patch_size"], pretrained_size=vit["pretrained_size"], img_size=vit["img_size"],
+                        window_size=vit["window_size"], global_attn_indexes=list(vit["global_attn_indexes"]),
+                        conv_inplane=conv_inplane, n_points=n_points, deform_num_heads=deform_num_heads,
+                        init_values=init_values, interaction_indexes=[list(i) for i in interaction_indexes],
+                        cffn_ratio=cffn_ratio, deform_ratio=deform_ratio, arch=arch,
+                        use_extra_extractor=use_extra_extractor)
+        a = CONVNEXT_ARCH[arch] if isinstance(arch, str) else arch
+        self.depths, self.channels = list(a["depths"]), list(a["channels"])
+        if [2 * c for c in self.channels] != [conv_inplane * m for m in (4, 8, 16, 32)]:
+            raise ValueError("conv_inplane*{4,8,16,32} must equal twice the ConvNeXt stage widths (AM:894-907)")
+        for c in self.channels:
+            if c % 32 != 0:
+                raise ValueError("ConvNeXt stage widths must be multiples of 32 (groups=32 convs, GroupNorm(32))")
+        hd = D // num_heads
+        if hd not in (32, 64):
+            raise NotImplementedError(f"mmsa: attention head_dim {hd} not supported by the HIP kernel (32 or 64)")
+        self.img_size = vit["img_size"]
+        self.embed_dim = D
+        self.interaction_indexes = self.cfg["interaction_indexes"]
+        self.modalities_name, self.modalities_ch = modalities_name, modalities_ch
+        self.in_ch_im = 3
+        build_tree(self, self.cfg)
+        self._packed = None
+        self._ws = None
+        self.register_load_state_dict_post_hook(lambda m, _: m.invalidate())
+        self.init_weights(pretrained)
+        self.eval()
+
+    # ------------------------------------------------------------------ plugin surface
+    def init_weights(self, pretrained=None):
+        """IE:305-315: load a (SAM) checkpoint non-strictly when a path is given."""
+        if isinstance(pretrained, str):
+            ck = torch.load(pretrained, map_location="cpu")
+            sd = ck.get("state_dict", ck.get("model", ck)) if isinstance(ck, dict) else ck
+            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+            self.load_state_dict(sd, strict=False)
+
+    def invalidate(self):
+        """Drop packed weights (call after mutating parameters in place)."""
+        self._packed = None
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("mmsa: the MI355X backbone implements the inference forward path only")
+        return super().train(False)
+
+    # ------------------------------------------------------------------ packing (one-time weight preprocessing)
+    @torch.no_grad()
+    def _pack(self, dev):
+        cfg = self.cfg
+        sd = {k: v.detach().to(dev, torch.float32) for k, v in self.state_dict().items() if v.dtype.is_floating_point}
+        pk = {}
+        D = cfg["embed_dim"]
+
+        def planes(w2d, kpad=None):
+            return ops.split_planes(w2d.contiguous(), kpad)
+
+        def scalar(k):
+            return float(sd[k].item())
+
+        # --- ViT
+        pk["pe_w"] = planes(sd["patch_embed.proj.weight"].reshape(D, -1))  # K order (c,kh,kw)
+        pk["pe_b"] = sd["patch_embed.proj.bias"].contiguous()
+        pk["blocks"] = []
+        for i in range(cfg["depth"]):
+            b = f"blocks.{i}."
+            pk["blocks"].append(dict(
+                n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
+                qkv=planes(sd[b + "attn.qkv.weight"]), qkv_b=sd[b + "attn.qkv.bias"].contiguous(),
+                proj=planes(sd[b + "attn.proj.weight"]), proj_b=sd[b + "attn.proj.bias"],
+                lin1=planes(sd[b + "mlp.lin1.weight"]), lin1_b=sd[b + "mlp.lin1.bias"],
+                lin2=planes(sd[b + "mlp.lin2.weight"]), lin2_b=sd[b + "mlp.lin2.bias"],
+                rph=sd[b + "attn.rel_pos_h"], rpw=sd[b + "attn.rel_pos_w"],
+                ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"]))
+        # --- TwinConvNeXt
+        t = "spm.twin_conv."
+        pk["twin"] = {}
+        for s in ("x", "y"):
+            d = t + f"downsample_layers_{s}."
+            st = dict(stem=planes(sd[d + "0.0.weight"].reshape(self.channels[0], -1)), stem_b=sd[d + "0.0.bias"],
+                      stem_nw=sd[d + "0.1.weight"], stem_nb=sd[d + "0.1.bias"], ds=[], stages=[], out_norm=[])
+            for i in range(1, 4):
+                w = sd[d + f"{i}.1.weight"]  # [Cout, Cin, 2, 2] -> K order (kh, kw, cin)
+                st["ds"].append(dict(nw=sd[d + f"{i}.0.weight"], nb=sd[d + f"{i}.0.bias"],
+                                     w=planes(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)), b=sd[d + f"{i}.1.bias"]))
+            for i in range(4):
+                blks = []
+                for j in range(self.depths[i]):
+                    b = t + f"stages_{s}.{i}.{j}."
+                    dw = sd[b + "depthwise_conv.weight"]  # [C,1,7,7] -> tap-major [49, C]
+                    blks.append(dict(dw=dw.reshape(dw.shape[0], 49).t().contiguous(), dw_b=sd[b + "depthwise_conv.bias"],
+                                     nw=sd[b + "norm.weight"], nb=sd[b + "norm.bias"],
+                                     pw1=planes(sd[b + "pointwise_conv1.weight"]), pw1_b=sd[b + "pointwise_conv1.bias"],
+                                     pw2=planes(sd[b + "pointwise_conv2.weight"]), pw2_b=sd[b + "pointwise_conv2.bias"],
+                                     gamma=sd[b + "gamma"]))
+                st["stages"].append(blks)
+                st["out_norm"].append((sd[t + f"norm_{s}{i}.weight"], sd[t + f"norm_{s}{i}.bias"]))
+            pk["twin"][s] = st
+        # --- fusion neck
+        f = "spm.smart_fusion."
+        pk["neck"] = []
+        for i in range(4):
+            C = 2 * self.channels[i]
+            c = self.channels[i]
+            lv = dict(gfe=[], loc=[])
+            for m in ("rgb", "sne"):
+                b = f + f"global_feature_encoder_{m}.{i}."
+                q1 = sd[b + "attn.qkv1.weight"]  # [3c, c/32, 1, 1], groups 32 -> [G][tap][ci][co]
+                q2 = sd[b + "attn.qkv2.weight"]  # [3c, 3c/32, 3, 3]
+                G = 32
+                co1, ci1 = 3 * c // G, c // G
+                co2, ci2 = 3 * c // G, 3 * c // G
+                lv["gfe"].append(dict(
+                    nw=sd[b + "norm1.body.weight"], nb=sd[b + "norm1.body.bias"],
+                    q1=q1.reshape(G, co1, ci1, 1).permute(0, 3, 2, 1).contiguous(),
+                    q2=q2.reshape(G, co2, ci2, 9).permute(0, 3, 2, 1).contiguous(),
+                    temp=sd[b + "attn.scale"].reshape(8).contiguous(), scale2=scalar(b + "attn.scale2"),
+                    proj=sd[b + "attn.proj.weight"].reshape(c, c).contiguous()))
+                b = f + f"local_feature_encoder_{m}.{i}."
+                dw = sd[b + "bottleneckBlock.2.weight"]
+                lv["loc"].append(dict(
+                    w1=planes(sd[b + "bottleneckBlock.0.weight"].reshape(2 * c, c)),
+                    dw=dw.reshape(2 * c, 9).t().contiguous(),
+                    w3=planes(sd[b + "bottleneckBlock.4.weight"].reshape(c, 2 * c)), scale=scalar(b + "scale")))
+            b = f + f"fuse_blocks.{i}."
+            lv["gx"], lv["gy"] = scalar(b + "gammax.scale"), scalar(b + "gammay.scale")
+            lv["lnw"], lv["lnb"] = sd[b + "norm.weight"].contiguous(), sd[b + "norm.bias"].contiguous()
+            lv["lnw_mean"], lv["lnb_mean"] = float(lv["lnw"].double().mean().item()), float(lv["lnb"].double().mean().item())
+            b = f + f"enhance_blocks.{i}.conv_atten."
+            lv["ffrm_w"] = sd[b + "conv.weight"].reshape(C, C).contiguous()
+            lv["gn_w"], lv["gn_b"] = sd[b + "gn.weight"], sd[b + "gn.bias"]
+            b = f + f"detail_feature_extractions.{i}."
+            dw = sd[b + "dwconv.weight"]  # [2C, 2, 3, 3], groups=C -> [G=C][tap][ci=2][co=2]
+            lv["mlp_in"] = planes(sd[b + "project_in.weight"].reshape(2 * C, C))
+            lv["mlp_dw"] = dw.reshape(C, 2, 2, 9).permute(0, 3, 2, 1).contiguous()
+            lv["mlp_out"] = planes(sd[b + "project_out.weight"].reshape(C, C))
+            lv["s1"], lv["s2"] = scalar(f + f"scale_layers.{i}.scale1"), scalar(f + f"scale_layers.{i}.scale2")
+            b = f + f"ca_blocks.{i}.coord_atten."
+            mip = max(8, C // 32)
+            inv = sd[b + "bn1.weight"] / torch.sqrt(sd[b + "bn1.running_var"] + 1e-5)  # BN(eval) folded into conv1
+            w1 = sd[b + "conv1.weight"].reshape(mip, C) * inv[:, None]
+            b1 = (sd[b + "conv1.bias"] - sd[b + "bn1.running_mean"]) * inv + sd[b + "bn1.bias"]
+            lv["mip"], lv["mip_pad"] = mip, ops.pad32(mip)
+            lv["ca1"], lv["ca1_b"] = planes(w1), b1.contiguous()
+            lv["cah"], lv["cah_b"] = planes(sd[b + "conv_h.weight"].reshape(C, mip)), sd[b + "conv_h.bias"]
+            lv["caw"], lv["caw_b"] = planes(sd[b + "conv_w.weight"].reshape(C, mip)), sd[b + "conv_w.bias"]
+            lv["fc"] = planes(sd[f"spm.fc{i+1}.weight"].reshape(D, C))
+            fb = sd[f"spm.fc{i+1}.bias"]
+            lv["fc_b"] = (fb + sd["level_embed"][i - 1]).contiguous() if i >= 1 else fb.contiguous()  # BK:149-156 folded
+            pk["neck"].append(lv)
+        # --- interactions
+        M, Pn = cfg["deform_num_heads"], cfg["n_points"]
+
+        def pack_msda(b):
+            w = torch.cat([sd[b + "sampling_offsets.weight"], sd[b + "attention_weights.weight"]], 0)
+            bb = torch.cat([sd[b + "sampling_offsets.bias"], sd[b + "attention_weights.bias"]], 0)
+            return dict(oa=planes(w), oa_b=bb.contiguous(), val=planes(sd[b + "value_proj.weight"]), val_b=sd[b + "value_proj.bias"],
+                        out=planes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
+
+        def pack_extractor(b):
+            dw = sd[b + "ffn.dwconv.dwconv.weight"]
+            return dict(qnw=sd[b + "query_norm.weight"], qnb=sd[b + "query_norm.bias"], fnw=sd[b + "feat_norm.weight"],
+                        fnb=sd[b + "feat_norm.bias"], attn=pack_msda(b + "attn."),
+                        fc1=planes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
+                        dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
+                        fc2=planes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
+                        ffw=sd[b + "ffn_norm.weight"], ffb=sd[b + "ffn_norm.bias"])
+
+        pk["inter"] = []
+        n_int = len(self.interaction_indexes)
+        for i in range(n_int):
+            b = f"interactions.{i}."
+            it = dict(inj=dict(gamma=sd[b + "injector.gamma"], qnw=sd[b + "injector.query_norm.weight"],
+                               qnb=sd[b + "injector.query_norm.bias"], fnw=sd[b + "injector.feat_norm.weight"],
+                               fnb=sd[b + "injector.feat_norm.bias"], attn=pack_msda(b + "injector.attn.")),
+                      ext=[pack_extractor(b + "extractor.")])
+            if i == n_int - 1:
+                it["ext"] += [pack_extractor(b + "extra_extractors.0."), pack_extractor(b + "extra_extractors.1.")]
+            pk["inter"].append(it)
+        # --- tail: ConvTranspose2d(D,D,2,2) weight [Cin, Cout, 2, 2] -> rows (i,j,co), K = ci  (BK:55,324)
+        up = sd["up.weight"]
+        pk["up"] = planes(up.permute(2, 3, 1, 0).reshape(4 * D, D))
+        pk["up_b"] = sd["up.bias"].repeat(4).contiguous()
+        pk["bn"] = []
+        for i in range(1, 5):
+            inv = sd[f"norm{i}.weight"] / torch.sqrt(sd[f"norm{i}.running_var"] + 1e-5)
+            pk["bn"].append((inv.contiguous(), (sd[f"norm{i}.bias"] - sd[f"norm{i}.running_mean"] * inv).contiguous()))
+        pk["pos_src"] = sd["pos_embed"]
+        pk["geom"] = {}
+        torch.cuda.synchronize(dev)
+        return pk
+
+    # geometry-dependent, input-independent tables (cached per (H, W))
+    @torch.no_grad()
+    def _geometry(self, H, W, dev):
+        pk = self._packed
+        key = (H, W)
+        if key in pk["geom"]:
+            return pk["geom"][key]
+        cfg = self.cfg
+        p = cfg["patch_size"]
+        Hp, Wp = H // p, W // p
+        g = {}
+        g["pos"] = _bicubic_resize(pk["pos_src"][0], Hp, Wp).reshape(Hp * Wp, -1).contiguous()  # BK:136-143
+        # deform_inputs (AM:397-431)
+        ss1 = torch.tensor([(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)], dtype=torch.int64)
+        ss2 = torch.tensor([(H // 16, W // 16)], dtype=torch.int64)
+        g["ss1"], g["ss2"] = ss1.to(dev), ss2.to(dev)
+        g["lsi1"] = torch.cat((ss1.new_zeros(1), ss1.prod(1).cumsum(0)[:-1])).to(dev)
+        g["lsi2"] = ss2.new_zeros(1).to(dev)
+        g["ref1"] = _ref_points([(H // 16, W // 16)]).to(dev)
+        g["ref2"] = _ref_points([(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]).to(dev)
+        # rel-pos gather tables (IE:554-584)
+        g["rel"] = []
+        ws = cfg["window_size"]
+        for blk in pk["blocks"]:
+            if blk["ws"]:
+                g["rel"].append((_rel_table(ws, blk["rph"]), _rel_table(ws, blk["rpw"])))
+            else:
+                g["rel"].append((_rel_table(Hp, blk["rph"]), _rel_table(Wp, blk["rpw"])))
+        pk["geom"][key] = g
+        return g
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("mmsa: input must be a GPU tensor; the MI355X backbone has no CPU path")
+        if x.dim() != 4 or x.shape[1] != 6:
+            raise RuntimeError(f"mmsa: expected [B, 6, H, W] (rgb + auxiliary modality), got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        if H != self.img_size or W != self.img_size:
+            raise RuntimeError(f"mmsa: H=W=img_size={self.img_size} is required (GFFM LayerNorm length, AM:240-241); got {H}x{W}")
+        if H % 32 != 0:
+            raise RuntimeError("mmsa: img_size must be a multiple of 32")
+        dev = x.device
+        x = x.contiguous().float()
+        if self._packed is None or self._packed.get("dev") != dev:
+            self._packed = self._pack(dev)
+            self._packed["dev"] = dev
+        if self._ws is None or self._ws.device != dev:
+            self._ws = Workspace(dev)
+        pk, ws, cfg = self._packed, self._ws, self.cfg
+        geo = self._geometry(H, W, dev)
+        D = cfg["embed_dim"]
+        p = cfg["patch_size"]
+        Hp, Wp = H // p, W // p
+        T = Hp * Wp
+        n2, n3, n4 = (H // 8) * (W // 8), T, (H // 32) * (W // 32)
+        Nc = n2 + n3 + n4
+
+        # ---- spatial prior module -> c1 [B*HW/16, D], c (c2|c3|c4 + level embed) [B, Nc, D]
+        c1 = ws.get("c1", B * (H // 4) * (W // 4), D)
+        cbuf = ws.get("c", B * Nc, D)
+        self._spm(x, B, H, W, c1, cbuf, Nc)
+
+        # ---- patch embedding + absolute position embedding (IE:662-671, BK:268-278)
+        a = ws.get("pe_a", B * T, pk["pe_w"].kpad)
+        ops.im2col_nchw(x, 0, 3, p, a)
+        xs = [ws.get(f"x{i}", B * T, D) for i in range(len(self.interaction_indexes) + 1)]
+        ops.gemm(a, pk["pe_w"], xs[0], bias=pk["pe_b"], resid=geo["pos"], resid_mod=T)
+
+        # ---- interactions (AM:567-581)
+        for i, idx in enumerate(self.interaction_indexes):
+            it = pk["inter"][i]
+            self._injector(it["inj"], xs[i], xs[i + 1], cbuf, geo, B, T, Nc)
+            for bi in range(idx[0], idx[-1] + 1):
+                self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp)
+            for ex in it["ext"]:
+                self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
+
+        # ---- tail (BK:316-337)
+        outs = []
+        ops.gemm(cbuf, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=Nc * D,
+                 stride_r=(H // 4) * (W // 4) * D, stride_c=(H // 4) * (W // 4) * D, pixel_shuffle=(H // 8, W // 8, D))
+        f1 = torch.empty(B, D, H // 4, W // 4, device=dev)
+        ops.tail_fuse(c1, (H // 4) * (W // 4) * D, xs[1], *pk["bn"][0], f1, B, H // 4, W // 4, Hp, Wp)
+        f2 = torch.empty(B, D, H // 8, W // 8, device=dev)
+        ops.tail_fuse(cbuf, Nc * D, xs[2], *pk["bn"][1], f2, B, H // 8, W // 8, Hp, Wp)
+        f3 = torch.empty(B, D, Hp, Wp, device=dev)
+        ops.tail_fuse(cbuf[n2:], Nc * D, xs[3], *pk["bn"][2], f3, B, Hp, Wp, Hp, Wp)
+        f4 = torch.empty(B, D, H // 32, W // 32, device=dev)
+        ops.tail_fuse(cbuf[n2 + n3:], Nc * D, xs[4], *pk["bn"][3], f4, B, H // 32, W // 32, Hp, Wp)
+        outs = [f1, f2, f3, f4]
+        return outs, None
+
+    # ------------------------------------------------------------------ SAM ViT block (IE:382-423)
+    def _block(self, bp, rel, x, B, Hp, Wp):
+        ws, cfg = self._ws, self.cfg
+        D, heads = cfg["embed_dim"], cfg["num_heads"]
+        hd = D // heads
+        T = Hp * Wp
+        n = ws.get("blk_n", B * T, D)
+        ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, n)
+        qkv = ws.get("blk_qkv", B * T, 3 * D)
+        ops.gemm(n, bp["qkv"], qkv, bias=bp["qkv_b"])
+        wsz = bp["ws"]
+        kk = 2 * wsz if wsz else Hp + Wp
+        rp = ws.get("blk_rp", B * heads * T, kk)
+        ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
+        ao = ws.get("blk_ao", B * T, D)
+        ops.attention(qkv, bp["qkv_b"], rp, ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+        ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
+        ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, n)
+        h = ws.get("blk_h", B * T, bp["lin1"].n)
+        ops.gemm(n, bp["lin1"], h, bias=bp["lin1_b"], act="gelu")
+        ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x)
+
+    # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)
+    def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None):
+        ws, cfg = self._ws, self.cfg
+        M, Pn = cfg["deform_num_heads"], cfg["n_points"]
+        dv = ap["val"].n
+        val = ws.get("msda_val", B * S, dv)
+        ops.gemm(fn, ap["val"], val, bias=ap["val_b"])
+        raw = ws.get("msda_raw", B * Lq, ap["oa"].n)
+        ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"])
+        samp = ws.get("msda_s", B * Lq, dv)
+        ops.msda_fused(val, ss, lsi, raw, ref, samp, B, S, M, dv // M, L, Lq, Pn)
+        ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale)
+
+    def _injector(self, ip, x_in, x_out, c, geo, B, T, Nc):  # AM:525-542
+        ws, D = self._ws, self.cfg["embed_dim"]
+        qn = ws.get("inj_qn", B * T, D)
+        fn = ws.get("inj_fn", B * Nc, D)
+        ops.layernorm(x_in, ip["qnw"], ip["qnb"], 1e-6, qn)
+        ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, fn)
+        self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"])
+
+    def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
+        ws, D = self._ws, self.cfg["embed_dim"]
+        qn = ws.get("inj_fn", B * Nc, D)
+        fn = ws.get("inj_qn", B * T, D)
+        ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, qn)
+        ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, fn)
+        self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
+        ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, qn)
+        hid = ep["fc1"].n
+        h1 = ws.get("ffn_h1", B * Nc, hid)
+        h2 = ws.get("ffn_h2", B * Nc, hid)
+        ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
+        off = 0
+        for (hh, wwd) in ((H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)):  # AM:462-470 token split 16n/4n/n
+            ops.dwconv(h1[off:], ep["dw"], ep["dw_b"], h2[off:], B, hh, wwd, 3, act="gelu",
+                       xstride_b=Nc * hid, ystride_b=Nc * hid)
+            off += hh * wwd
+        ops.gemm(h2, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
+
+    # ------------------------------------------------------------------ spatial prior module (AM:929-964)
+    def _spm(self, x, B, H, W, c1_out, cbuf, Nc):
+        pk, ws = self._packed, self._ws
+        D = self.cfg["embed_dim"]
+        chans = self.channels
+        sizes = [(H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+        tcat = [ws.get(f"tcat{i}", B * sizes[i][0] * sizes[i][1], 2 * chans[i]) for i in range(4)]
+        # --- TwinConvNeXt (TC:445-476): two independent streams, outputs channel-concatenated
+        for si, s in enumerate(("x", "y")):
+            st = pk["twin"][s]
+            h0, w0 = sizes[0]
+            a = ws.get("stem_a", B * h0 * w0, st["stem"].kpad)
+            ops.im2col_nchw(x, 3 * si, 3, 4, a)
+            t0 = ws.get("cn_tmp", B * h0 * w0, chans[0])
+            ops.gemm(a, st["stem"], t0, bias=st["stem_b"])
+            cur = ws.get("cn_cur0", B * h0 * w0, chans[0])
+            ops.layernorm(t0, st["stem_nw"], st["stem_nb"], 1e-6, cur)
+            for i in range(4):
+                hh, wwd = sizes[i]
+                P = B * hh * wwd
+                c = chans[i]
+                if i >= 1:
+                    ds = st["ds"][i - 1]
+                    pa = ws.get("cn_patch", P, 4 * chans[i - 1])
+                    ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]))
+                    cur = ws.get(f"cn_cur{i}", P, c)
+                    ops.gemm(pa, ds["w"], cur, bias=ds["b"])
+                d = ws.get("cn_tmp", P, c)
+                n = ws.get("cn_n", P, c)
+                hbuf = ws.get("cn_h", P, 4 * c)
+                for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
+                    ops.dwconv(cur, blk["dw"], blk["dw_b"], d, B, hh, wwd, 7)
+                    ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, n)
+                    ops.gemm(n, blk["pw1"], hbuf, bias=blk["pw1_b"], act="gelu")
+                    ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur)
+                nw, nb = st["out_norm"][i]
+                ops.layernorm(cur, nw, nb, 1e-6, tcat[i][:, si * c:(si + 1) * c])
+        # --- RoadFormer2Neck (AM:364-394) + fc1..4 (AM:947-956)
+        off_rows = 0
+        for i in range(4):
+            hh, wwd = sizes[i]
+            out = c1_out if i == 0 else cbuf[off_rows:]
+            self._neck_level(pk["neck"][i], tcat[i], B, hh, wwd, chans[i], out,
+                             0 if i == 0 else Nc * D)
+            if i >= 1:
+                off_rows += hh * wwd
+
+    def _neck_level(self, lv, t, B, h, w, c, out, out_stride_b):
+        ws = self._ws
+        C = 2 * c
+        HW = h * w
+        P = B * HW
+        gcat = ws.get("nk_g", P, C)
+        lcat = ws.get("nk_l", P, C)
+        for m in range(2):
+            X = t[:, m * c:(m + 1) * c]
+            # GFE (AM:133-145, 75-109): x + LN(x) + proj(softmax(norm(q) norm(k)^T * temp) v) * scale2
+            gp = lv["gfe"][m]
+            y = ws.get("nk_y", P, c)
+            s = ws.get("nk_s", P, c)
+            ops.layernorm(X, gp["nw"], gp["nb"], 1e-5, y, out2=s)
+            q1 = ws.get("nk_q1", P, 3 * c)
+            q2 = ws.get("nk_q2", P, 3 * c)
+            ops.gconv(y, gp["q1"], None, q1, B, h, w, 32, c // 32, 3 * c // 32, 1)
+            ops.gconv(q1, gp["q2"], None, q2, B, h, w, 32, 3 * c // 32, 3 * c // 32, 3)
+            st = ws.get("nk_st", B * 3, 3 * c, dtype=torch.float64)
+            ops.colstats(q2, HW * 3 * c, B, HW, st)
+            g = ws.get("nk_gram", B * c, c)
+            ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8)
+            cp = ops.pad32(c)
+            pl = ops.Planes(ws.get(f"nk_phi{c}", B * c, cp, dtype=torch.int16, zero=True),
+                            ws.get(f"nk_plo{c}", B * c, cp, dtype=torch.int16, zero=True), c, c, cp)
+            base = st.data_ptr()
+            ops.chanattn_build(g, base + 8 * (3 * c), 9 * c, base + 8 * (3 * c + c), 9 * c, gp["temp"], gp["proj"], pl, B, c, 8)
+            ops.gemm(q2[:, 2 * c:], pl, gcat[:, m * c:(m + 1) * c], alpha=gp["scale2"], resid=s, batch=B, m=HW,
+                     stride_a=HW * 3 * c, stride_w=c * cp, stride_r=HW * c, stride_c=HW * C)
+            # MobileNetV2 (AM:281-295)
+            lp = lv["loc"][m]
+            h1 = ws.get("nk_q1", P, 2 * c)
+            h2 = ws.get("nk_q2", P, 2 * c)
+            ops.gemm(X, lp["w1"], h1, act="relu6")
+            ops.dwconv(h1, lp["dw"], None, h2, B, h, w, 3, act="relu6")
+            ops.gemm(h2, lp["w3"], lcat[:, m * c:(m + 1) * c], alpha=lp["scale"], resid=X)
+        # GFFM (AM:242-267)
+        e = ws.get("nk_gram", B * c, c)
+        ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1)
+        cp = ops.pad32(c)
+        px = ops.Planes(ws.get(f"nk_phi{c}", B * c, cp, dtype=torch.int16, zero=True),
+                        ws.get(f"nk_plo{c}", B * c, cp, dtype=torch.int16, zero=True), c, c, cp)
+        py = ops.Planes(ws.get(f"nk_phi2{c}", B * c, cp, dtype=torch.int16, zero=True),
+                        ws.get(f"nk_plo2{c}", B * c, cp, dtype=torch.int16, zero=True), c, c, cp)
+        ops.gffm_build(e, px, py, B, c)
+        fbuf = ws.get("nk_f", P, C)
+        ops.gemm(gcat[:, c:], px, fbuf[:, :c], alpha=lv["gx"], resid=gcat[:, :c], batch=B, m=HW,
+                 stride_a=HW * C, stride_w=c * cp, stride_r=HW * C, stride_c=HW * C)
+        ops.gemm(gcat[:, :c], py, fbuf[:, c:], alpha=lv["gy"], resid=gcat[:, c:], batch=B, m=HW,
+                 stride_a=HW * C, stride_w=c * cp, stride_r=HW * C, stride_c=HW * C)
+        # LayerNorm over H*W (AM:265) + FFRM (AM:158-162), one apply pass
+        st = ws.get("nk_st", B * 3, C, dtype=torch.float64)
+        ops.colstats(fbuf, HW * C, B, HW, st, wrow=lv["lnw"])
+        mean = ws.get("nk_mean", B, C)
+        rstd = ws.get("nk_rstd", B, C)
+        mult = ws.get("nk_mult", B, C)
+        ops.ffrm_finalize(st, B, HW, C, lv["lnw_mean"], lv["lnb_mean"], lv["ffrm_w"], lv["gn_w"], lv["gn_b"], mean, rstd, mult)
+        fn = ws.get("nk_g", P, C)  # gcat is dead now
+        ops.lnhw_apply(fbuf, mean, rstd, mult, lv["lnw"], lv["lnb"], fn, B, HW)
+        # gated MLP on the local branch (AM:127-132) and Scale2 (AM:279-280)
+        hm = ws.get("nk_hm", P, 2 * C)
+        hd = ws.get("nk_hd", P, 2 * C)
+        ops.gemm(lcat, lv["mlp_in"], hm)
+        ops.gconv(hm, lv["mlp_dw"], None, hd, B, h, w, C, 2, 2, 3)
+        hg = ws.get("nk_l", P, C)  # lcat is dead now
+        ops.gelu_gate(hd, hg, C)
+        z = ws.get("nk_f", P, C)  # fbuf is dead now
+        ops.gemm(hg, lv["mlp_out"], z, alpha=lv["s2"], resid=fn, beta=lv["s1"])
+        # CoordinateAttention (AM:187-201) + residual (AM:218-221)
+        pooled = ws.get("nk_pool", B * (h + w), C)
+        ops.pool_hw(z, pooled, B, h, w)
+        y1 = ws.get(f"nk_y1_{lv['mip_pad']}", B * (h + w), lv["mip_pad"], zero=True)
+        ops.gemm(pooled, lv["ca1"], y1, bias=lv["ca1_b"], act="hswish")
+        att = ws.get("nk_att", B * (h + w), C)
+        ops.gemm(y1, lv["cah"], att, bias=lv["cah_b"], act="sigmoid", batch=B, m=h,
+                 stride_a=(h + w) * lv["mip_pad"], stride_c=(h + w) * C)
+        ops.gemm(y1[h:], lv["caw"], att[h:], bias=lv["caw_b"], act="sigmoid", batch=B, m=w,
+                 stride_a=(h + w) * lv["mip_pad"], stride_c=(h + w) * C)
+        zo = ws.get("nk_g", P, C)  # fn is dead now
+        ops.ca_apply(z, att, zo, B, h, w)
+        # fc_i (AM:947-956) straight into c1 / the c2|c3|c4 token buffer (level embed folded into the bias)
+        if out_stride_b == 0:
+            ops.gemm(zo, lv["fc"], out, bias=lv["fc_b"])
+        else:
+            ops.gemm(zo, lv["fc"], out, bias=lv["fc_b"], batch=B, m=HW, stride_a=HW * C, stride_c=out_stride_b)
+
+
+class SAMAdapterbimodalMixModNewInTwinConvNEWwithcp(SAMAdapterbimodalMixModNewInTwinConvNEW):
+    """Second registered name (backbones/__init__.py:3-9): identical inference math, extra training-only kwargs."""
+
+
+# ---------------------------------------------------------------------- pack-time helpers (host/torch, one-time)
+def _ref_points(shapes):
+    """get_reference_points (AM:397-409): per-query (x, y) in [0,1], levels concatenated -> [Lq, 2] fp32."""
+    refs = []
+    for (h, w) in shapes:
+        ys = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32) / h
+        xs = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32) / w
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        refs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+    return torch.cat(refs, 0).contiguous()
+
+
+def rel_pos_index(q_size, k_size):
+    """Integer gather table of get_rel_pos (IE:579-584): float coords then .long() -- kept bit-exact."""
+    q = torch.arange(q_size)[:, None] * max(k_size / q_size, 1.0)
+    k = torch.arange(k_size)[None, :] * max(q_size / k_size, 1.0)
+    return ((q - k) + (k_size - 1) * max(q_size / k_size, 1.0)).long()
+
+
+def _linear_resize_rows(tab, L):
+    """F.interpolate(mode='linear', align_corners=False) along dim 0 of a [Lin, C] table (IE:568-575)."""
+    Lin = tab.shape[0]
+    scale = Lin / L
+    pos = (torch.arange(L, dtype=torch.float32, device=tab.device) + 0.5) * scale - 0.5
+    pos = pos.clamp(min=0)
+    i0 = pos.floor().long().clamp(max=Lin - 1)
+    i1 = (i0 + 1).clamp(max=Lin - 1)
+    lam = (pos - i0.float()).unsqueeze(1)
+    return tab[i0] * (1 - lam) + tab[i1] * lam
+
+
+def _rel_table(size, rel_pos):
+    """get_rel_pos(size, size, rel_pos) -> gathered [size, size, hd] table (IE:554-584)."""
+    L = 2 * size - 1
+    tab = rel_pos if rel_pos.shape[0] == L else _linear_resize_rows(rel_pos, L)
+    return tab[rel_pos_index(size, size).to(tab.device)].contiguous()
+
+
+def _cubic_w(t, A=-0.75):
+    def c1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def c2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    return torch.stack([c2(t + 1), c1(t), c1(1 - t), c2(2 - t)], -1)
+
+
+def _bicubic_matrix(n_in, n_out, device):
+    scale = n_in / n_out
+    x = (torch.arange(n_out, dtype=torch.float32, device=device) + 0.5) * scale - 0.5
+    ix = x.floor()
+    w = _cubic_w(x - ix)  # [n_out, 4]
+    m = torch.zeros(n_out, n_in, dtype=torch.float32, device=device)
+    for k in range(4):
+        idx = (ix.long() - 1 + k).clamp(0, n_in - 1)
+        m.scatter_add_(1, idx[:, None], w[:, k:k + 1])
+    return m
+
+
+def _bicubic_resize(src_hwc, H, W):
+    """F.interpolate(mode='bicubic', align_corners=False) of a [h, w, C] map (BK:136-143); identity when sizes match."""
+    h, w, _ = src_hwc.shape
+    if (h, w) == (H, W):
+        return src_hwc.contiguous()
+    my = _bicubic_matrix(h, H, src_hwc.device)
+    mx = _bicubic_matrix(w, W, src_hwc.device)
+    return torch.einsum("Hh,hwc,Ww->HWc", my, src_hwc, mx).contiguous()

@@ -1,0 +1,77 @@
+"""ctypes binding of libmmsa_hip.so (the C ABI declared in include/mmsa.h).
+
+There is NO fallback: if the shared library is missing the import of this module raises, and every op
+raises RuntimeError when the library reports an error.  Build it with
+`python multimodal-sam-adapter_amd/build.py` (hipcc --offload-arch=gfx950)."""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmsa_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f"{LIB_PATH} not found: the MI355X HIP library is required (no CPU/PyTorch fallback exists). "
+        "Build it with: python multimodal-sam-adapter_amd/build.py")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+P = c_void_p
+I = c_int
+L = c_long
+F = c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "mmsa_version": [],
+    "mmsa_last_error": [],
+    "mmsa_event_create": [POINTER(c_void_p)],
+    "mmsa_event_record": [P, P],
+    "mmsa_event_elapsed_ms": [P, P, POINTER(c_float)],
+    "mmsa_event_destroy": [P],
+    "mmsa_ms_deform_attn_forward": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "mmsa_msda_fused": [P, P, P, P, L, P, P, L, I, I, I, I, I, I, I, P],
+    "mmsa_gemm_split3": [P, L, L, P, P, L, P, L, P, P, L, L, I, F, P, L, L, I, I, I, I, I, F, I, I, I, I, P],
+    "mmsa_split_planes": [P, L, I, I, I, P, P, P],
+    "mmsa_attention": [P, L, P, P, P, L, I, I, I, I, I, I, F, P],
+    "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
+    "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, I, I, I, I, I, P],
+    "mmsa_colstats": [P, L, L, P, I, I, I, P, P],
+    "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P],
+    "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
+    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, I, I, I, I, I, I, P],
+    "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],
+    "mmsa_im2col_nchw": [P, I, I, I, I, I, I, I, P, I, P],
+    "mmsa_gram_tn": [P, L, P, L, L, P, I, I, I, I, P],
+    "mmsa_chanattn_build": [P, P, L, P, L, P, P, P, P, I, I, I, I, P],
+    "mmsa_gffm_build": [P, P, P, P, P, I, I, I, P],
+    "mmsa_gelu_gate": [P, L, P, L, L, I, P],
+    "mmsa_pool_hw": [P, L, P, L, I, I, I, I, P],
+    "mmsa_ca_apply": [P, L, P, L, P, L, I, I, I, I, P],
+    "mmsa_tail_fuse": [P, L, L, P, L, P, P, P, I, I, I, I, I, I, P],
+}
+_RESTYPES = {"mmsa_last_error": c_char_p}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
+    _fn.argtypes = _args
+    _fn.restype = _RESTYPES.get(_name, c_int)
+
+
+def last_error() -> str:
+    return _lib.mmsa_last_error().decode()
+
+
+def call(name, *args):
+    """Invoke an entry point; raise RuntimeError(mmsa_last_error()) on a non-zero return code."""
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {last_error()}")
+
+
+def version() -> int:
+    return _lib.mmsa_version()
+
+
+raw = _lib

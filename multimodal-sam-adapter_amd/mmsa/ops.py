@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C ABI (include/mmsa.h).  PyTorch is only plumbing here: device memory,
+the current HIP stream and shape bookkeeping.  No arithmetic is done by torch on this path, and nothing
+falls back to torch when the library fails -- errors propagate as RuntimeError."""
+import torch
+
+from . import lib
+
+ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"mmsa: {name} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"mmsa: {name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _mat(t, name):
+    """2-D fp32 matrix view with unit column stride -> (ptr, rows, cols, ld)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"mmsa: {name} must be a 2-D view with unit column stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return _chk(t, name=name), t.shape[0], t.shape[1], t.stride(0)
+
+
+class Planes:
+    """bf16 hi/lo planes of a weight matrix [N, Kpad] (optionally batched [B, N, Kpad])."""
+
+    def __init__(self, hi, lo, n, k, kpad):
+        self.hi, self.lo, self.n, self.k, self.kpad = hi, lo, n, k, kpad
+
+
+def pad32(k):
+    return (k + 31) // 32 * 32
+
+
+def split_planes(w2d, kpad=None):
+    """fp32 [N, K] (device) -> Planes with K zero-padded to a multiple of 32."""
+    p, n, k, ld = _mat(w2d, "weight")
+    kpad = kpad or pad32(k)
+    hi = torch.empty(n, kpad, dtype=torch.int16, device=w2d.device)
+    lo = torch.empty_like(hi)
+    lib.call("mmsa_split_planes", p, ld, n, k, kpad, hi.data_ptr(), lo.data_ptr(), _stream())
+    return Planes(hi, lo, n, k, kpad)
+
+
+def gemm(a, w, out, bias=None, act="none", alpha=1.0, colscale=None, resid=None, beta=1.0, resid_mod=0,
+         batch=1, stride_a=0, stride_w=0, stride_bias=0, stride_r=0, stride_c=0, m=None, pixel_shuffle=None):
+    """out = beta*resid + colscale*alpha*act(a @ w^T + bias).  a,out,resid: 2-D fp32 views; w: Planes."""
+    pa, ma, ka, lda = _mat(a, "A")
+    pc, mc, nc, ldc = _mat(out, "C")
+    m = ma if m is None else m
+    if ka < w.kpad and lda < w.kpad:
+        raise RuntimeError(f"mmsa.gemm: A has {ka} columns (ld {lda}) but the packed weight expects K={w.kpad}")
+    pr, ldr = None, 0
+    if resid is not None:
+        pr, _, _, ldr = _mat(resid, "resid")
+    ps = pixel_shuffle or (0, 0, 0)
+    lib.call("mmsa_gemm_split3", pa, lda, stride_a, w.hi.data_ptr(), w.lo.data_ptr(), stride_w,
+             _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
+             pc, ldc, stride_c, m, w.n, w.kpad, batch, ACT[act], alpha, 1 if pixel_shuffle else 0, ps[0], ps[1], ps[2],
+             _stream())
+    return out
+
+
+def layernorm(x, w, b, eps, out, out2=None, patchify=None):
+    px, rows, c, ldx = _mat(x, "x")
+    py, _, _, ldy = _mat(out, "y")
+    p2, ld2 = None, 0
+    if out2 is not None:
+        p2, _, _, ld2 = _mat(out2, "y2")
+    mh, mw = patchify or (0, 0)
+    lib.call("mmsa_layernorm_rows", px, ldx, _chk(w), _chk(b), eps, py, ldy, p2, ld2, rows, c,
+             1 if patchify else 0, mh, mw, _stream())
+    return out
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Drop-in for MultiScaleDeformableAttention.ms_deform_attn_forward (ops/src/vision.cpp:14)."""
+    for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{n} tensor has to be contiguous")  # ms_deform_attn_cuda.cu:28-32
+    if not (spatial_shapes.is_contiguous() and level_start_index.is_contiguous()):
+        raise RuntimeError("spatial_shapes / level_start_index tensor has to be contiguous")
+    n, s, m, d = value.shape
+    _, lq, _, l, p, _ = sampling_loc.shape
+    out = torch.empty(n, lq, m * d, dtype=torch.float32, device=value.device)
+    lib.call("mmsa_ms_deform_attn_forward", _chk(value), _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64),
+             _chk(sampling_loc), _chk(attn_weight), out.data_ptr(), n, s, m, d, l, lq, p, im2col_step, _stream())
+    return out
+
+
+def msda_fused(value2d, spatial_shapes, level_start_index, raw, ref_points, out, batch, spatial, heads, d, levels, lq, points):
+    pv, _, _, _ = _mat(value2d, "value")
+    pr, _, _, ldraw = _mat(raw, "raw")
+    po, _, _, ldo = _mat(out, "out")
+    lib.call("mmsa_msda_fused", pv, _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64), pr, ldraw,
+             _chk(ref_points), po, ldo, batch, spatial, heads, d, levels, lq, points, _stream())
+    return out
+
+
+def relpos_bias(qkv, rh, rw, rp, b, h, w, heads, hd, ws):
+    pq, _, _, ldq = _mat(qkv, "qkv")
+    lib.call("mmsa_relpos_bias", pq, ldq, _chk(rh), _chk(rw), _chk(rp), b, h, w, heads, hd, ws, _stream())
+    return rp
+
+
+def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
+    pq, _, _, ldq = _mat(qkv, "qkv")
+    po, _, _, ldo = _mat(out, "out")
+    lib.call("mmsa_attention", pq, ldq, _chk(qkv_bias), _chk(rp), po, ldo, b, h, w, heads, hd, ws, scale, _stream())
+    return out
+
+
+def colstats(x, stride_b, b, hw, out, wrow=None):
+    px, _, c, ldx = _mat(x, "x")
+    lib.call("mmsa_colstats", px, ldx, stride_b, _chk(wrow), b, hw, c, _chk(out, torch.float64), _stream())
+    return out
+
+
+def ffrm_finalize(stats, b, hw, c, mean_w, mean_b, wc, gn_w, gn_b, mean_o, rstd_o, mult_o):
+    lib.call("mmsa_ffrm_finalize", _chk(stats, torch.float64), b, hw, c, mean_w, mean_b, _chk(wc), _chk(gn_w), _chk(gn_b),
+             _chk(mean_o), _chk(rstd_o), _chk(mult_o), _stream())
+
+
+def lnhw_apply(x, mean, rstd, mult, w, bias, out, b, hw):
+    px, _, c, ldx = _mat(x, "x")
+    po, _, _, ldo = _mat(out, "y")
+    lib.call("mmsa_lnhw_apply", px, ldx, _chk(mean), _chk(rstd), _chk(mult), _chk(w), _chk(bias), po, ldo, b, hw, c, _stream())
+    return out
+
+
+def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=None):
+    px, _, c, ldx = _mat(x, "x")
+    po, _, _, ldo = _mat(out, "y")
+    xs = h * wd * ldx if xstride_b is None else xstride_b
+    ys = h * wd * ldo if ystride_b is None else ystride_b
+    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, b, h, wd, c, k, ACT[act], _stream())
+    return out
+
+
+def gconv(x, w, bias, out, b, h, wd, groups, cin_g, cout_g, k, act="none"):
+    px, _, _, ldx = _mat(x, "x")
+    po, _, _, ldo = _mat(out, "y")
+    lib.call("mmsa_gconv_nhwc", px, ldx, _chk(w), _chk(bias), po, ldo, b, h, wd, groups, cin_g, cout_g, k, ACT[act], _stream())
+    return out
+
+
+def im2col_nchw(x, c0, cin, p, out):
+    b, ctot, h, w = x.shape
+    if not x.is_contiguous():
+        raise RuntimeError("mmsa.im2col_nchw: input image must be contiguous NCHW")
+    po, _, kpad, ld = _mat(out, "out")
+    if ld != kpad:
+        raise RuntimeError("mmsa.im2col_nchw: output must be dense")
+    lib.call("mmsa_im2col_nchw", _chk(x), b, ctot, c0, cin, h, w, p, po, kpad, _stream())
+    return out
+
+
+def gram_tn(x, y, stride_b, g, b, p, nblk=1):
+    px, _, c, ldx = _mat(x, "X")
+    py, _, _, ldy = _mat(y, "Y")
+    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g), b, p, c, nblk, _stream())
+    return g
+
+
+def chanattn_build(g, sq, sq_stride, sk, sk_stride, temp, wp, planes, b, c, heads):
+    lib.call("mmsa_chanattn_build", _chk(g), sq, sq_stride, sk, sk_stride, _chk(temp), _chk(wp),
+             planes.hi.data_ptr(), planes.lo.data_ptr(), b, c, planes.kpad, heads, _stream())
+
+
+def gffm_build(e, px_, py_, b, c):
+    lib.call("mmsa_gffm_build", _chk(e), px_.hi.data_ptr(), px_.lo.data_ptr(), py_.hi.data_ptr(), py_.lo.data_ptr(),
+             b, c, px_.kpad, _stream())
+
+
+def gelu_gate(x, out, c):
+    px, rows, _, ldx = _mat(x, "x")
+    po, _, _, ldo = _mat(out, "y")
+    lib.call("mmsa_gelu_gate", px, ldx, po, ldo, rows, c, _stream())
+    return out
+
+
+def pool_hw(z, out, b, h, w):
+    pz, _, c, ldz = _mat(z, "z")
+    po, _, _, ldo = _mat(out, "out")
+    lib.call("mmsa_pool_hw", pz, ldz, po, ldo, b, h, w, c, _stream())
+    return out
+
+
+def ca_apply(z, att, out, b, h, w):
+    pz, _, c, ldz = _mat(z, "z")
+    pa, _, _, lda = _mat(att, "att")
+    po, _, _, ldo = _mat(out, "out")
+    lib.call("mmsa_ca_apply", pz, ldz, pa, lda, po, ldo, b, h, w, c, _stream())
+    return out
+
+
+def tail_fuse(cmap, cstride_b, xtok, bn_scale, bn_shift, out, b, hc, wc, hx, wx):
+    pc, _, c, ldc = _mat(cmap, "cmap")
+    px, _, _, ldx = _mat(xtok, "xtok")
+    lib.call("mmsa_tail_fuse", pc, ldc, cstride_b, px, ldx, _chk(bn_scale), _chk(bn_shift), _chk(out), b, hc, wc, hx, wx, c, _stream())
+    return out

@@ -1,0 +1,105 @@
+"""CPU: the oracle (oracle/ref_encoder.py) against golden vectors produced by the imported reference
+(tools/oracle/make_golden.py).  This is what pins the oracle; the GPU parity tests then compare the HIP path
+with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_encoder as R
+from tests.configs import CONFIGS, make_input, probe_index, weights_checksum
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_msda_reference_known_answer(golden_dir):
+    """The reference's own fixture (ops/test.py:16-50): fp64 allclose, fp32 rtol 1e-2 / atol 1e-3."""
+    g = _load(golden_dir, "msda.npz")
+    shapes, lsi = torch.from_numpy(g["t_shapes"]), torch.from_numpy(g["t_lsi"])
+    v, loc, aw = (torch.from_numpy(g[k]) for k in ("t_value", "t_loc", "t_aw"))
+    for fn in (lambda *a: R.msda_core(a[0], a[1], a[3], a[4]), R.msda_direct):
+        out64 = fn(v.double(), shapes, lsi, loc.double(), aw.double())
+        assert torch.allclose(out64, torch.from_numpy(g["t_out64"]))
+        out32 = fn(v, shapes, lsi, loc, aw)
+        assert torch.allclose(out32, torch.from_numpy(g["t_out"]), rtol=1e-2, atol=1e-3)
+        assert torch.allclose(out32, torch.from_numpy(g["t_out"]), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["inj", "ext"])
+def test_msda_out_of_range_samples(golden_dir, tag):
+    g = _load(golden_dir, "msda.npz")
+    shapes, lsi = torch.from_numpy(g[f"{tag}_shapes"]), torch.from_numpy(g[f"{tag}_lsi"])
+    v, loc, aw = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("value", "loc", "aw"))
+    assert ((loc < 0) | (loc > 1)).float().mean() > 0.1  # zero-padding taps are exercised
+    ref = torch.from_numpy(g[f"{tag}_out"])
+    assert torch.allclose(R.msda_core(v, shapes, loc, aw), ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(R.msda_direct(v, shapes, lsi, loc, aw), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_window_bookkeeping_bit_exact(golden_dir):
+    g = _load(golden_dir, "bookkeeping.npz")
+    for (H, W, ws) in ((14, 14, 14), (16, 16, 14), (20, 20, 14), (64, 64, 14), (32, 32, 14)):
+        idx = torch.arange(1, 2 * H * W + 1, dtype=torch.float32).view(2, H, W, 1)
+        win, pad_hw = R.window_partition(idx, ws)
+        back = R.window_unpartition(win, ws, pad_hw, (H, W))
+        assert np.array_equal(win.squeeze(-1).to(torch.int64).numpy(), g[f"wp_{H}_{W}_{ws}"])
+        assert np.array_equal(back.squeeze(-1).to(torch.int64).numpy(), g[f"wu_{H}_{W}_{ws}"])
+
+
+def test_rel_pos_tables(golden_dir):
+    g = _load(golden_dir, "bookkeeping.npz")
+    for (q, L) in ((14, 27), (64, 127), (14, 31), (20, 31), (16, 31), (32, 127)):
+        out = R.get_rel_pos(q, q, torch.from_numpy(g[f"rp_in_{q}_{L}"]))
+        assert np.array_equal(out.numpy(), g[f"rp_out_{q}_{L}"])
+
+
+def _check_model(golden_dir, name, full):
+    cfg = CONFIGS[name]
+    g = _load(golden_dir, f"model_{name}.npz")
+    torch.manual_seed(0)
+    m = R.OracleEncoder(**cfg["kwargs"])
+    sd = R.seeded_state_dict(m, seed=cfg["seed"])
+    assert abs(weights_checksum(sd) - float(g["weights_checksum"])) <= 1e-6 * float(g["weights_checksum"])
+    m.load_state_dict(sd)
+    x = make_input(cfg)
+    assert abs(x.double().abs().sum().item() - float(g["x_checksum"])) < 1e-6 * float(g["x_checksum"])
+    fs, none = m(x)
+    assert none is None
+    for i, f in enumerate(fs):
+        assert list(f.shape) == list(g[f"f{i+1}_shape"])
+        pi = probe_index(f.numel(), 2048, seed=100 + i)
+        ref = torch.from_numpy(g[f"f{i+1}_probe"])
+        got = f.contiguous().flatten()[pi]
+        scale = float(g[f"f{i+1}_stats"][2])  # max |f|
+        assert (got - ref).abs().max().item() <= 2e-5 * scale, f"{name} f{i+1} probes"
+        st = g[f"f{i+1}_stats"]
+        assert abs(f.double().abs().mean().item() - st[1]) <= 1e-5 * st[1]
+        assert abs(f.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-5 * st[3]
+        if full:
+            ref_full = torch.from_numpy(g[f"f{i+1}"])
+            got_full = f if ref_full.shape == f.shape else f[..., ::2, ::2]
+            assert (got_full - ref_full).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320"])
+def test_oracle_tiny_models(golden_dir, name):
+    """224: window padding 14->14 none, rel-pos interpolation (pretrained 256); 256: pad 16->28; 320: pad 20->28."""
+    _check_model(golden_dir, name, full=True)
+
+
+def test_oracle_vitb512(golden_dir):
+    _check_model(golden_dir, "vitb512", full=False)
+
+
+def test_oracle_vitl1024(golden_dir):
+    """BASELINE.json configs[1] shape (DeLiVER ViT-L, 1024x1024), batch 1."""
+    _check_model(golden_dir, "vitl1024", full=False)
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    m = R.OracleEncoder(**CONFIGS["tiny224"]["kwargs"])
+    want = [l.split(" ")[0] for l in open(os.path.join(golden_dir, "state_dict_keys_tiny.txt"))]
+    assert list(m.state_dict().keys()) == want
