@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MI355X encoder forward (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one forward of the drop-in backbone `SAMAdapterbimodalMixModNewInTwinConvNEW` (ViT-L SAM encoder +
+RGB+LiDAR adapter, BASELINE configs[1]: 1024x1024, batch 2 per GPU) on synthetic tensors that are already resident
+in HBM, random-init weights of that architecture.  N > 1: one process per GPU, the batch is sharded (weak scaling:
+2 images per rank), and -- when the Segformer head stage is enabled -- one RCCL all-gather of the logits per step.
+Rank 0 prints ONE JSON line; `value` is the whole-job images/s (max-over-ranks time, barrier + synchronize on both
+sides of exactly K steps).
+
+Extra objects:
+  roofline     -- the dominant kernel (gemm_split3_kernel): algorithmic FLOPs (2*M*N*K per launch, NOT counting the
+                  3x split products) / HIP-event time of those launches, measured live in a profiled pass of one
+                  step right after the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline -- the CPU oracle (oracle/ref_encoder.py, a PyTorch-CPU restatement validated against the reference)
+                  timed on this box's host cores on ONE 1024x1024 image (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "multimodal-sam-adapter_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FLOPS_PER_IMAGE = 4.5207e12      # algorithmic GEMM/conv/bmm FLOPs per 1024^2 ViT-L image
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (BASELINE configs[1]: 2)")
+    ap.add_argument("--config", default="vitl1024", choices=["vitl1024", "vitb512", "tiny256"])
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import mmsa
+    from tests.configs import CONFIGS, make_input
+
+    cfg = CONFIGS[a.config]
+    torch.manual_seed(1234)
+    model = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    x = make_input(cfg, batch=a.batch, seed=1234 + rank).to(dev)
+
+    def step():
+        return model(x)
+
+    # warm-up (packs weights, sizes the workspace), then optional HIP-graph capture of the whole forward
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    graph = None
+    if not a.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    run = graph.replay if graph is not None else step
+    for _ in range(a.warmup):
+        run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    imgs = a.batch * world * a.steps
+    value = imgs / dt
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        prof = []
+        mmsa.ops.GEMM_PROFILE = prof
+        step()
+        torch.cuda.synchronize()
+        mmsa.ops.GEMM_PROFILE = None
+        flops, ms = mmsa.ops.collect_gemm_profile(prof)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_split3_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": len(prof), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+                    "kernel_ms_per_step": round(ms, 3),
+                    "note": "algorithmic 2*M*N*K FLOPs; the kernel issues 3x that on MFMA (bf16 hi/lo split for fp32-level parity)"}
+
+    cpu = None
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.config == "vitl1024":
+        from oracle import ref_encoder as R  # CPU baseline leg only
+        orc = R.OracleEncoder(**cfg["kwargs"])
+        xc = make_input(cfg, batch=1, seed=1234)
+        nthr = torch.get_num_threads()
+        tc = time.perf_counter()
+        orc(xc)
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(1.0 / tcpu, 4), "unit": "images/s", "cores": nthr, "kind": "port",
+               "sample": f"1 image 1024x1024 ViT-L RGB+LiDAR, fp32 PyTorch-CPU oracle, {tcpu:.1f} s"}
+
+    if rank == 0:
+        end_to_end_tflops = value * FLOPS_PER_IMAGE / 1e12 if a.config == "vitl1024" else None
+        out = {
+            "metric": "images/sec encoder fwd @1024x1024 RGB+LiDAR ViT-L",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3-split MFMA (fp32 accumulate, fp32 activations)", "data": "synthetic",
+            "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
+                       if a.config == "vitl1024" else f"{a.config} (not the BASELINE workload)",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       "collective": "none in the encoder (images independent)"},
+            "end_to_end_algorithmic_tflops": round(end_to_end_tflops, 1) if end_to_end_tflops else None,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -404,15 +404,17 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
         ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, qn)
         hid = ep["fc1"].n
+        hp = ep["fc2"].kpad  # K of fc2 padded to a multiple of 32; pad columns stay zero
         h1 = ws.get("ffn_h1", B * Nc, hid)
-        h2 = ws.get("ffn_h2", B * Nc, hid)
+        h2f = ws.get(f"ffn_h2_{hp}", B * Nc, hp, zero=True)
+        h2 = h2f[:, :hid]
         ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
         off = 0
         for (hh, wwd) in ((H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)):  # AM:462-470 token split 16n/4n/n
             ops.dwconv(h1[off:], ep["dw"], ep["dw_b"], h2[off:], B, hh, wwd, 3, act="gelu",
-                       xstride_b=Nc * hid, ystride_b=Nc * hid)
+                       xstride_b=Nc * hid, ystride_b=Nc * hp)
             off += hh * wwd
-        ops.gemm(h2, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
+        ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
 
     # ------------------------------------------------------------------ spatial prior module (AM:929-964)
     def _spm(self, x, B, H, W, c1_out, cbuf, Nc):

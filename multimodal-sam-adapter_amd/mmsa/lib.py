@@ -15,6 +15,11 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: the MI355X HIP library is required (no CPU/PyTorch fallback exists). "
         "Build it with: python multimodal-sam-adapter_amd/build.py")
 
+# torch must be imported first: it loads the HIP runtime it was built against, and libmmsa_hip.so's
+# libamdhip64.so.7 dependency then binds to that same runtime instance (one process, one HIP runtime, so the
+# library sees torch's device context, allocations and streams).
+import torch  # noqa: E402,F401
+
 _lib = ctypes.CDLL(LIB_PATH)
 
 P = c_void_p

@@ -5,7 +5,32 @@ import torch
 
 from . import lib
 
+import ctypes
+
 ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
+
+# When set to a list, every gemm() launch is bracketed by HIP events recorded on the launch stream and
+# (flops, start, stop) is appended; bench.py uses this for the roofline of the dominant kernel.
+GEMM_PROFILE = None
+
+
+def _event():
+    ev = ctypes.c_void_p()
+    lib.call("mmsa_event_create", ctypes.byref(ev))
+    return ev
+
+
+def collect_gemm_profile(prof):
+    """-> (total algorithmic FLOPs, total kernel milliseconds) of the recorded launches; frees the events."""
+    flops, ms = 0.0, 0.0
+    for f, e0, e1 in prof:
+        t = ctypes.c_float()
+        lib.call("mmsa_event_elapsed_ms", e0, e1, ctypes.byref(t))
+        flops += f
+        ms += t.value
+        lib.call("mmsa_event_destroy", e0)
+        lib.call("mmsa_event_destroy", e1)
+    return flops, ms
 
 
 def _stream():
@@ -62,10 +87,17 @@ def gemm(a, w, out, bias=None, act="none", alpha=1.0, colscale=None, resid=None,
     if resid is not None:
         pr, _, _, ldr = _mat(resid, "resid")
     ps = pixel_shuffle or (0, 0, 0)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = _event(), _event()
+        lib.call("mmsa_event_record", e0, _stream())
     lib.call("mmsa_gemm_split3", pa, lda, stride_a, w.hi.data_ptr(), w.lo.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, m, w.n, w.kpad, batch, ACT[act], alpha, 1 if pixel_shuffle else 0, ps[0], ps[1], ps[2],
              _stream())
+    if prof is not None:
+        lib.call("mmsa_event_record", e1, _stream())
+        prof.append((2.0 * m * w.n * w.k * batch, e0, e1))
     return out
 
 

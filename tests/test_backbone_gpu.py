@@ -1,0 +1,99 @@
+"""GPU end-to-end parity of the drop-in backbone (HIP path through the C ABI) against
+ (a) the committed golden vectors generated from the imported reference, and
+ (b) the CPU oracle on the same seeded weights and inputs (per-stage taps on failure)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_encoder as R
+from tests.configs import CONFIGS, make_input, probe_index
+from tests.util import assert_close, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(name):
+    import mmsa
+    cfg = CONFIGS[name]
+    torch.manual_seed(0)
+    orc = R.OracleEncoder(**cfg["kwargs"])
+    sd = R.seeded_state_dict(orc, seed=cfg["seed"])
+    orc.load_state_dict(sd)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    missing = m.load_state_dict(sd, strict=True)
+    return cfg, orc, m
+
+
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320"])
+def test_tiny_models_vs_golden_and_oracle(golden_dir, name):
+    cfg, orc, m = _build(name)
+    g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
+    x = make_input(cfg)
+    fs, none = m(x.to(DEV))
+    assert none is None and len(fs) == 4
+    ref, _ = orc(x)
+    for i, (f, r) in enumerate(zip(fs, ref)):
+        assert f.dtype == torch.float32 and f.is_cuda and f.is_contiguous()
+        assert_close(f, r, what=f"{name} f{i+1} vs oracle")
+        gold = torch.from_numpy(g[f"f{i+1}"])
+        got = f.cpu() if gold.shape == f.shape else f.cpu()[..., ::2, ::2]
+        assert_close(got, gold, what=f"{name} f{i+1} vs golden")
+
+
+def test_batch_and_determinism():
+    cfg, orc, m = _build("tiny256")
+    x = make_input(cfg, batch=3, seed=77)
+    f_a, _ = m(x.to(DEV))
+    f_a = [t.clone() for t in f_a]
+    f_b, _ = m(x.to(DEV))
+    ref, _ = orc(x)
+    for a, b, r in zip(f_a, f_b, ref):
+        assert_close(a, r, what="batch 3")
+        assert rel_l2(a, b) < 1e-5  # only the fp32 atomics of the Gram kernels are order dependent
+    # images are independent: batch element 1 alone gives the same result
+    f_1, _ = m(x[1:2].to(DEV))
+    for a, s in zip(f_a, f_1):
+        assert rel_l2(a[1:2], s) < 1e-5
+
+
+def test_vitb512_probes(golden_dir):
+    """BASELINE.json configs[0] geometry (ViT-B, 512x512) against the reference golden probes."""
+    cfg, orc, m = _build("vitb512")
+    del orc
+    g = np.load(os.path.join(golden_dir, "model_vitb512.npz"))
+    fs, _ = m(make_input(cfg).to(DEV))
+    for i, f in enumerate(fs):
+        pi = probe_index(f.numel(), 2048, seed=100 + i)
+        got = f.flatten()[pi.to(DEV)].cpu()
+        ref = torch.from_numpy(g[f"f{i+1}_probe"])
+        assert_close(got, ref, what=f"vitb512 f{i+1} probes")
+        st = g[f"f{i+1}_stats"]
+        assert abs(f.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-3 * st[3]
+
+
+def test_vitl1024_probes(golden_dir):
+    """BASELINE.json configs[1] geometry (ViT-L, 1024x1024 RGB+LiDAR) against the reference golden probes."""
+    cfg, orc, m = _build("vitl1024")
+    del orc
+    g = np.load(os.path.join(golden_dir, "model_vitl1024.npz"))
+    fs, _ = m(make_input(cfg).to(DEV))
+    for i, f in enumerate(fs):
+        pi = probe_index(f.numel(), 2048, seed=100 + i)
+        got = f.flatten()[pi.to(DEV)].cpu()
+        ref = torch.from_numpy(g[f"f{i+1}_probe"])
+        assert_close(got, ref, what=f"vitl1024 f{i+1} probes")
+        st = g[f"f{i+1}_stats"]
+        assert abs(f.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-3 * st[3]
+
+
+def test_rejects_wrong_inputs():
+    cfg, orc, m = _build("tiny224")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 6, 224, 224))  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 6, 256, 256, device=DEV))  # H=W=img_size required (AM:240-241)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 224, 224, device=DEV))
