@@ -1,0 +1,146 @@
+"""CPU tests of the host side: C-ABI surface, plugin API / state_dict contract, pack-time index and
+interpolation helpers, loud failure without a GPU, and the world_size-2 data-parallel harness over gloo."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import mmsa
+    hdr = open(os.path.join(ROOT, "include", "mmsa.h")).read()
+    declared = set(re.findall(r"\b(mmsa_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(mmsa.lib.raw, name), f"{name} declared in include/mmsa.h but not exported"
+    assert declared == set(mmsa.lib.SIGNATURES), "ctypes signature table and header disagree"
+    assert mmsa.lib.version() >= 100
+
+
+def test_plugin_registry_and_state_dict_contract(golden_dir):
+    import mmsa
+    from tests.configs import CONFIGS
+    for name in ("SAMAdapterbimodalMixModNewInTwinConvNEW", "SAMAdapterbimodalMixModNewInTwinConvNEWwithcp"):
+        m = mmsa.build_backbone(dict(type=name, conv_drop_path_rate=0.3, **CONFIGS["tiny224"]["kwargs"]))
+        lines = [l.rstrip("\n").split(" ", 1) for l in open(os.path.join(golden_dir, "state_dict_keys_tiny.txt"))]
+        sd = m.state_dict()
+        assert list(sd.keys()) == [k for k, _ in lines]
+        assert all(list(sd[k].shape) == eval(s) for k, s in lines)
+        assert not m.training
+
+
+def test_vitl_state_dict_contract(golden_dir):
+    from mmsa.params import param_spec
+    from tests.configs import CONFIGS
+    kw = dict(CONFIGS["vitl1024"]["kwargs"])
+    cfg = dict(embed_dim=kw["embed_dim"], depth=kw["depth"], num_heads=kw["num_heads"], mlp_ratio=kw["mlp_ratio"],
+               patch_size=16, pretrained_size=1024, img_size=1024, window_size=14, global_attn_indexes=kw["global_attn_indexes"],
+               conv_inplane=48, n_points=4, deform_num_heads=16, init_values=1e-6, interaction_indexes=kw["interaction_indexes"],
+               cffn_ratio=0.25, deform_ratio=0.5, arch="small", use_extra_extractor=True)
+    spec = param_spec(cfg)
+    lines = [l.rstrip("\n").split(" ", 1) for l in open(os.path.join(golden_dir, "state_dict_keys_vitl.txt"))]
+    assert [n for n, _, _ in spec] == [k for k, _ in lines]
+    assert all(list(s) == eval(t) for (_, s, _), (_, t) in zip(spec, lines))
+    assert sum(int(np.prod(s)) for _, s, k in spec if k == "param") == 455_9 * 10 ** 5 + sum(
+        int(np.prod(s)) for _, s, k in spec if k == "param") - 455_9 * 10 ** 5  # tautology guard; real check below
+    n_params = sum(int(np.prod(s)) if len(s) else 1 for _, s, k in spec if k == "param")
+    assert abs(n_params - 455.9e6) < 0.1e6
+
+
+def test_no_cpu_fallback_and_unsupported_configs():
+    import mmsa
+    from tests.configs import CONFIGS
+    kw = CONFIGS["tiny224"]["kwargs"]
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **kw))
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 6, 224, 224))
+    with pytest.raises(RuntimeError, match="GPU"):
+        mmsa.ops.layernorm(torch.zeros(4, 32), torch.ones(32), torch.zeros(32), 1e-6, torch.zeros(4, 32))
+    with pytest.raises(NotImplementedError):
+        mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **dict(kw, modalities_name=["rgb"], modalities_ch=[3])))
+    with pytest.raises(NotImplementedError):
+        m.train()
+    with pytest.raises(KeyError):
+        mmsa.build_backbone(dict(type="NoSuchBackbone"))
+
+
+def test_rel_pos_tables_bit_exact(golden_dir):
+    """get_rel_pos gather incl. the linear-interpolation branch (IE:554-584) -- index table bit-exact."""
+    from mmsa.backbone import _rel_table, rel_pos_index
+    g = np.load(os.path.join(golden_dir, "bookkeeping.npz"))
+    for (q, L) in ((14, 27), (64, 127), (14, 31), (20, 31), (16, 31), (32, 127)):
+        tab = torch.from_numpy(g[f"rp_in_{q}_{L}"])
+        out = _rel_table(q, tab)
+        ref = torch.from_numpy(g[f"rp_out_{q}_{L}"])
+        if L == 2 * q - 1:
+            assert torch.equal(out, ref)  # pure gather
+        else:
+            assert torch.allclose(out, ref, rtol=1e-6, atol=2e-6)  # fp32 lerp rounding
+        idx = rel_pos_index(q, q)
+        assert idx.dtype == torch.int64 and idx.min() == 0 and idx.max() == 2 * q - 2
+        assert torch.equal(idx, (torch.arange(q)[:, None] - torch.arange(q)[None, :]) + q - 1)
+
+
+def test_pos_embed_bicubic_matches_torch():
+    from mmsa.backbone import _bicubic_resize
+    src = torch.randn(1, 16, 16, 8)
+    for (H, W) in ((14, 14), (20, 20), (16, 16), (32, 24)):
+        ref = F.interpolate(src.permute(0, 3, 1, 2), size=(H, W), mode="bicubic", align_corners=False).permute(0, 2, 3, 1)[0]
+        assert torch.allclose(_bicubic_resize(src[0], H, W), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_reference_points_match_oracle():
+    from mmsa.backbone import _ref_points
+    from oracle import ref_encoder as R
+    for shapes in ([(14, 14)], [(28, 28), (14, 14), (7, 7)], [(128, 128), (64, 64), (32, 32)]):
+        assert torch.equal(_ref_points(shapes), R.get_reference_points(shapes, torch.float32).reshape(-1, 2))
+
+
+def test_shard_ranges_cover_batch():
+    from mmsa.dist import shard_range
+    for gb in (0, 1, 7, 16, 17):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_range(gb, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmsa import dist as D
+    lo, hi = D.shard_range(6, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 2, 3).contiguous() * 10 + rank
+    allg = D.allgather_logits(local)
+    slow = D.max_over_ranks(0.5 + rank, torch.device("cpu"))
+    q.put((rank, lo, hi, allg.clone(), slow))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_harness_gloo_world2():
+    """N>1 path of bench.py: batch sharding, ONE all-gather of the per-rank logits, max-over-ranks timing."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, g0, s0), (r1, lo1, hi1, g1, s1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 6)
+    assert torch.equal(g0, g1) and g0.shape == (6, 2, 3)
+    assert g0[:, 0, 0].tolist() == [0.0, 10.0, 20.0, 31.0, 41.0, 51.0]  # rank-major order
+    assert s0 == s1 == 1.5
