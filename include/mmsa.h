@@ -100,7 +100,7 @@ int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int
 /* GFFM LayerNorm(H*W) statistics + FFRM gate (AM:241,265 and AM:158-162), see csrc/norm.hip. */
 int mmsa_ffrm_finalize(const double* stats, int B, int HW, int C, float mean_w, float mean_b, const float* Wc,
                        const float* gn_w, const float* gn_b, float* mean_o, float* rstd_o, float* mult_o,
-                       mmsa_stream_t stream);
+                       float* scratch /* [2,B,C] */, mmsa_stream_t stream);
 int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rstd, const float* mult, const float* w,
                     const float* bias, float* y, long ldy, int B, int HW, int C, mmsa_stream_t stream);
 

@@ -90,10 +90,135 @@ __global__ __launch_bounds__(256) void gconv_nhwc_kernel(const float* __restrict
   }
 }
 
+// Tiled grouped conv for the GFE qkv convs (groups = 32, cin_g / cout_g = 3..72): one workgroup = a 16x16 pixel
+// tile of one (image, group).  The group's input halo tile is staged through LDS in chunks of 8 input channels
+// (layout [ci][row][col]: a wavefront reads consecutive pixels -> conflict free), every lane keeps COUT
+// accumulators, and the weights -- identical for all lanes -- come through the scalar path (wave-uniform index),
+// so the inner loop is one LDS read per COUT FMAs.
+template <int COUT, int K>
+__global__ __launch_bounds__(256) void gconv_tiled_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                          float* __restrict__ y, long ldy, int H, int W, int cin_g, int tilesX) {
+  constexpr int PAD = K / 2, TW = 16 + 2 * PAD, CCH = 8;
+  __shared__ float tile[CCH][TW * TW];
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int tx0 = (blockIdx.x % tilesX) * 16, ty0 = (blockIdx.x / tilesX) * 16;
+  const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
+  const float* xb = x + (long)b * H * W * ldx + g * cin_g;
+  const float* wg = w + (long)g * K * K * cin_g * COUT;
+  float acc[COUT];
+#pragma unroll
+  for (int i = 0; i < COUT; ++i) acc[i] = 0.f;
+  for (int ci0 = 0; ci0 < cin_g; ci0 += CCH) {
+    const int nch = min(CCH, cin_g - ci0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TW * TW * nch; i += 256) {
+      const int ci = i % nch, pos = i / nch;
+      const int ly = pos / TW, lx = pos - ly * TW;
+      const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+      float v = 0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xb[((long)iy * W + ix) * ldx + ci0 + ci];
+      tile[ci][pos] = v;
+    }
+    __syncthreads();
+    for (int ci = 0; ci < nch; ++ci) {
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const float xv = tile[ci][(py + kh) * TW + px + kw];
+          const float* wp = wg + ((long)(kh * K + kw) * cin_g + ci0 + ci) * COUT;
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[co] += xv * wp[co];
+        }
+    }
+  }
+  const int oy = ty0 + py, ox = tx0 + px;
+  if (oy < H && ox < W) {
+    float* yp = y + ((long)b * H * W + (long)oy * W + ox) * ldy + g * COUT;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) yp[co] = acc[co];
+  }
+}
+
+// 3x3 conv with 2 input / 2 output channels per group (gated-MLP dwconv, AM:123-124), float4 = two groups.
+// weights [G][9][ci=2][co=2] -> one float4 per (group, tap).
+__global__ __launch_bounds__(256) void dwpair_nhwc_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                          float* __restrict__ y, long ldy, int B, int H, int W, int C) {
+  const int c4n = C >> 2;
+  const long total = (long)B * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long t = i / c4n;
+    const int ww = (int)(t % W);
+    t /= W;
+    const int hh = (int)(t % H);
+    const int b = (int)(t / H);
+    const float* xb = x + (long)b * H * W * ldx + c;
+    const float* wa = w + (long)(c >> 1) * 36;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = hh + kh - 1;
+      if (ih < 0 || ih >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ww + kw - 1;
+        if (iw < 0 || iw >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(xb + ((long)ih * W + iw) * ldx);
+        const float4 fa = *reinterpret_cast<const float4*>(wa + (kh * 3 + kw) * 4);
+        const float4 fb = *reinterpret_cast<const float4*>(wa + 36 + (kh * 3 + kw) * 4);
+        acc.x += v.x * fa.x + v.y * fa.z;
+        acc.y += v.x * fa.y + v.y * fa.w;
+        acc.z += v.z * fb.x + v.w * fb.z;
+        acc.w += v.z * fb.y + v.w * fb.w;
+      }
+    }
+    *reinterpret_cast<float4*>(y + (((long)b * H + hh) * W + ww) * ldy + c) = acc;
+  }
+}
+
+template <int COUT>
+static void launch_gconv_tiled(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W, int G,
+                               int cin_g, int k, hipStream_t stream) {
+  const int tx = cdiv(W, 16), ty = cdiv(H, 16);
+  dim3 grid(tx * ty, G, B);
+  if (k == 1)
+    hipLaunchKernelGGL((gconv_tiled_kernel<COUT, 1>), grid, dim3(256), 0, stream, x, ldx, w, y, ldy, H, W, cin_g, tx);
+  else
+    hipLaunchKernelGGL((gconv_tiled_kernel<COUT, 3>), grid, dim3(256), 0, stream, x, ldx, w, y, ldy, H, W, cin_g, tx);
+}
+
 extern "C" int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                                int B, int H, int W, int G, int cin_g, int cout_g, int k, int act, hipStream_t stream) {
   MMSA_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && G > 0 && cin_g > 0 && cout_g > 0, "gconv_nhwc: bad args");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "gconv_nhwc: odd kernel <= 7 expected, got %d", k);
+  if (!bias && act == ACT_NONE && (k == 1 || k == 3)) {
+    bool done = true;
+    switch (cout_g) {
+      case 3: launch_gconv_tiled<3>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 6: launch_gconv_tiled<6>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 9: launch_gconv_tiled<9>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 12: launch_gconv_tiled<12>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 18: launch_gconv_tiled<18>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 24: launch_gconv_tiled<24>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 36: launch_gconv_tiled<36>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      case 72: launch_gconv_tiled<72>(x, ldx, w, y, ldy, B, H, W, G, cin_g, k, stream); break;
+      default: done = false;
+    }
+    if (done) {
+      MMSA_CHECK_LAUNCH("gconv_nhwc(tiled)");
+      return MMSA_OK;
+    }
+    if (k == 3 && cin_g == 2 && cout_g == 2 && (G & 1) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 &&
+        ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w)) & 15) == 0) {
+      const long total4 = (long)B * H * W * (G * 2 / 4);
+      int blocks = cdiv(total4, 256);
+      if (blocks > 16384) blocks = 16384;
+      hipLaunchKernelGGL(dwpair_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, w, y, ldy, B, H, W, G * 2);
+      MMSA_CHECK_LAUNCH("gconv_nhwc(pair)");
+      return MMSA_OK;
+    }
+  }
   const long total = (long)B * H * W * G * cout_g;
   int blocks = cdiv(total, 256);
   if (blocks > 32768) blocks = 32768;

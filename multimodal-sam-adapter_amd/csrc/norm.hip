@@ -148,21 +148,14 @@ extern "C" int mmsa_colstats(const float* x, long ldx, long strideB, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// FFRM finalize (one block per batch image).  From the column stats of the GFFM output F (before its
-// LayerNorm over HW) derive, per channel:  mean, rstd of the spatial LayerNorm (eps 1e-5, AM:241,265) and the
-// FFRM gate (AM:158-162):  avg = mean_p(LN(F))  [analytic: rstd*(sum_p w[p]F/HW - mean*mean(w)) + mean(b)],
-// z = Wc . avg (1x1 conv, no bias), GroupNorm(32) over channels (spatial 1x1), ReLU, sigmoid, mult = 1 + a.
-__global__ __launch_bounds__(256) void ffrm_finalize_kernel(const double* __restrict__ stats, int HW, int C,
-                                                            float mean_w, float mean_b,
-                                                            const float* __restrict__ Wc, const float* __restrict__ gn_w,
-                                                            const float* __restrict__ gn_b,
-                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                            float* __restrict__ mult_o) {
-  extern __shared__ float sm[];  // avg[C], z[C], gmean[32], grstd[32]
-  float* avg = sm;
-  float* z = sm + C;
-  float* gmean = z + C;
-  float* grstd = gmean + 32;
+// FFRM finalize.  From the column stats of the GFFM output F (before its LayerNorm over HW) derive, per channel:
+// mean, rstd of the spatial LayerNorm (eps 1e-5, AM:241,265) and the FFRM gate (AM:158-162):
+//   avg = mean_p(LN(F))  [analytic: rstd*(sum_p w[p]F/HW - mean*mean(w)) + mean(b)],
+//   z = Wc . avg (1x1 conv, no bias), GroupNorm(32) over channels (spatial 1x1), ReLU, sigmoid, mult = 1 + a.
+// Three small launches: stats (grid B), matvec (one wave per output channel, grid C/4 x B), gate (grid B).
+__global__ __launch_bounds__(256) void ffrm_stats_kernel(const double* __restrict__ stats, int HW, int C, float mean_w, float mean_b,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                         float* __restrict__ avg_o) {
   const int b = blockIdx.x;
   const double* st = stats + (long)b * 3 * C;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -172,25 +165,41 @@ __global__ __launch_bounds__(256) void ffrm_finalize_kernel(const double* __rest
     const double rs = 1.0 / sqrt(var + 1e-5);
     mean_o[(long)b * C + c] = (float)m;
     rstd_o[(long)b * C + c] = (float)rs;
-    avg[c] = (float)(rs * (st[2 * C + c] / HW - m * (double)mean_w) + (double)mean_b);
+    avg_o[(long)b * C + c] = (float)(rs * (st[2 * C + c] / HW - m * (double)mean_w) + (double)mean_b);
   }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int o = wv; o < C; o += 4) {
-    float s = 0.f;
-    for (int i = lane; i < C; i += 64) s += Wc[(long)o * C + i] * avg[i];
-    s = wave_sum(s);
-    if (lane == 0) z[o] = s;
+}
+
+__global__ __launch_bounds__(256) void ffrm_matvec_kernel(const float* __restrict__ Wc, const float* __restrict__ avg,
+                                                          float* __restrict__ z, int C) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (o >= C) return;
+  const float* wr = Wc + (long)o * C;
+  const float* av = avg + (long)b * C;
+  float s = 0.f;
+  for (int i = lane * 4; i < C; i += 256) {
+    const float4 w4 = *reinterpret_cast<const float4*>(wr + i);
+    const float4 a4 = *reinterpret_cast<const float4*>(av + i);
+    s += w4.x * a4.x + w4.y * a4.y + w4.z * a4.z + w4.w * a4.w;
   }
-  __syncthreads();
+  s = wave_sum(s);
+  if (lane == 0) z[(long)b * C + o] = s;
+}
+
+__global__ __launch_bounds__(256) void ffrm_gate_kernel(const float* __restrict__ z, const float* __restrict__ gn_w,
+                                                        const float* __restrict__ gn_b, float* __restrict__ mult_o, int C) {
+  __shared__ float gmean[32], grstd[32];
+  const int b = blockIdx.x;
+  const float* zb = z + (long)b * C;
   const int cg = C / 32;
   if (threadIdx.x < 32) {
     float m = 0.f;
-    for (int i = 0; i < cg; ++i) m += z[threadIdx.x * cg + i];
+    for (int i = 0; i < cg; ++i) m += zb[threadIdx.x * cg + i];
     m /= cg;
     float v = 0.f;
     for (int i = 0; i < cg; ++i) {
-      const float d = z[threadIdx.x * cg + i] - m;
+      const float d = zb[threadIdx.x * cg + i] - m;
       v += d * d;
     }
     gmean[threadIdx.x] = m;
@@ -199,19 +208,23 @@ __global__ __launch_bounds__(256) void ffrm_finalize_kernel(const double* __rest
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     const int gi = c / cg;
-    float t = (z[c] - gmean[gi]) * grstd[gi] * gn_w[c] + gn_b[c];
+    float t = (zb[c] - gmean[gi]) * grstd[gi] * gn_w[c] + gn_b[c];
     t = fmaxf(t, 0.f);
     mult_o[(long)b * C + c] = 1.0f + 1.0f / (1.0f + expf(-t));
   }
 }
 
+// scratch: float [2, B, C] (avg, z)
 extern "C" int mmsa_ffrm_finalize(const double* stats, int B, int HW, int C, float mean_w, float mean_b,
                                   const float* Wc, const float* gn_w, const float* gn_b,
-                                  float* mean_o, float* rstd_o, float* mult_o, hipStream_t stream) {
-  MMSA_CHECK_ARG(stats && Wc && gn_w && gn_b && mean_o && rstd_o && mult_o, "ffrm_finalize: null pointer");
+                                  float* mean_o, float* rstd_o, float* mult_o, float* scratch, hipStream_t stream) {
+  MMSA_CHECK_ARG(stats && Wc && gn_w && gn_b && mean_o && rstd_o && mult_o && scratch, "ffrm_finalize: null pointer");
   MMSA_CHECK_ARG(C % 32 == 0 && C <= 8192, "ffrm_finalize: C=%d must be a multiple of 32", C);
-  hipLaunchKernelGGL(ffrm_finalize_kernel, dim3(B), dim3(256), (2 * C + 64) * sizeof(float), stream, stats, HW, C, mean_w,
-                     mean_b, Wc, gn_w, gn_b, mean_o, rstd_o, mult_o);
+  float* avg = scratch;
+  float* z = scratch + (long)B * C;
+  hipLaunchKernelGGL(ffrm_stats_kernel, dim3(B), dim3(256), 0, stream, stats, HW, C, mean_w, mean_b, mean_o, rstd_o, avg);
+  hipLaunchKernelGGL(ffrm_matvec_kernel, dim3(cdiv(C, 4), B), dim3(256), 0, stream, Wc, avg, z, C);
+  hipLaunchKernelGGL(ffrm_gate_kernel, dim3(B), dim3(256), 0, stream, z, gn_w, gn_b, mult_o, C);
   MMSA_CHECK_LAUNCH("ffrm_finalize");
   return MMSA_OK;
 }

@@ -519,7 +519,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         mean = ws.get("nk_mean", B, C)
         rstd = ws.get("nk_rstd", B, C)
         mult = ws.get("nk_mult", B, C)
-        ops.ffrm_finalize(st, B, HW, C, lv["lnw_mean"], lv["lnb_mean"], lv["ffrm_w"], lv["gn_w"], lv["gn_b"], mean, rstd, mult)
+        ops.ffrm_finalize(st, B, HW, C, lv["lnw_mean"], lv["lnb_mean"], lv["ffrm_w"], lv["gn_w"], lv["gn_b"], mean, rstd, mult,
+                          ws.get("nk_ffrm", 2 * B, C))
         fn = ws.get("nk_g", P, C)  # gcat is dead now
         ops.lnhw_apply(fbuf, mean, rstd, mult, lv["lnw"], lv["lnb"], fn, B, HW)
         # gated MLP on the local branch (AM:127-132) and Scale2 (AM:279-280)

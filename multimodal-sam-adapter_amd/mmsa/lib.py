@@ -43,7 +43,7 @@ SIGNATURES = {
     "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, I, I, I, I, I, P],
     "mmsa_colstats": [P, L, L, P, I, I, I, P, P],
-    "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P],
+    "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P, P],
     "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
     "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, I, I, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],

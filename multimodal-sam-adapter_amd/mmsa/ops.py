@@ -156,9 +156,9 @@ def colstats(x, stride_b, b, hw, out, wrow=None):
     return out
 
 
-def ffrm_finalize(stats, b, hw, c, mean_w, mean_b, wc, gn_w, gn_b, mean_o, rstd_o, mult_o):
+def ffrm_finalize(stats, b, hw, c, mean_w, mean_b, wc, gn_w, gn_b, mean_o, rstd_o, mult_o, scratch):
     lib.call("mmsa_ffrm_finalize", _chk(stats, torch.float64), b, hw, c, mean_w, mean_b, _chk(wc), _chk(gn_w), _chk(gn_b),
-             _chk(mean_o), _chk(rstd_o), _chk(mult_o), _stream())
+             _chk(mean_o), _chk(rstd_o), _chk(mult_o), _chk(scratch), _stream())
 
 
 def lnhw_apply(x, mean, rstd, mult, w, bias, out, b, hw):

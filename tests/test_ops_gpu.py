@@ -147,7 +147,7 @@ def test_colstats_ffrm_lnhw(ops):
     mean, rstd, mult = (torch.empty(B, C, device=DEV) for _ in range(3))
     ops.ffrm_finalize(st, B, HW, C, float(ln.weight.double().mean()), float(ln.bias.double().mean()),
                       sd["conv_atten.conv.weight"].reshape(C, C).contiguous().to(DEV), sd["conv_atten.gn.weight"].to(DEV),
-                      sd["conv_atten.gn.bias"].to(DEV), mean, rstd, mult)
+                      sd["conv_atten.gn.bias"].to(DEV), mean, rstd, mult, torch.empty(2 * B, C, device=DEV))
     out = torch.empty(B * HW, C, device=DEV)
     ops.lnhw_apply(x, mean, rstd, mult, ln.weight.data.to(DEV), ln.bias.data.to(DEV), out, B, HW)
     assert_close(out.view(B, H, W, C).permute(0, 3, 1, 2), ref, tol=1e-4, what="lnhw+ffrm")
