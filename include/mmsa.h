@@ -54,7 +54,8 @@ int mmsa_ms_deform_attn_forward(const float* value, const int64_t* spatial_shape
  * (columns [0, M*L*P*2) offsets, then M*L*P logits), the per-query reference points [Lq,2], does softmax over L*P,
  * loc = ref + off/(W_l,H_l), and the sampling gather.  out [N*Lq, ldo]. */
 int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                    const float* raw, long ldraw, const float* ref_points, float* out, long ldo, int batch,
+                    const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
+                    uint16_t* out_hi, uint16_t* out_lo, long ldop /* optional bf16 hi/lo planes output */, int batch,
                     int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
                     mmsa_stream_t stream);
 
@@ -64,10 +65,14 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * (broadcast over the batch, e.g. pos_embed).  out_mode 1 = 2x2 pixel-shuffle store for ConvTranspose2d(k=2,s=2)
  * (BK:55,324): row (b,h,w), column (i,j,co) -> row (b,2h+i,2w+j), column co; resid uses the destination index.
  * Call sites replaced: IE:488,499,162-167; TC:107-111,297-304,328-335; AM:947-950,447-451,87-89,121-126,286-290;
- * ops/modules/ms_deform_attn.py:103,107-110,129; BK:324. */
-int mmsa_gemm_split3(const float* A, long lda, long strideA, const uint16_t* Whi, const uint16_t* Wlo, long strideW,
+ * ops/modules/ms_deform_attn.py:103,107-110,129; BK:324.
+ * A is EITHER fp32 (`A`, split to hi/lo while staged) OR activation planes (`Ahi`,`Alo`: bf16 hi/lo written by the
+ * producing kernel; lda/strideA then count bf16 elements).  The result goes to fp32 `C`, to planes `Chi`/`Clo`, or both. */
+int mmsa_gemm_split3(const float* A, const uint16_t* Ahi, const uint16_t* Alo, long lda, long strideA,
+                     const uint16_t* Whi, const uint16_t* Wlo, long strideW,
                      const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,
-                     long strideR, int resid_mod, float beta, float* C, long ldc, long strideC, int M, int N, int K,
+                     long strideR, int resid_mod, float beta, float* C, long ldc, long strideC,
+                     uint16_t* Chi, uint16_t* Clo, long ldcp, long strideCp, int M, int N, int K,
                      int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, mmsa_stream_t stream);
 
 /* fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad], zero padded. */
@@ -79,11 +84,17 @@ int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pa
  * window_size 0 = global.  out [B*H*W, ldo]. head_dim in {32, 64}. */
 int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo, int B,
                    int H, int W, int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
+/* same with qkv, qkv_bias and the output as bf16 hi/lo planes (strides in bf16 elements) */
+int mmsa_attention_planes(const uint16_t* qkv_hi, const uint16_t* qkv_lo, long ldq, const uint16_t* bias_hi,
+                          const uint16_t* bias_lo, const float* rp, uint16_t* out_hi, uint16_t* out_lo, long ldo, int B,
+                          int H, int W, int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
 
 /* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
  * get_rel_pos(...)  (IE:554-584), (KH,KW,QS) = (ws,ws,ws) for windowed blocks or (H,W,max) for global ones. */
 int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp, int B, int H, int W,
                      int heads, int head_dim, int window_size, mmsa_stream_t stream);
+int mmsa_relpos_bias_planes(const uint16_t* qkv_hi, const uint16_t* qkv_lo, long ldq, const float* Rh, const float* Rw,
+                            float* rp, int B, int H, int W, int heads, int head_dim, int window_size, mmsa_stream_t stream);
 
 /* --- normalisation / reductions ------------------------------------------------------------------------------
  * Row LayerNorm (biased variance): y = (x-mean)/sqrt(var+eps)*w + b; optional y2 = x + y.  map_mode 1 scatters
@@ -91,7 +102,8 @@ int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* R
  * the ConvNeXt 2x2 s2 downsample conv, TC:328-335).  Replaces nn.LayerNorm / LN2d / WithBias_LayerNorm:
  * IE:367,377; AM:479-487,519-520,51-74; mmpretrain_custom/models/utils/norm.py:51-90. */
 int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps, float* y, long ldy,
-                        float* y2, long ldy2, int rows, int C, int map_mode, int map_H, int map_W, mmsa_stream_t stream);
+                        float* y2, long ldy2, uint16_t* yhi, uint16_t* ylo, long ldp /* optional planes of y */,
+                        int rows, int C, int map_mode, int map_H, int map_W, mmsa_stream_t stream);
 
 /* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
 int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C, double* out,
@@ -108,7 +120,8 @@ int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rs
  * dwconv: weights tap-major [k*k, C]; replaces TC:69-70,102; AM:288; AM:459,464-469.
  * gconv: weights [G][k*k][cin_g][cout_g]; replaces AM:87-88,123-124.
  * im2col_nchw: out[(b,ph,pw)][(c,kh,kw)] from NCHW input channels [c0, c0+Cin) (IE:658-663, TC:297-304). */
-int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y, long ldy,
+int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y,
+                     uint16_t* yhi, uint16_t* ylo /* optional planes, same ldy/ystrideB */, long ldy,
                      long ystrideB, int B, int H, int W, int C, int k, int act, mmsa_stream_t stream);
 int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
                     int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);

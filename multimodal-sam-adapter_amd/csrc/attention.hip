@@ -25,6 +25,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct AttnArgs {
   const float* qkv; long ldq;    // [B*T, 3*D]: q | k | v, channel = head*HD + c   (IE:488 memory order)
   const float* qkv_bias;         // [3*D]
+  const unsigned short* qhi; const unsigned short* qlo;      // planes form of qkv (PL kernels), same ldq
+  const unsigned short* bhi; const unsigned short* blo;      // planes form of qkv_bias
+  unsigned short* ohi; unsigned short* olo;                  // planes output (PL kernels), row stride ldo
   const float* rp;               // [B, heads, T, KH+KW] rel-pos bias terms (relpos kernel below)
   float* out; long ldo;          // [B*T, D], channel = head*HD + c (IE:498)
   int B, H, W, heads, D;
@@ -37,7 +40,7 @@ struct AttnArgs {
   float scale;
 };
 
-template <int HD>
+template <int HD, bool PL>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
@@ -71,9 +74,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
   };
 
-  const float* qkv_b = a.qkv + (long)b * T * a.ldq + head * HD;
-  const float* kbias = a.qkv_bias + a.D + head * HD;
-  const float* vbias = a.qkv_bias + 2 * a.D + head * HD;
+  const long qkv_off = (long)b * T * a.ldq + head * HD;
+  const float* qkv_b = PL ? nullptr : a.qkv + qkv_off;
+  const float* kbias = PL ? nullptr : a.qkv_bias + a.D + head * HD;
+  const float* vbias = PL ? nullptr : a.qkv_bias + 2 * a.D + head * HD;
+  const unsigned short* ph_b = PL ? a.qhi + qkv_off : nullptr;
+  const unsigned short* pl_b = PL ? a.qlo + qkv_off : nullptr;
 
   // ---- bias tables for the block's 128 queries -> LDS
   {
@@ -96,9 +102,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int jq = q0 + wave * 32 + sub * 16 + l15;
     const int tq = token_of(jq);
     tq_sub[sub] = tq;
-    const float* qp = qkv_b + (long)(tq >= 0 ? tq : 0) * a.ldq;
+    const long qrow = (long)(tq >= 0 ? tq : 0) * a.ldq;
+    const float* qp = qkv_b + qrow;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (PL) {  // planes: fragments are plain 16-byte loads; the softmax scale is applied to S instead
+        qh[sub][ks] = *reinterpret_cast<const bf16x8*>(ph_b + qrow + ks * 32 + 8 * G);
+        ql_[sub][ks] = *reinterpret_cast<const bf16x8*>(pl_b + qrow + ks * 32 + 8 * G);
+        continue;
+      }
       float4 v0 = *reinterpret_cast<const float4*>(qp + ks * 32 + 8 * G);
       float4 v1 = *reinterpret_cast<const float4*>(qp + ks * 32 + 8 * G + 4);
       v0.x *= a.scale; v0.y *= a.scale; v0.z *= a.scale; v0.w *= a.scale;
@@ -112,42 +124,76 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
   }
 
-  // ---- K/V staging: thread -> (key = tid/4, quarter = tid%4), HD/4 floats of K and of V
-  constexpr int NF4 = HD / 16;  // float4 per thread per operand
+  // ---- K/V staging: thread -> (key = tid/4, quarter = tid%4), HD/4 channels of K and of V
+  constexpr int NF4 = HD / 16;  // float4 per thread per operand (fp32 input)
+  constexpr int NU = HD / 32;   // uint4 per thread per plane per operand (planes input)
   const int skey = tid >> 2, squart = tid & 3;
   float4 rk[NF4], rv[NF4];
-#define LOAD_KV(kb_)                                                        \
-  do {                                                                      \
-    const int tk_ = token_of((kb_) * 64 + skey);                            \
-    _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                       \
-      const int c = squart * (HD / 4) + 4 * i;                              \
-      if (tk_ >= 0) {                                                       \
-        const float* p = qkv_b + (long)tk_ * a.ldq + c;                     \
-        rk[i] = *reinterpret_cast<const float4*>(p + a.D);                  \
-        rv[i] = *reinterpret_cast<const float4*>(p + 2 * a.D);              \
-      } else if (tk_ == -1) {                                               \
-        rk[i] = *reinterpret_cast<const float4*>(kbias + c);                \
-        rv[i] = *reinterpret_cast<const float4*>(vbias + c);                \
-      } else {                                                              \
-        rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);                            \
-        rv[i] = rk[i];                                                      \
-      }                                                                     \
-    }                                                                       \
+  uint4 rkh[NU], rkl[NU], rvh[NU], rvl[NU];
+#define LOAD_KV(kb_)                                                                         \
+  do {                                                                                       \
+    const int tk_ = token_of((kb_) * 64 + skey);                                             \
+    if constexpr (PL) {                                                                      \
+      _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                       \
+        const int c = squart * (HD / 4) + 8 * i;                                             \
+        if (tk_ >= 0) {                                                                      \
+          const long o_ = (long)tk_ * a.ldq + c;                                             \
+          rkh[i] = *reinterpret_cast<const uint4*>(ph_b + o_ + a.D);                         \
+          rkl[i] = *reinterpret_cast<const uint4*>(pl_b + o_ + a.D);                         \
+          rvh[i] = *reinterpret_cast<const uint4*>(ph_b + o_ + 2 * a.D);                     \
+          rvl[i] = *reinterpret_cast<const uint4*>(pl_b + o_ + 2 * a.D);                     \
+        } else if (tk_ == -1) {                                                              \
+          rkh[i] = *reinterpret_cast<const uint4*>(a.bhi + a.D + head * HD + c);             \
+          rkl[i] = *reinterpret_cast<const uint4*>(a.blo + a.D + head * HD + c);             \
+          rvh[i] = *reinterpret_cast<const uint4*>(a.bhi + 2 * a.D + head * HD + c);         \
+          rvl[i] = *reinterpret_cast<const uint4*>(a.blo + 2 * a.D + head * HD + c);         \
+        } else {                                                                             \
+          rkh[i] = make_uint4(0u, 0u, 0u, 0u); rkl[i] = rkh[i]; rvh[i] = rkh[i]; rvl[i] = rkh[i]; \
+        }                                                                                    \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
+        const int c = squart * (HD / 4) + 4 * i;                                             \
+        if (tk_ >= 0) {                                                                      \
+          const float* p = qkv_b + (long)tk_ * a.ldq + c;                                    \
+          rk[i] = *reinterpret_cast<const float4*>(p + a.D);                                 \
+          rv[i] = *reinterpret_cast<const float4*>(p + 2 * a.D);                             \
+        } else if (tk_ == -1) {                                                              \
+          rk[i] = *reinterpret_cast<const float4*>(kbias + c);                               \
+          rv[i] = *reinterpret_cast<const float4*>(vbias + c);                               \
+        } else {                                                                             \
+          rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+          rv[i] = rk[i];                                                                     \
+        }                                                                                    \
+      }                                                                                      \
+    }                                                                                        \
   } while (0)
-#define STORE_KV()                                                          \
-  do {                                                                      \
-    _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                       \
-      const int c = squart * (HD / 4) + 4 * i;                              \
-      uint2 h, l;                                                           \
-      split4(rk[i], h, l);                                                  \
-      const int ko = (c >> 3) * (64 * 16) + skey * 16 + (c & 7) * 2;        \
-      *reinterpret_cast<uint2*>(Khi + ko) = h;                              \
-      *reinterpret_cast<uint2*>(Klo + ko) = l;                              \
-      split4(rv[i], h, l);                                                  \
-      const int vo = skey * VSTR + c * 2;                                   \
-      *reinterpret_cast<uint2*>(Vhi + vo) = h;                              \
-      *reinterpret_cast<uint2*>(Vlo + vo) = l;                              \
-    }                                                                       \
+#define STORE_KV()                                                                           \
+  do {                                                                                       \
+    if constexpr (PL) {                                                                      \
+      _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                       \
+        const int c = squart * (HD / 4) + 8 * i;                                             \
+        const int ko = (c >> 3) * (64 * 16) + skey * 16;                                     \
+        *reinterpret_cast<uint4*>(Khi + ko) = rkh[i];                                        \
+        *reinterpret_cast<uint4*>(Klo + ko) = rkl[i];                                        \
+        const int vo = skey * VSTR + c * 2;                                                  \
+        *reinterpret_cast<uint4*>(Vhi + vo) = rvh[i];                                        \
+        *reinterpret_cast<uint4*>(Vlo + vo) = rvl[i];                                        \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
+        const int c = squart * (HD / 4) + 4 * i;                                             \
+        uint2 h, l;                                                                          \
+        split4(rk[i], h, l);                                                                 \
+        const int ko = (c >> 3) * (64 * 16) + skey * 16 + (c & 7) * 2;                       \
+        *reinterpret_cast<uint2*>(Khi + ko) = h;                                             \
+        *reinterpret_cast<uint2*>(Klo + ko) = l;                                             \
+        split4(rv[i], h, l);                                                                 \
+        const int vo = skey * VSTR + c * 2;                                                  \
+        *reinterpret_cast<uint2*>(Vhi + vo) = h;                                             \
+        *reinterpret_cast<uint2*>(Vlo + vo) = l;                                             \
+      }                                                                                      \
+    }                                                                                        \
   } while (0)
 
   f32x4 o[2][DT];
@@ -205,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
           if (j < a.Nk) {
             const int kh = (int)(((unsigned)j * a.magicKW) >> 24);
             const int kw = j - kh * a.KW;
-            v = s[sub][t][r] + bhq[kh] + bwq[kw];
+            v = (PL ? s[sub][t][r] * a.scale : s[sub][t][r]) + bhq[kh] + bwq[kw];
           } else {
             v = -INFINITY;
           }
@@ -279,27 +325,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const float inv = 1.0f / l;
     const int tq = tq_sub[sub];
     if (tq >= 0) {
-      float* op = a.out + ((long)b * T + tq) * a.ldo + head * HD + 4 * G;
+      const long oo = ((long)b * T + tq) * a.ldo + head * HD + 4 * G;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const float4 v = make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv);
-        *reinterpret_cast<float4*>(op + 16 * d) = v;
+        if constexpr (PL) {
+          uint2 hh, ll;
+          split4(v, hh, ll);
+          *reinterpret_cast<uint2*>(a.ohi + oo + 16 * d) = hh;
+          *reinterpret_cast<uint2*>(a.olo + oo + 16 * d) = ll;
+        } else {
+          *reinterpret_cast<float4*>(a.out + oo + 16 * d) = v;
+        }
       }
     }
   }
 }
 
-extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo,
-                              int B, int H, int W, int heads, int head_dim, int window_size, float scale,
-                              hipStream_t stream) {
-  MMSA_CHECK_ARG(qkv && qkv_bias && rp && out, "attention: null pointer");
+static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head_dim, int window_size, float scale,
+                            bool planes, hipStream_t stream) {
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0 && window_size >= 0, "attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "attention: head_dim %d not supported (32 or 64)", head_dim);
   const int D = heads * head_dim;
-  MMSA_CHECK_ARG(ldq >= 3L * D && (ldq & 3) == 0 && ldo >= D && (ldo & 3) == 0, "attention: bad leading dimensions");
-  MMSA_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)qkv_bias)) & 15) == 0, "attention: pointers must be 16-byte aligned");
-  AttnArgs a;
-  a.qkv = qkv; a.ldq = ldq; a.qkv_bias = qkv_bias; a.rp = rp; a.out = out; a.ldo = ldo;
+  MMSA_CHECK_ARG(a.ldq >= 3L * D && (a.ldq & 7) == 0 && a.ldo >= D && (a.ldo & 3) == 0, "attention: bad leading dimensions");
   a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
   int ngroups;
   if (window_size > 0) {
@@ -327,15 +375,39 @@ extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias,
   const size_t smem = 2 * (head_dim / 8) * 64 * 16 + 2 * 64 * VSTR + (size_t)128 * (a.KHs + a.KWs) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 160 * 1024, "attention: bias tables do not fit LDS (KH=%d KW=%d)", a.KH, a.KW);
   dim3 grid(ngroups * cdiv(a.Nk, 128), heads, B);
-  if (head_dim == 64) {
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), smem, stream, a);
-  } else {
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(attn_kernel<32>, grid, dim3(256), smem, stream, a);
-  }
+#define ATTN_LAUNCH(HD_, PL_)                                                                                              \
+  do {                                                                                                                     \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, PL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((attn_kernel<HD_, PL_>), grid, dim3(256), smem, stream, a);                                         \
+  } while (0)
+  if (head_dim == 64) { if (planes) ATTN_LAUNCH(64, true); else ATTN_LAUNCH(64, false); }
+  else { if (planes) ATTN_LAUNCH(32, true); else ATTN_LAUNCH(32, false); }
+#undef ATTN_LAUNCH
   MMSA_CHECK_LAUNCH("attention");
   return MMSA_OK;
+}
+
+extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo,
+                              int B, int H, int W, int heads, int head_dim, int window_size, float scale,
+                              hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv && qkv_bias && rp && out, "attention: null pointer");
+  MMSA_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)qkv_bias)) & 15) == 0, "attention: pointers must be 16-byte aligned");
+  AttnArgs a = {};
+  a.qkv = qkv; a.ldq = ldq; a.qkv_bias = qkv_bias; a.rp = rp; a.out = out; a.ldo = ldo;
+  return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, false, stream);
+}
+
+// planes form: qkv, qkv_bias and the output are bf16 hi/lo planes (same layouts, strides in elements)
+extern "C" int mmsa_attention_planes(const unsigned short* qkv_hi, const unsigned short* qkv_lo, long ldq,
+                                     const unsigned short* bias_hi, const unsigned short* bias_lo, const float* rp,
+                                     unsigned short* out_hi, unsigned short* out_lo, long ldo, int B, int H, int W,
+                                     int heads, int head_dim, int window_size, float scale, hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv_hi && qkv_lo && bias_hi && bias_lo && rp && out_hi && out_lo, "attention_planes: null pointer");
+  MMSA_CHECK_ARG(((((uintptr_t)qkv_hi) | ((uintptr_t)qkv_lo) | ((uintptr_t)bias_hi) | ((uintptr_t)bias_lo)) & 15) == 0 &&
+                 ((((uintptr_t)out_hi) | ((uintptr_t)out_lo)) & 7) == 0, "attention_planes: alignment");
+  AttnArgs a = {};
+  a.qhi = qkv_hi; a.qlo = qkv_lo; a.ldq = ldq; a.bhi = bias_hi; a.blo = bias_lo; a.rp = rp; a.ohi = out_hi; a.olo = out_lo; a.ldo = ldo;
+  return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, true, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,8 +417,9 @@ extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias,
 // with (qh,qw) = token coords in its window (windowed blocks) or in the image (global blocks).
 // Rh/Rw are the gathered tables get_rel_pos(q,k,rel_pos)[q,k,:] (IE:554-584), built once at pack time.
 // Block = one image row (H-term) or one image column (W-term) of tokens x one head.
-template <int HD>
-__global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ qkv, long ldq, const float* __restrict__ Rh,
+template <int HD, bool PL>
+__global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ qkv, const unsigned short* __restrict__ qhi,
+                                                     const unsigned short* __restrict__ qlo, long ldq, const float* __restrict__ Rh,
                                                      const float* __restrict__ Rw, float* __restrict__ rp,
                                                      int H, int W, int heads, int ws, int KH, int KW) {
   constexpr int RS = HD + 4;
@@ -373,8 +446,19 @@ __global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ q
     for (int i = threadIdx.x; i < nt * (HD / 4); i += 256) {
       const int t = i / (HD / 4), c = (i % (HD / 4)) * 4;
       const int tok = isH ? line * W + (t0 + t) : (t0 + t) * W + line;
-      *reinterpret_cast<float4*>(sQ + t * RS + c) =
-          *reinterpret_cast<const float4*>(qkv + ((long)b * T + tok) * ldq + head * HD + c);
+      const long qo = ((long)b * T + tok) * ldq + head * HD + c;
+      if constexpr (PL) {  // q = hi + lo (what the attention MFMAs see)
+        const uint2 h = *reinterpret_cast<const uint2*>(qhi + qo);
+        const uint2 l = *reinterpret_cast<const uint2*>(qlo + qo);
+        float4 v;
+        v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+        v.y = __uint_as_float(h.x & 0xFFFF0000u) + __uint_as_float(l.x & 0xFFFF0000u);
+        v.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+        v.w = __uint_as_float(h.y & 0xFFFF0000u) + __uint_as_float(l.y & 0xFFFF0000u);
+        *reinterpret_cast<float4*>(sQ + t * RS + c) = v;
+      } else {
+        *reinterpret_cast<float4*>(sQ + t * RS + c) = *reinterpret_cast<const float4*>(qkv + qo);
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nt * KK; i += 256) {
@@ -394,20 +478,34 @@ __global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ q
   }
 }
 
-extern "C" int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp,
-                                int B, int H, int W, int heads, int head_dim, int window_size, hipStream_t stream) {
-  MMSA_CHECK_ARG(qkv && Rh && Rw && rp, "relpos_bias: null pointer");
+static int relpos_launch(const float* qkv, const unsigned short* qhi, const unsigned short* qlo, long ldq, const float* Rh,
+                         const float* Rw, float* rp, int B, int H, int W, int heads, int head_dim, int window_size,
+                         hipStream_t stream) {
+  MMSA_CHECK_ARG((qkv || (qhi && qlo)) && Rh && Rw && rp, "relpos_bias: null pointer");
   MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "relpos_bias: head_dim %d not supported", head_dim);
-  MMSA_CHECK_ARG((ldq & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)Rh) | ((uintptr_t)Rw)) & 15) == 0, "relpos_bias: alignment");
+  MMSA_CHECK_ARG((ldq & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)Rh) | ((uintptr_t)Rw)) & 15) == 0 &&
+                 ((((uintptr_t)qhi) | ((uintptr_t)qlo)) & 7) == 0, "relpos_bias: alignment");
   const int KH = window_size ? window_size : H, KW = window_size ? window_size : W;
   const int KKmax = KH > KW ? KH : KW;
   const size_t smem = (size_t)(KKmax + 64) * (head_dim + 4) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 64 * 1024, "relpos_bias: table slice does not fit LDS (K=%d)", KKmax);
   dim3 grid(H + W, heads, B);
-  if (head_dim == 64)
-    hipLaunchKernelGGL(relpos_kernel<64>, grid, dim3(256), smem, stream, qkv, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW);
-  else
-    hipLaunchKernelGGL(relpos_kernel<32>, grid, dim3(256), smem, stream, qkv, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW);
+#define RP_LAUNCH(HD_, PL_) hipLaunchKernelGGL((relpos_kernel<HD_, PL_>), grid, dim3(256), smem, stream, qkv, qhi, qlo, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW)
+  if (head_dim == 64) { if (qhi) RP_LAUNCH(64, true); else RP_LAUNCH(64, false); }
+  else { if (qhi) RP_LAUNCH(32, true); else RP_LAUNCH(32, false); }
+#undef RP_LAUNCH
   MMSA_CHECK_LAUNCH("relpos_bias");
   return MMSA_OK;
+}
+
+extern "C" int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp,
+                                int B, int H, int W, int heads, int head_dim, int window_size, hipStream_t stream) {
+  return relpos_launch(qkv, nullptr, nullptr, ldq, Rh, Rw, rp, B, H, W, heads, head_dim, window_size, stream);
+}
+
+extern "C" int mmsa_relpos_bias_planes(const unsigned short* qkv_hi, const unsigned short* qkv_lo, long ldq, const float* Rh,
+                                       const float* Rw, float* rp, int B, int H, int W, int heads, int head_dim,
+                                       int window_size, hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv_hi && qkv_lo, "relpos_bias_planes: null pointer");
+  return relpos_launch(nullptr, qkv_hi, qkv_lo, ldq, Rh, Rw, rp, B, H, W, heads, head_dim, window_size, stream);
 }

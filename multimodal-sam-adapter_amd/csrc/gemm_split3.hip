@@ -1,4 +1,5 @@
-// split3 GEMM for gfx950:  C[M,N] = epilogue( A[M,K] (fp32) x W[N,K]^T (bf16 hi/lo planes) )
+// split3 GEMM for gfx950:  C[M,N] = epilogue( A[M,K] x W[N,K]^T ),  W as bf16 hi/lo planes,
+// A either fp32 (split to hi/lo while staged) or already bf16 hi/lo planes written by the producing kernel.
 //
 // Every Linear / 1x1-conv / patchify-conv / conv-transpose of the encoder path goes through this
 // kernel (reference call sites: IE:488,499,162-167 qkv/proj/MLP; TC:107-111 pointwise convs;
@@ -10,19 +11,24 @@
 // Tiling: 128x128 block tile, BK = 32 (= one v_mfma_f32_16x16x32_bf16 k-step), 4 waves (2x2), each
 // wave 64x64 = 4x4 MFMA tiles x 3 products.  The MFMA "A" operand is the WEIGHT tile and the "B"
 // operand the ACTIVATION tile, so a lane's 4 accumulator registers are 4 consecutive output columns
-// -> 16-byte epilogue loads/stores.  Activations are split to hi/lo while being staged to LDS;
-// weights are pre-split at pack time.  LDS image per plane: [k-chunk g=0..3][row 0..127][8 bf16], which
+// -> 16-byte epilogue loads/stores.  LDS image per plane: [k-chunk g=0..3][row 0..127][8 bf16], which
 // makes every ds_read_b128 fragment read bank-conflict free (16 lanes x 16 B = one 256-B bank row).
 // Two LDS stages + register prefetch: one barrier per k-tile.
+//
+// Activation planes (A_PLANES): an hi/lo bf16 pair costs the same 4 bytes per element as fp32 but is split ONCE
+// by the producer (LayerNorm, GELU epilogue, attention, MSDA, depthwise conv) instead of once per column block
+// of every consumer GEMM, and is staged with plain 16-byte copies (no VALU work in the main loop).
+// The epilogue can emit fp32, planes, or both.
 #include "common.h"
 
 struct GemmArgs {
-  const float* A; long lda; long strideA;
+  const float* A; const unsigned short* Ahi; const unsigned short* Alo; long lda; long strideA;
   const unsigned short* Whi; const unsigned short* Wlo; long strideW;
   const float* bias; long strideBias;
   const float* colscale;
   const float* resid; long ldr; long strideR; int resid_mod; float beta;
   float* C; long ldc; long strideC;
+  unsigned short* Chi; unsigned short* Clo; long ldcp; long strideCp;
   int M, N, K;
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;   // out_mode 1: 2x2 pixel-shuffle store (conv-transpose 2x2 s2)
@@ -34,6 +40,7 @@ struct GemmArgs {
 #define PLANE_BYTES (4 * 128 * 16)     // 8 KiB per bf16 plane per stage
 #define STAGE_BYTES (4 * PLANE_BYTES)  // Ahi, Alo, Whi, Wlo
 
+template <bool AP>
 __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -44,46 +51,61 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   const int n0 = blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
   const int bz = blockIdx.z;
-
-  const float* A = a.A + (long)bz * a.strideA;
-  const unsigned short* Whi = a.Whi + (long)bz * a.strideW;
-  const unsigned short* Wlo = a.Wlo + (long)bz * a.strideW;
   const int K = a.K;
 
   // ---- global load assignment
-  // activations: 4 x float4 per thread: row = (tid>>3) + 32*i, float col = (tid&7)*4
-  const int a_c4 = (tid & 7) * 4;
-  auto a_row_ptr = [&](int i) {
-    int r = m0 + (tid >> 3) + 32 * i;
-    r = r < a.M ? r : a.M - 1;
-    return A + (long)r * a.lda + a_c4;
-  };
-  const float* a_ptr0 = a_row_ptr(0);
-  const float* a_ptr1 = a_row_ptr(1);
-  const float* a_ptr2 = a_row_ptr(2);
-  const float* a_ptr3 = a_row_ptr(3);
-  const int a_lds_off = ((tid & 7) >> 1) * 2048 + (tid >> 3) * 16 + (tid & 1) * 8;  // + 32*16*i
-  // weights: 2 x uint4 per plane per thread: row = (tid>>2) + 64*i, chunk = tid&3
-  auto w_row_off = [&](int i) {
-    int r = n0 + (tid >> 2) + 64 * i;
-    r = r < a.N ? r : a.N - 1;
-    return (long)r * K + (tid & 3) * 8;
-  };
-  const unsigned short* w_hi_ptr0 = Whi + w_row_off(0);
-  const unsigned short* w_hi_ptr1 = Whi + w_row_off(1);
-  const unsigned short* w_lo_ptr0 = Wlo + w_row_off(0);
-  const unsigned short* w_lo_ptr1 = Wlo + w_row_off(1);
-  const int w_lds_off = (tid & 3) * 2048 + (tid >> 2) * 16;  // + 64*16*i
+  // fp32 activations: 4 x float4 per thread: row = (tid>>3) + 32*i, float col = (tid&7)*4
+  // plane operands (weights always, activations when AP): 2 x uint4 per plane per thread:
+  //   row = (tid>>2) + 64*i, k-chunk = tid&3
+  const float* a_ptr0 = nullptr; const float* a_ptr1 = nullptr; const float* a_ptr2 = nullptr; const float* a_ptr3 = nullptr;
+  const unsigned short* ah_ptr0 = nullptr; const unsigned short* ah_ptr1 = nullptr;
+  const unsigned short* al_ptr0 = nullptr; const unsigned short* al_ptr1 = nullptr;
+  if constexpr (AP) {
+    const unsigned short* Ahi = a.Ahi + (long)bz * a.strideA;
+    const unsigned short* Alo = a.Alo + (long)bz * a.strideA;
+    int r0 = m0 + (tid >> 2), r1 = r0 + 64;
+    r0 = r0 < a.M ? r0 : a.M - 1;
+    r1 = r1 < a.M ? r1 : a.M - 1;
+    ah_ptr0 = Ahi + (long)r0 * a.lda + (tid & 3) * 8; ah_ptr1 = Ahi + (long)r1 * a.lda + (tid & 3) * 8;
+    al_ptr0 = Alo + (long)r0 * a.lda + (tid & 3) * 8; al_ptr1 = Alo + (long)r1 * a.lda + (tid & 3) * 8;
+  } else {
+    const float* A = a.A + (long)bz * a.strideA;
+    const int a_c4 = (tid & 7) * 4;
+    int r0 = m0 + (tid >> 3), r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
+    r0 = r0 < a.M ? r0 : a.M - 1; r1 = r1 < a.M ? r1 : a.M - 1;
+    r2 = r2 < a.M ? r2 : a.M - 1; r3 = r3 < a.M ? r3 : a.M - 1;
+    a_ptr0 = A + (long)r0 * a.lda + a_c4; a_ptr1 = A + (long)r1 * a.lda + a_c4;
+    a_ptr2 = A + (long)r2 * a.lda + a_c4; a_ptr3 = A + (long)r3 * a.lda + a_c4;
+  }
+  const int a_lds_off = ((tid & 7) >> 1) * 2048 + (tid >> 3) * 16 + (tid & 1) * 8;  // fp32 path, + 512*i
+  const unsigned short* Whi = a.Whi + (long)bz * a.strideW;
+  const unsigned short* Wlo = a.Wlo + (long)bz * a.strideW;
+  int wr0 = n0 + (tid >> 2), wr1 = wr0 + 64;
+  wr0 = wr0 < a.N ? wr0 : a.N - 1;
+  wr1 = wr1 < a.N ? wr1 : a.N - 1;
+  const unsigned short* w_hi_ptr0 = Whi + (long)wr0 * K + (tid & 3) * 8;
+  const unsigned short* w_hi_ptr1 = Whi + (long)wr1 * K + (tid & 3) * 8;
+  const unsigned short* w_lo_ptr0 = Wlo + (long)wr0 * K + (tid & 3) * 8;
+  const unsigned short* w_lo_ptr1 = Wlo + (long)wr1 * K + (tid & 3) * 8;
+  const int p_lds_off = (tid & 3) * 2048 + (tid >> 2) * 16;  // plane operands, + 1024*i
 
-  float4 ra0, ra1, ra2, ra3;
-  uint4 rwh0, rwh1, rwl0, rwl1;
+  float4 ra0, ra1, ra2, ra3;            // fp32 activations in flight
+  uint4 rah0, rah1, ral0, ral1;         // plane activations in flight
+  uint4 rwh0, rwh1, rwl0, rwl1;         // weights in flight
 
 #define LOAD_GLOBAL(k0)                                                   \
   do {                                                                    \
-    ra0 = *reinterpret_cast<const float4*>(a_ptr0 + (k0));                \
-    ra1 = *reinterpret_cast<const float4*>(a_ptr1 + (k0));                \
-    ra2 = *reinterpret_cast<const float4*>(a_ptr2 + (k0));                \
-    ra3 = *reinterpret_cast<const float4*>(a_ptr3 + (k0));                \
+    if constexpr (AP) {                                                   \
+      rah0 = *reinterpret_cast<const uint4*>(ah_ptr0 + (k0));             \
+      rah1 = *reinterpret_cast<const uint4*>(ah_ptr1 + (k0));             \
+      ral0 = *reinterpret_cast<const uint4*>(al_ptr0 + (k0));             \
+      ral1 = *reinterpret_cast<const uint4*>(al_ptr1 + (k0));             \
+    } else {                                                              \
+      ra0 = *reinterpret_cast<const float4*>(a_ptr0 + (k0));              \
+      ra1 = *reinterpret_cast<const float4*>(a_ptr1 + (k0));              \
+      ra2 = *reinterpret_cast<const float4*>(a_ptr2 + (k0));              \
+      ra3 = *reinterpret_cast<const float4*>(a_ptr3 + (k0));              \
+    }                                                                     \
     rwh0 = *reinterpret_cast<const uint4*>(w_hi_ptr0 + (k0));             \
     rwh1 = *reinterpret_cast<const uint4*>(w_hi_ptr1 + (k0));             \
     rwl0 = *reinterpret_cast<const uint4*>(w_lo_ptr0 + (k0));             \
@@ -101,11 +123,18 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
 #define STORE_LDS(stage_)                                                              \
   do {                                                                                 \
     unsigned char* sb_ = smem + (stage_) * STAGE_BYTES;                                \
-    STORE_A(sb_, ra0, 0); STORE_A(sb_, ra1, 1); STORE_A(sb_, ra2, 2); STORE_A(sb_, ra3, 3); \
-    *reinterpret_cast<uint4*>(sb_ + 2 * PLANE_BYTES + w_lds_off) = rwh0;               \
-    *reinterpret_cast<uint4*>(sb_ + 2 * PLANE_BYTES + w_lds_off + 1024) = rwh1;        \
-    *reinterpret_cast<uint4*>(sb_ + 3 * PLANE_BYTES + w_lds_off) = rwl0;               \
-    *reinterpret_cast<uint4*>(sb_ + 3 * PLANE_BYTES + w_lds_off + 1024) = rwl1;        \
+    if constexpr (AP) {                                                                \
+      *reinterpret_cast<uint4*>(sb_ + 0 * PLANE_BYTES + p_lds_off) = rah0;             \
+      *reinterpret_cast<uint4*>(sb_ + 0 * PLANE_BYTES + p_lds_off + 1024) = rah1;      \
+      *reinterpret_cast<uint4*>(sb_ + 1 * PLANE_BYTES + p_lds_off) = ral0;             \
+      *reinterpret_cast<uint4*>(sb_ + 1 * PLANE_BYTES + p_lds_off + 1024) = ral1;      \
+    } else {                                                                           \
+      STORE_A(sb_, ra0, 0); STORE_A(sb_, ra1, 1); STORE_A(sb_, ra2, 2); STORE_A(sb_, ra3, 3); \
+    }                                                                                  \
+    *reinterpret_cast<uint4*>(sb_ + 2 * PLANE_BYTES + p_lds_off) = rwh0;               \
+    *reinterpret_cast<uint4*>(sb_ + 2 * PLANE_BYTES + p_lds_off + 1024) = rwh1;        \
+    *reinterpret_cast<uint4*>(sb_ + 3 * PLANE_BYTES + p_lds_off) = rwl0;               \
+    *reinterpret_cast<uint4*>(sb_ + 3 * PLANE_BYTES + p_lds_off + 1024) = rwl1;        \
   } while (0)
 
   f32x4 acc[4][4];  // [ni][mi]
@@ -148,8 +177,10 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. +3]
   const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
   const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
-  float* C = a.C + (long)bz * a.strideC;
-  const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0);
+  float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
+  unsigned short* Chi = a.Chi ? a.Chi + (long)bz * a.strideCp : nullptr;
+  unsigned short* Clo = a.Clo ? a.Clo + (long)bz * a.strideCp : nullptr;
+  const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + l15;
@@ -188,14 +219,26 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
           const float4 rr = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
           o.x += a.beta * rr.x; o.y += a.beta * rr.y; o.z += a.beta * rr.z; o.w += a.beta * rr.w;
         }
-        *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
+        if (C) *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
+        if (Chi) {
+          uint2 hh, ll;
+          split4(o, hh, ll);
+          *reinterpret_cast<uint2*>(Chi + drow * a.ldcp + dcol) = hh;
+          *reinterpret_cast<uint2*>(Clo + drow * a.ldcp + dcol) = ll;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r < a.N) {
             float x = v[r];
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol + r];
-            C[drow * a.ldc + dcol + r] = x;
+            if (C) C[drow * a.ldc + dcol + r] = x;
+            if (Chi) {
+              unsigned short hh, ll;
+              split_bf16(x, hh, ll);
+              Chi[drow * a.ldcp + dcol + r] = hh;
+              Clo[drow * a.ldcp + dcol + r] = ll;
+            }
           }
         }
       }
@@ -204,44 +247,58 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
 }
 
 // C-ABI entry: see include/mmsa.h for the contract.
-extern "C" int mmsa_gemm_split3(const float* A, long lda, long strideA,
+extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ahi, const unsigned short* Alo, long lda, long strideA,
                                 const unsigned short* Whi, const unsigned short* Wlo, long strideW,
                                 const float* bias, long strideBias, const float* colscale,
                                 const float* resid, long ldr, long strideR, int resid_mod, float beta,
                                 float* C, long ldc, long strideC,
+                                unsigned short* Chi, unsigned short* Clo, long ldcp, long strideCp,
                                 int M, int N, int K, int batch, int act, float alpha,
                                 int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream) {
-  MMSA_CHECK_ARG(A && Whi && Wlo && C, "gemm_split3: null pointer");
+  const bool ap = Ahi != nullptr;
+  MMSA_CHECK_ARG((A || (Ahi && Alo)) && Whi && Wlo && (C || (Chi && Clo)), "gemm_split3: null pointer");
+  MMSA_CHECK_ARG(!(A && Ahi), "gemm_split3: pass either fp32 A or A planes, not both");
+  MMSA_CHECK_ARG((Chi == nullptr) == (Clo == nullptr), "gemm_split3: output planes come in pairs");
   MMSA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_split3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   MMSA_CHECK_ARG(K % BK == 0, "gemm_split3: K=%d must be a multiple of %d (producers pad)", K, BK);
-  MMSA_CHECK_ARG((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "gemm_split3: A must be 16-byte aligned with lda%%4==0 (lda=%ld)", lda);
+  if (ap) {
+    MMSA_CHECK_ARG((lda & 7) == 0 && (strideA & 7) == 0 && ((((uintptr_t)Ahi) | ((uintptr_t)Alo)) & 15) == 0,
+                   "gemm_split3: A planes must be 16-byte aligned with lda%%8==0 (lda=%ld)", lda);
+  } else {
+    MMSA_CHECK_ARG((lda & 3) == 0 && (strideA & 3) == 0 && (((uintptr_t)A) & 15) == 0, "gemm_split3: A must be 16-byte aligned with lda%%4==0 (lda=%ld)", lda);
+  }
   MMSA_CHECK_ARG(lda >= K, "gemm_split3: lda=%ld < K=%d", lda, K);
-  MMSA_CHECK_ARG((((uintptr_t)Whi) & 15) == 0 && (((uintptr_t)Wlo) & 15) == 0, "gemm_split3: weight planes must be 16-byte aligned");
-  MMSA_CHECK_ARG((((uintptr_t)C) & 15) == 0 && (!resid || (((uintptr_t)resid) & 15) == 0), "gemm_split3: C/resid must be 16-byte aligned");
+  MMSA_CHECK_ARG((((uintptr_t)Whi) & 15) == 0 && (((uintptr_t)Wlo) & 15) == 0 && (strideW & 7) == 0, "gemm_split3: weight planes must be 16-byte aligned");
+  MMSA_CHECK_ARG((!C || (((uintptr_t)C) & 15) == 0) && (!resid || (((uintptr_t)resid) & 15) == 0), "gemm_split3: C/resid must be 16-byte aligned");
+  MMSA_CHECK_ARG(!Chi || ((((uintptr_t)Chi) | ((uintptr_t)Clo)) & 7) == 0, "gemm_split3: output planes must be 8-byte aligned");
   MMSA_CHECK_ARG(act >= ACT_NONE && act <= ACT_SIGMOID, "gemm_split3: bad act %d", act);
   if (out_mode == 1) {
     MMSA_CHECK_ARG(ps_H > 0 && ps_W > 0 && ps_C > 0 && N == 4 * ps_C && M % (ps_H * ps_W) == 0 && (ps_C & 3) == 0,
                    "gemm_split3: pixel-shuffle store needs N==4*C, M%%(H*W)==0");
-    MMSA_CHECK_ARG(ldc >= ps_C, "gemm_split3: ldc < C");
+    MMSA_CHECK_ARG((!C || ldc >= ps_C) && (!Chi || ldcp >= ps_C), "gemm_split3: ldc < C");
   } else {
     MMSA_CHECK_ARG(out_mode == 0, "gemm_split3: bad out_mode %d", out_mode);
-    MMSA_CHECK_ARG(ldc >= N, "gemm_split3: ldc=%ld < N=%d", ldc, N);
+    MMSA_CHECK_ARG((!C || ldc >= N) && (!Chi || ldcp >= N), "gemm_split3: ldc=%ld < N=%d", ldc, N);
   }
   GemmArgs a;
-  a.A = A; a.lda = lda; a.strideA = strideA;
+  a.A = A; a.Ahi = Ahi; a.Alo = Alo; a.lda = lda; a.strideA = strideA;
   a.Whi = Whi; a.Wlo = Wlo; a.strideW = strideW;
   a.bias = bias; a.strideBias = strideBias; a.colscale = colscale;
   a.resid = resid; a.ldr = ldr; a.strideR = strideR; a.resid_mod = resid_mod; a.beta = beta;
-  a.C = C; a.ldc = ldc; a.strideC = strideC;
+  a.C = C; a.ldc = C ? ldc : 0; a.strideC = strideC;
+  a.Chi = Chi; a.Clo = Clo; a.ldcp = Chi ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
-  hipLaunchKernelGGL(gemm_split3_kernel, grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  if (ap)
+    hipLaunchKernelGGL(gemm_split3_kernel<true>, grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  else
+    hipLaunchKernelGGL(gemm_split3_kernel<false>, grid, dim3(256), 2 * STAGE_BYTES, stream, a);
   MMSA_CHECK_LAUNCH("gemm_split3");
   return MMSA_OK;
 }
 
-// ---- weight pre-pack: fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad] (zero padded)
+// ---- pre-pack: fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad] (zero padded)
 __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
   const long total = (long)rows * cols_pad;

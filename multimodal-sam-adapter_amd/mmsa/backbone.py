@@ -36,6 +36,10 @@ class Workspace:
             self.bufs[name] = b
         return b[:n].view(rows, cols)
 
+    def planes(self, name, rows, cols, zero=False):
+        """bf16 hi/lo activation planes [rows, cols] (int16 storage)."""
+        return ops.Planes(self.get(name + ".hi", rows, cols, torch.int16, zero), self.get(name + ".lo", rows, cols, torch.int16, zero))
+
     def nbytes(self):
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
 
@@ -135,6 +139,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             pk["blocks"].append(dict(
                 n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
                 qkv=planes(sd[b + "attn.qkv.weight"]), qkv_b=sd[b + "attn.qkv.bias"].contiguous(),
+                qkv_bp=ops.split_planes(sd[b + "attn.qkv.bias"].reshape(1, -1).contiguous(), kpad=3 * D),  # k = v of pad tokens
                 proj=planes(sd[b + "attn.proj.weight"]), proj_b=sd[b + "attn.proj.bias"],
                 lin1=planes(sd[b + "mlp.lin1.weight"]), lin1_b=sd[b + "mlp.lin1.bias"],
                 lin2=planes(sd[b + "mlp.lin2.weight"]), lin2_b=sd[b + "mlp.lin2.bias"],
@@ -339,7 +344,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
 
         # ---- tail (BK:316-337)
         outs = []
-        ops.gemm(cbuf, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=Nc * D,
+        c2p = ws.planes("up_a", B * n2, D)
+        for bi in range(B):
+            ops.split_planes(cbuf[bi * Nc:bi * Nc + n2], kpad=D, out=c2p[bi * n2:(bi + 1) * n2])
+        ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=n2 * D,
                  stride_r=(H // 4) * (W // 4) * D, stride_c=(H // 4) * (W // 4) * D, pixel_shuffle=(H // 8, W // 8, D))
         f1 = torch.empty(B, D, H // 4, W // 4, device=dev)
         ops.tail_fuse(c1, (H // 4) * (W // 4) * D, xs[1], *pk["bn"][0], f1, B, H // 4, W // 4, Hp, Wp)
@@ -358,20 +366,22 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         D, heads = cfg["embed_dim"], cfg["num_heads"]
         hd = D // heads
         T = Hp * Wp
-        n = ws.get("blk_n", B * T, D)
-        ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, n)
-        qkv = ws.get("blk_qkv", B * T, 3 * D)
-        ops.gemm(n, bp["qkv"], qkv, bias=bp["qkv_b"])
+        # intermediate activations travel as bf16 hi/lo planes: split once by the producer, consumed by the
+        # GEMM / attention kernels with plain 16-byte copies (same bytes as fp32, no re-splitting per column block)
+        n = ws.planes("blk_n", B * T, D)
+        ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
+        qkv = ws.planes("blk_qkv", B * T, 3 * D)
+        ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
         kk = 2 * wsz if wsz else Hp + Wp
         rp = ws.get("blk_rp", B * heads * T, kk)
         ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
-        ao = ws.get("blk_ao", B * T, D)
-        ops.attention(qkv, bp["qkv_b"], rp, ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+        ao = ws.planes("blk_ao", B * T, D)
+        ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
         ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
-        ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, n)
-        h = ws.get("blk_h", B * T, bp["lin1"].n)
-        ops.gemm(n, bp["lin1"], h, bias=bp["lin1_b"], act="gelu")
+        ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
+        h = ws.planes("blk_h", B * T, bp["lin1"].n)
+        ops.gemm(n, bp["lin1"], bias=bp["lin1_b"], act="gelu", out_planes=h)
         ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x)
 
     # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)
@@ -383,36 +393,36 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.gemm(fn, ap["val"], val, bias=ap["val_b"])
         raw = ws.get("msda_raw", B * Lq, ap["oa"].n)
         ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"])
-        samp = ws.get("msda_s", B * Lq, dv)
-        ops.msda_fused(val, ss, lsi, raw, ref, samp, B, S, M, dv // M, L, Lq, Pn)
+        samp = ws.planes("msda_s", B * Lq, dv)
+        ops.msda_fused(val, ss, lsi, raw, ref, None, B, S, M, dv // M, L, Lq, Pn, out_planes=samp)
         ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale)
 
     def _injector(self, ip, x_in, x_out, c, geo, B, T, Nc):  # AM:525-542
         ws, D = self._ws, self.cfg["embed_dim"]
-        qn = ws.get("inj_qn", B * T, D)
-        fn = ws.get("inj_fn", B * Nc, D)
-        ops.layernorm(x_in, ip["qnw"], ip["qnb"], 1e-6, qn)
-        ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, fn)
+        qn = ws.planes("inj_qn", B * T, D)
+        fn = ws.planes("inj_fn", B * Nc, D)
+        ops.layernorm(x_in, ip["qnw"], ip["qnb"], 1e-6, out_planes=qn)
+        ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
         self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"])
 
     def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
         ws, D = self._ws, self.cfg["embed_dim"]
-        qn = ws.get("inj_fn", B * Nc, D)
-        fn = ws.get("inj_qn", B * T, D)
-        ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, qn)
-        ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, fn)
+        qn = ws.planes("inj_fn", B * Nc, D)
+        fn = ws.planes("inj_qn", B * T, D)
+        ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
+        ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, out_planes=fn)
         self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
-        ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, qn)
+        ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, out_planes=qn)
         hid = ep["fc1"].n
         hp = ep["fc2"].kpad  # K of fc2 padded to a multiple of 32; pad columns stay zero
         h1 = ws.get("ffn_h1", B * Nc, hid)
-        h2f = ws.get(f"ffn_h2_{hp}", B * Nc, hp, zero=True)
+        h2f = ws.planes(f"ffn_h2_{hp}", B * Nc, hp, zero=True)
         h2 = h2f[:, :hid]
         ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
         off = 0
         for (hh, wwd) in ((H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)):  # AM:462-470 token split 16n/4n/n
-            ops.dwconv(h1[off:], ep["dw"], ep["dw_b"], h2[off:], B, hh, wwd, 3, act="gelu",
-                       xstride_b=Nc * hid, ystride_b=Nc * hp)
+            ops.dwconv(h1[off:], ep["dw"], ep["dw_b"], None, B, hh, wwd, 3, act="gelu",
+                       xstride_b=Nc * hid, ystride_b=Nc * hp, out_planes=h2[off:])
             off += hh * wwd
         ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
 
@@ -439,17 +449,17 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 c = chans[i]
                 if i >= 1:
                     ds = st["ds"][i - 1]
-                    pa = ws.get("cn_patch", P, 4 * chans[i - 1])
-                    ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]))
+                    pa = ws.planes("cn_patch", P, 4 * chans[i - 1])
+                    ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, out_planes=pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]))
                     cur = ws.get(f"cn_cur{i}", P, c)
                     ops.gemm(pa, ds["w"], cur, bias=ds["b"])
                 d = ws.get("cn_tmp", P, c)
-                n = ws.get("cn_n", P, c)
-                hbuf = ws.get("cn_h", P, 4 * c)
+                n = ws.planes("cn_n", P, c)
+                hbuf = ws.planes("cn_h", P, 4 * c)
                 for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
                     ops.dwconv(cur, blk["dw"], blk["dw_b"], d, B, hh, wwd, 7)
-                    ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, n)
-                    ops.gemm(n, blk["pw1"], hbuf, bias=blk["pw1_b"], act="gelu")
+                    ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n)
+                    ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf)
                     ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur)
                 nw, nb = st["out_norm"][i]
                 ops.layernorm(cur, nw, nb, 1e-6, tcat[i][:, si * c:(si + 1) * c])

@@ -1,0 +1,129 @@
+"""GPU parity of the activation-planes paths (bf16 hi/lo pairs written by producers, consumed by the GEMM and
+attention kernels) against fp32 torch / the oracle.  Same tolerance as the fp32-input paths."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_encoder as R
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mmsa
+    return mmsa.ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def planes_to_float(p):
+    hi = (p.hi.to(torch.int32) << 16).view(torch.float32)
+    lo = (p.lo.to(torch.int32) << 16).view(torch.float32)
+    return hi + lo
+
+
+def test_split_planes_roundtrip(ops):
+    x = torch.randn(37, 50, generator=g(1)) * 3
+    p = ops.split_planes(x.to(DEV))
+    assert p.hi.shape == (37, 64) and p.kpad == 64
+    back = planes_to_float(p).cpu()
+    assert torch.all(back[:, 50:] == 0)
+    assert ((back[:, :50] - x).abs() <= x.abs() * 2 ** -15).all()  # ~16 mantissa bits
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 96, 64), (1000, 576, 1024), (4096, 1024, 768), (77, 28, 96)])
+def test_gemm_planes_in_and_out(ops, M, N, K):
+    a = torch.randn(M, K, generator=g(2))
+    w = torch.randn(N, K, generator=g(3)) / K ** 0.5
+    b = torch.randn(N, generator=g(4))
+    res = torch.randn(M, N, generator=g(5))
+    ref = F.gelu(F.linear(a.double(), w.double(), b.double())).float() + res
+    ap = ops.split_planes(a.to(DEV), kpad=K)
+    pl = ops.split_planes(w.to(DEV))
+    out = torch.empty(M, N, device=DEV)
+    outp = ops.alloc_planes(M, N, DEV)
+    ops.gemm(ap, pl, out, bias=b.to(DEV), act="gelu", resid=res.to(DEV), out_planes=outp)
+    assert_close(out, ref, what="planes-in gemm fp32 out")
+    assert_close(planes_to_float(outp), ref, what="planes-in gemm planes out")
+    # planes-only output from an fp32 A
+    outp2 = ops.alloc_planes(M, N, DEV)
+    ops.gemm(a.to(DEV), pl, bias=b.to(DEV), act="gelu", resid=res.to(DEV), out_planes=outp2)
+    assert_close(planes_to_float(outp2), ref, what="fp32-in gemm planes out")
+
+
+def test_layernorm_planes_and_patchify(ops):
+    x = torch.randn(2 * 6 * 8, 64, generator=g(6)) * 2 + 0.3
+    w, b = torch.randn(64, generator=g(7)), torch.randn(64, generator=g(8))
+    y = F.layer_norm(x, (64,), w, b, 1e-6)
+    p = ops.alloc_planes(x.shape[0], 64, DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out_planes=p)
+    assert_close(planes_to_float(p), y, tol=5e-5, what="LN planes")
+    ref = y.view(2, 3, 2, 4, 2, 64).permute(0, 1, 3, 2, 4, 5).reshape(2 * 3 * 4, 256)
+    pp = ops.alloc_planes(24, 256, DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out_planes=pp, patchify=(6, 8))
+    assert_close(planes_to_float(pp), ref, tol=5e-5, what="LN patchify planes")
+
+
+@pytest.mark.parametrize("H,W,heads,hd,ws,table", [
+    (16, 16, 2, 32, 14, 27), (20, 20, 2, 64, 14, 27), (64, 64, 2, 64, 14, 27),
+    (14, 14, 2, 32, 0, 31), (20, 12, 3, 64, 0, 39), (64, 64, 2, 64, 0, 127)])
+def test_attention_planes(ops, H, W, heads, hd, ws, table):
+    import mmsa.backbone as bb
+    B, D = 2, heads * hd
+    att = R.Attention(D, heads, (table // 2 + 1, table // 2 + 1))
+    sd = R.seeded_state_dict(att, 7)
+    sd["rel_pos_h"] = torch.randn(table, hd, generator=g(50)) * 0.3
+    sd["rel_pos_w"] = torch.randn(table, hd, generator=g(51)) * 0.3
+    sd["qkv.bias"] = torch.randn(3 * D, generator=g(52)) * 0.5
+    att.load_state_dict(sd)
+    x = torch.randn(B, H, W, D, generator=g(53))
+    with torch.no_grad():
+        if ws:
+            xw, pad_hw = R.window_partition(x, ws)
+            ref = R.window_unpartition(att(xw), ws, pad_hw, (H, W))
+        else:
+            ref = att(x)
+    T = H * W
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV)
+    ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
+    if ws:
+        rh, rw = bb._rel_table(ws, sd["rel_pos_h"].to(DEV)), bb._rel_table(ws, sd["rel_pos_w"].to(DEV))
+        kk = 2 * ws
+    else:
+        rh, rw = bb._rel_table(H, sd["rel_pos_h"].to(DEV)), bb._rel_table(W, sd["rel_pos_w"].to(DEV))
+        kk = H + W
+    rp = torch.empty(B * heads * T, kk, device=DEV)
+    ops.relpos_bias(qkv, rh, rw, rp, B, H, W, heads, hd, ws)
+    ao = ops.alloc_planes(B * T, D, DEV)
+    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).to(DEV), kpad=3 * D)
+    ops.attention(qkv, biasp, rp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
+    out = torch.empty(B * T, D, device=DEV)
+    ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
+    assert_close(out.view(B, H, W, D), ref, what=f"attention planes {H}x{W} ws={ws}")
+
+
+def test_msda_and_dwconv_planes_outputs(ops):
+    B, M, D, L, Pn, Lq = 1, 4, 32, 1, 4, 100
+    S = 10 * 10
+    ss = torch.tensor([(10, 10)], dtype=torch.long).to(DEV)
+    lsi = torch.zeros(1, dtype=torch.long, device=DEV)
+    val = torch.randn(B * S, M * D, generator=g(60)).to(DEV)
+    raw = torch.randn(B * Lq, M * L * Pn * 3, generator=g(61)).to(DEV)
+    ref_pts = torch.rand(Lq, 2, generator=g(62)).to(DEV)
+    o32 = torch.empty(B * Lq, M * D, device=DEV)
+    op = ops.alloc_planes(B * Lq, M * D, DEV)
+    ops.msda_fused(val, ss, lsi, raw, ref_pts, o32, B, S, M, D, L, Lq, Pn, out_planes=op)
+    assert_close(planes_to_float(op), o32.cpu(), tol=5e-5, what="msda planes")
+    C, H, W = 32, 9, 7
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, groups=C)
+    x = torch.randn(2, C, H, W, generator=g(63))
+    ref = F.gelu(conv(x)).detach().permute(0, 2, 3, 1).reshape(-1, C)
+    p = ops.alloc_planes(2 * H * W, C, DEV)
+    ops.dwconv(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), conv.weight.detach().reshape(C, 9).t().contiguous().to(DEV),
+               conv.bias.detach().to(DEV), None, 2, H, W, 3, act="gelu", out_planes=p)
+    assert_close(planes_to_float(p), ref, tol=5e-5, what="dwconv planes")
