@@ -40,7 +40,9 @@ struct GemmArgs {
 #define PLANE_BYTES (4 * 128 * 16)     // 8 KiB per bf16 plane per stage
 #define STAGE_BYTES (4 * PLANE_BYTES)  // Ahi, Alo, Whi, Wlo
 
-template <bool AP>
+// GEN = true compiles in the rarely used index arithmetic (pixel-shuffle store, broadcast residual): integer
+// divisions per output element that the common epilogue must not pay for.
+template <bool AP, bool GEN>
 __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -56,38 +58,44 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   // ---- global load assignment
   // fp32 activations: 4 x float4 per thread: row = (tid>>3) + 32*i, float col = (tid&7)*4
   // plane operands (weights always, activations when AP): 2 x uint4 per plane per thread:
-  //   row = (tid>>2) + 64*i, k-chunk = tid&3
+  //   row = (tid&7) + 8*(tid>>5) + 64*i, k-chunk = (tid>>3)&3 -- each 8-lane ds_write_b128 group then writes
+  //   128 contiguous LDS bytes (8 rows of one chunk): conflict free.  (row = tid>>2, chunk = tid&3 would put
+  //   4 lanes of every group on the same banks: chunk stride 2048 B = 0 mod 128.)
+  const int p_row = (tid & 7) + 8 * (tid >> 5), p_chunk = (tid >> 3) & 3;
+  // fp32 activations: lane -> (half = tid&1, row = ((tid>>1)&7) + 8*(tid>>6), chunk = (tid>>4)&3): each 16-lane
+  // ds_write_b64 group writes 128 contiguous bytes
+  const int f_row = ((tid >> 1) & 7) + 8 * (tid >> 6), f_chunk = (tid >> 4) & 3, f_half = tid & 1;
   const float* a_ptr0 = nullptr; const float* a_ptr1 = nullptr; const float* a_ptr2 = nullptr; const float* a_ptr3 = nullptr;
   const unsigned short* ah_ptr0 = nullptr; const unsigned short* ah_ptr1 = nullptr;
   const unsigned short* al_ptr0 = nullptr; const unsigned short* al_ptr1 = nullptr;
   if constexpr (AP) {
     const unsigned short* Ahi = a.Ahi + (long)bz * a.strideA;
     const unsigned short* Alo = a.Alo + (long)bz * a.strideA;
-    int r0 = m0 + (tid >> 2), r1 = r0 + 64;
+    int r0 = m0 + p_row, r1 = r0 + 64;
     r0 = r0 < a.M ? r0 : a.M - 1;
     r1 = r1 < a.M ? r1 : a.M - 1;
-    ah_ptr0 = Ahi + (long)r0 * a.lda + (tid & 3) * 8; ah_ptr1 = Ahi + (long)r1 * a.lda + (tid & 3) * 8;
-    al_ptr0 = Alo + (long)r0 * a.lda + (tid & 3) * 8; al_ptr1 = Alo + (long)r1 * a.lda + (tid & 3) * 8;
+    ah_ptr0 = Ahi + (long)r0 * a.lda + p_chunk * 8; ah_ptr1 = Ahi + (long)r1 * a.lda + p_chunk * 8;
+    al_ptr0 = Alo + (long)r0 * a.lda + p_chunk * 8; al_ptr1 = Alo + (long)r1 * a.lda + p_chunk * 8;
   } else {
     const float* A = a.A + (long)bz * a.strideA;
-    const int a_c4 = (tid & 7) * 4;
-    int r0 = m0 + (tid >> 3), r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
+    const int a_c4 = f_chunk * 8 + f_half * 4;
+    int r0 = m0 + f_row, r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
     r0 = r0 < a.M ? r0 : a.M - 1; r1 = r1 < a.M ? r1 : a.M - 1;
     r2 = r2 < a.M ? r2 : a.M - 1; r3 = r3 < a.M ? r3 : a.M - 1;
     a_ptr0 = A + (long)r0 * a.lda + a_c4; a_ptr1 = A + (long)r1 * a.lda + a_c4;
     a_ptr2 = A + (long)r2 * a.lda + a_c4; a_ptr3 = A + (long)r3 * a.lda + a_c4;
   }
-  const int a_lds_off = ((tid & 7) >> 1) * 2048 + (tid >> 3) * 16 + (tid & 1) * 8;  // fp32 path, + 512*i
+  const int a_lds_off = f_chunk * 2048 + f_row * 16 + f_half * 8;  // fp32 path, + 512*i
   const unsigned short* Whi = a.Whi + (long)bz * a.strideW;
   const unsigned short* Wlo = a.Wlo + (long)bz * a.strideW;
-  int wr0 = n0 + (tid >> 2), wr1 = wr0 + 64;
+  int wr0 = n0 + p_row, wr1 = wr0 + 64;
   wr0 = wr0 < a.N ? wr0 : a.N - 1;
   wr1 = wr1 < a.N ? wr1 : a.N - 1;
-  const unsigned short* w_hi_ptr0 = Whi + (long)wr0 * K + (tid & 3) * 8;
-  const unsigned short* w_hi_ptr1 = Whi + (long)wr1 * K + (tid & 3) * 8;
-  const unsigned short* w_lo_ptr0 = Wlo + (long)wr0 * K + (tid & 3) * 8;
-  const unsigned short* w_lo_ptr1 = Wlo + (long)wr1 * K + (tid & 3) * 8;
-  const int p_lds_off = (tid & 3) * 2048 + (tid >> 2) * 16;  // plane operands, + 1024*i
+  const unsigned short* w_hi_ptr0 = Whi + (long)wr0 * K + p_chunk * 8;
+  const unsigned short* w_hi_ptr1 = Whi + (long)wr1 * K + p_chunk * 8;
+  const unsigned short* w_lo_ptr0 = Wlo + (long)wr0 * K + p_chunk * 8;
+  const unsigned short* w_lo_ptr1 = Wlo + (long)wr1 * K + p_chunk * 8;
+  const int p_lds_off = p_chunk * 2048 + p_row * 16;  // plane operands, + 1024*i
 
   float4 ra0, ra1, ra2, ra3;            // fp32 activations in flight
   uint4 rah0, rah1, ral0, ral1;         // plane activations in flight
@@ -181,6 +189,19 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   unsigned short* Chi = a.Chi ? a.Chi + (long)bz * a.strideCp : nullptr;
   unsigned short* Clo = a.Clo ? a.Clo + (long)bz * a.strideCp : nullptr;
   const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
+  // column parameters of this lane's 4x4 columns, loaded once, unconditionally (clamped index): the element loop
+  // must not contain loads (each would cost a dependent s_waitcnt vmcnt(0))
+  float bv[4][4], cv[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nn = min(n0 + wn * 64 + ni * 16 + 4 * g + r, a.N - 1);
+      int ci = nn;
+      if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
+      bv[ni][r] = bias ? bias[nn] : 0.f;
+      cv[ni][r] = a.colscale ? a.colscale[ci] * a.alpha : a.alpha;
+    }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + l15;
@@ -192,27 +213,21 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
       float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
       long drow = m;
       int dcol = n;
-      if (a.out_mode == 1) {
-        const int ij = n / a.ps_C;
-        dcol = n - ij * a.ps_C;
-        const int w_ = m % a.ps_W;
-        const int t_ = m / a.ps_W;
-        const int h_ = t_ % a.ps_H;
-        const int b_ = t_ / a.ps_H;
-        drow = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
-      }
-      const long rrow = a.resid_mod > 0 ? (drow % a.resid_mod) : drow;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (n + r < a.N) {
-          float x = v[r];
-          if (bias) x += bias[n + r];
-          x = apply_act(x, a.act);
-          x *= a.alpha;
-          if (a.colscale) x *= a.colscale[dcol + r];
-          v[r] = x;
+      long rrow = m;
+      if constexpr (GEN) {
+        if (a.out_mode == 1) {
+          const int ij = n / a.ps_C;
+          dcol = n - ij * a.ps_C;
+          const int w_ = m % a.ps_W;
+          const int t_ = m / a.ps_W;
+          const int h_ = t_ % a.ps_H;
+          const int b_ = t_ / a.ps_H;
+          drow = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
         }
+        rrow = a.resid_mod > 0 ? (long)((int)drow % a.resid_mod) : drow;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r] + bv[ni][r], a.act) * cv[ni][r];
       if (vec_ok && n + 3 < a.N) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (resid) {
@@ -245,6 +260,16 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
     }
   }
 }
+
+#include <stdlib.h>
+int mmsa_gemm_v2_launch(const unsigned short* Ahi, const unsigned short* Alo, long lda, long strideA,
+                        const unsigned short* Whi, const unsigned short* Wlo, long strideW,
+                        const float* bias, long strideBias, const float* colscale,
+                        const float* resid, long ldr, long strideR, int resid_mod, float beta,
+                        float* C, long ldc, long strideC,
+                        unsigned short* Chi, unsigned short* Clo, long ldcp, long strideCp,
+                        int M, int N, int K, int batch, int act, float alpha,
+                        int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream);
 
 // C-ABI entry: see include/mmsa.h for the contract.
 extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ahi, const unsigned short* Alo, long lda, long strideA,
@@ -289,11 +314,21 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ahi, const
   a.Chi = Chi; a.Clo = Clo; a.ldcp = Chi ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
+  // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 forces this one
+  static const bool force_v1 = getenv("MMSA_GEMM_V1") != nullptr;
+  if (ap && M >= 128 && !force_v1)
+    return mmsa_gemm_v2_launch(Ahi, Alo, lda, strideA, Whi, Wlo, strideW, bias, strideBias, colscale, resid, ldr, strideR,
+                               resid_mod, beta, C, ldc, strideC, Chi, Clo, ldcp, strideCp, M, N, K, batch, act, alpha,
+                               out_mode, ps_H, ps_W, ps_C, stream);
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
-  if (ap)
-    hipLaunchKernelGGL(gemm_split3_kernel<true>, grid, dim3(256), 2 * STAGE_BYTES, stream, a);
-  else
-    hipLaunchKernelGGL(gemm_split3_kernel<false>, grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  const bool gen = out_mode != 0 || resid_mod > 0;
+  if (ap) {
+    if (gen) hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+    else hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  } else {
+    if (gen) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+    else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  }
   MMSA_CHECK_LAUNCH("gemm_split3");
   return MMSA_OK;
 }
