@@ -124,10 +124,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
   }
 
-  // ---- K/V staging: thread -> (key = tid/4, quarter = tid%4), HD/4 channels of K and of V
+  // ---- K/V staging: thread -> (key, quarter of the head dim), HD/4 channels of K and of V.  Lanes 0-7 of every
+  // 8-lane ds_write_b128 group take 8 consecutive keys of ONE quarter, so a group writes 128 contiguous bytes of
+  // the K image (key = tid/4, quarter = tid%4 would put 4 lanes of a group on the same banks: 4-way conflict).
   constexpr int NF4 = HD / 16;  // float4 per thread per operand (fp32 input)
   constexpr int NU = HD / 32;   // uint4 per thread per plane per operand (planes input)
-  const int skey = tid >> 2, squart = tid & 3;
+  const int skey = (tid & 7) + 8 * (tid >> 5), squart = (tid >> 3) & 3;
   float4 rk[NF4], rv[NF4];
   uint4 rkh[NU], rkl[NU], rvh[NU], rvl[NU];
 #define LOAD_KV(kb_)                                                                         \

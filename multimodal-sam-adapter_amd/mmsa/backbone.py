@@ -44,6 +44,19 @@ class Workspace:
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
 
 
+class _Tagged:
+    """Workspace view that prefixes buffer names (private buffers for a chain that runs on its own stream)."""
+
+    def __init__(self, ws, tag):
+        self.ws, self.tag = ws, tag
+
+    def get(self, name, *a, **k):
+        return self.ws.get(self.tag + name, *a, **k)
+
+    def planes(self, name, *a, **k):
+        return self.ws.planes(self.tag + name, *a, **k)
+
+
 class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     def __init__(self, pretrain_size=1024, num_heads=12, conv_inplane=64, n_points=4,
                  modalities_name=['rgb', 'depth', 'lidar', 'event'], modalities_ch=[3, 3, 3, 1],
@@ -433,48 +446,76 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         chans = self.channels
         sizes = [(H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
         tcat = [ws.get(f"tcat{i}", B * sizes[i][0] * sizes[i][1], 2 * chans[i]) for i in range(4)]
-        # --- TwinConvNeXt (TC:445-476): two independent streams, outputs channel-concatenated
-        for si, s in enumerate(("x", "y")):
-            st = pk["twin"][s]
-            h0, w0 = sizes[0]
-            a = ws.get("stem_a", B * h0 * w0, st["stem"].kpad)
-            ops.im2col_nchw(x, 3 * si, 3, 4, a)
-            t0 = ws.get("cn_tmp", B * h0 * w0, chans[0])
-            ops.gemm(a, st["stem"], t0, bias=st["stem_b"])
-            cur = ws.get("cn_cur0", B * h0 * w0, chans[0])
-            ops.layernorm(t0, st["stem_nw"], st["stem_nb"], 1e-6, cur)
-            for i in range(4):
-                hh, wwd = sizes[i]
-                P = B * hh * wwd
-                c = chans[i]
-                if i >= 1:
-                    ds = st["ds"][i - 1]
-                    pa = ws.planes("cn_patch", P, 4 * chans[i - 1])
-                    ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, out_planes=pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]))
-                    cur = ws.get(f"cn_cur{i}", P, c)
-                    ops.gemm(pa, ds["w"], cur, bias=ds["b"])
-                d = ws.get("cn_tmp", P, c)
-                n = ws.planes("cn_n", P, c)
-                hbuf = ws.planes("cn_h", P, 4 * c)
-                for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
-                    ops.dwconv(cur, blk["dw"], blk["dw_b"], d, B, hh, wwd, 7)
-                    ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n)
-                    ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf)
-                    ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur)
-                nw, nb = st["out_norm"][i]
-                ops.layernorm(cur, nw, nb, 1e-6, tcat[i][:, si * c:(si + 1) * c])
-        # --- RoadFormer2Neck (AM:364-394) + fc1..4 (AM:947-956)
-        off_rows = 0
+        # The two ConvNeXt streams and the four neck levels are independent chains of mostly small launches
+        # (M = 8192 rows at 1/16 resolution fills only ~1/3 of the CUs per GEMM), so they run on separate HIP
+        # streams (fork/join with events; captured as parallel branches of the HIP graph) with private workspaces.
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None or self._side[0].device != x.device:
+            self._side = [torch.cuda.Stream(device=x.device) for _ in range(3)]
+        side = self._side
+        fork = torch.cuda.Event()
+        fork.record(main)
+        # --- TwinConvNeXt (TC:445-476): rgb stream on the current stream, auxiliary stream on a side stream
+        side[0].wait_event(fork)
+        with torch.cuda.stream(side[0]):
+            self._twin_stream(1, x, B, sizes, tcat)
+            ev_y = torch.cuda.Event()
+            ev_y.record(side[0])
+        self._twin_stream(0, x, B, sizes, tcat)
+        main.wait_event(ev_y)
+        # --- RoadFormer2Neck (AM:364-394) + fc1..4 (AM:947-956): level 0 here, levels 1..3 on side streams
+        ready = torch.cuda.Event()
+        ready.record(main)
+        offs = [0, 0, sizes[1][0] * sizes[1][1], sizes[1][0] * sizes[1][1] + sizes[2][0] * sizes[2][1]]
+        joins = []
+        for i in (1, 2, 3):
+            s = side[i - 1]
+            s.wait_event(ready)
+            with torch.cuda.stream(s):
+                self._neck_level(i, pk["neck"][i], tcat[i], B, sizes[i][0], sizes[i][1], chans[i], cbuf[offs[i]:], Nc * D)
+                e = torch.cuda.Event()
+                e.record(s)
+                joins.append(e)
+        self._neck_level(0, pk["neck"][0], tcat[0], B, sizes[0][0], sizes[0][1], chans[0], c1_out, 0)
+        for e in joins:
+            main.wait_event(e)
+
+    def _twin_stream(self, si, x, B, sizes, tcat):
+        """One ConvNeXt stream (TC:451-472); writes its half of the channel-concatenated stage outputs."""
+        pk, ws = self._packed, self._ws
+        chans = self.channels
+        st = pk["twin"]["xy"[si]]
+        t = f"cn{si}_"
+        h0, w0 = sizes[0]
+        a = ws.get(t + "stem_a", B * h0 * w0, st["stem"].kpad)
+        ops.im2col_nchw(x, 3 * si, 3, 4, a)
+        t0 = ws.get(t + "tmp", B * h0 * w0, chans[0])
+        ops.gemm(a, st["stem"], t0, bias=st["stem_b"])
+        cur = ws.get(t + "cur0", B * h0 * w0, chans[0])
+        ops.layernorm(t0, st["stem_nw"], st["stem_nb"], 1e-6, cur)
         for i in range(4):
             hh, wwd = sizes[i]
-            out = c1_out if i == 0 else cbuf[off_rows:]
-            self._neck_level(pk["neck"][i], tcat[i], B, hh, wwd, chans[i], out,
-                             0 if i == 0 else Nc * D)
+            P = B * hh * wwd
+            c = chans[i]
             if i >= 1:
-                off_rows += hh * wwd
+                ds = st["ds"][i - 1]
+                pa = ws.planes(t + "patch", P, 4 * chans[i - 1])
+                ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, out_planes=pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]))
+                cur = ws.get(t + f"cur{i}", P, c)
+                ops.gemm(pa, ds["w"], cur, bias=ds["b"])
+            d = ws.get(t + "tmp", P, c)
+            n = ws.planes(t + "n", P, c)
+            hbuf = ws.planes(t + "h", P, 4 * c)
+            for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
+                ops.dwconv(cur, blk["dw"], blk["dw_b"], d, B, hh, wwd, 7)
+                ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n)
+                ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf)
+                ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur)
+            nw, nb = st["out_norm"][i]
+            ops.layernorm(cur, nw, nb, 1e-6, tcat[i][:, si * c:(si + 1) * c])
 
-    def _neck_level(self, lv, t, B, h, w, c, out, out_stride_b):
-        ws = self._ws
+    def _neck_level(self, level, lv, t, B, h, w, c, out, out_stride_b):
+        ws = _Tagged(self._ws, f"nk{level}_")
         C = 2 * c
         HW = h * w
         P = B * HW
