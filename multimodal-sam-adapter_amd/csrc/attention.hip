@@ -40,7 +40,7 @@ struct AttnArgs {
   float scale;
 };
 
-template <int HD, bool PL>
+template <int HD, bool PL, bool FB>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
@@ -122,6 +122,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       qh[sub][ks] = __builtin_bit_cast(bf16x8, hh4);
       ql_[sub][ks] = __builtin_bit_cast(bf16x8, ll4);
     }
+  }
+
+  // FB: W-term of the bias for this lane's fixed key columns (kw = 16t + 4G + r), pre-multiplied by log2(e)
+  float bwr[2][4][4];
+  if constexpr (FB) {
+    __syncthreads();  // bias tables are in LDS
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bwr[sub][t][r] = bw[(wave * 32 + sub * 16 + l15) * a.KWs + 16 * t + 4 * G + r] * 1.4426950408889634f;
   }
 
   // ---- K/V staging: thread -> (key, quarter of the head dim), HD/4 channels of K and of V.  Lanes 0-7 of every
@@ -236,61 +249,74 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       }
     }
 
-    // ---- bias, mask, online softmax
+    // ---- bias, mask, online softmax -- all in log2 units (scores and bias pre-multiplied by log2(e)) so that the
+    // exponential is a bare v_exp_f32
     bf16x8 ph[2][2], pl[2][2];  // [sub][k-step of 32 keys]
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = (PL ? a.scale : 1.0f) * LOG2E;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int qloc = wave * 32 + sub * 16 + l15;
       const float* bhq = bh + qloc * a.KHs;
       const float* bwq = bw + qloc * a.KWs;
       float mx = -INFINITY;
+      if constexpr (FB) {
+        // global attention on a 64-wide grid: the 64 keys of a block are one image row (kh = kb) and
+        // kw = 16t + 4G + r is the same in every block -> the W-term lives in registers, the H-term is one read
+        const float bhv = bhq[kb] * LOG2E;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = kb * 64 + 16 * t + 4 * G + r;
-          float v;
-          if (j < a.Nk) {
-            const int kh = (int)(((unsigned)j * a.magicKW) >> 24);
-            const int kw = j - kh * a.KW;
-            v = (PL ? s[sub][t][r] * a.scale : s[sub][t][r]) + bhq[kh] + bwq[kw];
-          } else {
-            v = -INFINITY;
+          for (int r = 0; r < 4; ++r) {
+            const float v = s[sub][t][r] * sc2 + (bhv + bwr[sub][t][r]);
+            s[sub][t][r] = v;
+            mx = fmaxf(mx, v);
           }
-          s[sub][t][r] = v;
-          mx = fmaxf(mx, v);
-        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = kb * 64 + 16 * t + 4 * G + r;
+            float v;
+            if (j < a.Nk) {
+              const int kh = (int)(((unsigned)j * a.magicKW) >> 24);
+              const int kw = j - kh * a.KW;
+              v = s[sub][t][r] * sc2 + (bhq[kh] + bwq[kw]) * LOG2E;
+            } else {
+              v = -INFINITY;
+            }
+            s[sub][t][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[sub], mx);
-      const float alpha = __expf(m_run[sub] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
       m_run[sub] = m_new;
       float psum = 0.f;
-      unsigned short hbits[16], lbits[16];
+      // MFMA k-slot (G, j): j < 4 -> key 16*(2*s2) + 4G + j ; j >= 4 -> key 16*(2*s2+1) + 4G + (j-4)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 hh, ll;
+        unsigned* hp = reinterpret_cast<unsigned*>(&hh);
+        unsigned* lp = reinterpret_cast<unsigned*>(&ll);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[sub][t][r] - m_new);
-          psum += p;
-          split_bf16(p, hbits[t * 4 + r], lbits[t * 4 + r]);
+        for (int u = 0; u < 4; ++u) {  // dword u = elements (2u, 2u+1): tile 2*s2 + (u>>1), regs 2*(u&1), 2*(u&1)+1
+          const int t = 2 * s2 + (u >> 1), r = 2 * (u & 1);
+          const float p0 = __builtin_amdgcn_exp2f(s[sub][t][r] - m_new);
+          const float p1 = __builtin_amdgcn_exp2f(s[sub][t][r + 1] - m_new);
+          psum += p0 + p1;
+          split2(p0, p1, hp[u], lp[u]);
         }
+        ph[sub][s2] = __builtin_bit_cast(bf16x8, hh);
+        pl[sub][s2] = __builtin_bit_cast(bf16x8, ll);
+      }
       l_run[sub] = l_run[sub] * alpha + psum;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         o[sub][d][0] *= alpha; o[sub][d][1] *= alpha; o[sub][d][2] *= alpha; o[sub][d][3] *= alpha;
-      }
-      // MFMA k-slot (G, j): j < 4 -> key 16*(2*s2) + 4G + j ; j >= 4 -> key 16*(2*s2+1) + 4G + (j-4)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 vh, vl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          vh[j] = (short)hbits[(2 * s2 + (j >> 2)) * 4 + (j & 3)];
-          vl[j] = (short)lbits[(2 * s2 + (j >> 2)) * 4 + (j & 3)];
-        }
-        ph[sub][s2] = vh;
-        pl[sub][s2] = vl;
       }
     }
 
@@ -377,13 +403,19 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
   const size_t smem = 2 * (head_dim / 8) * 64 * 16 + 2 * 64 * VSTR + (size_t)128 * (a.KHs + a.KWs) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 160 * 1024, "attention: bias tables do not fit LDS (KH=%d KW=%d)", a.KH, a.KW);
   dim3 grid(ngroups * cdiv(a.Nk, 128), heads, B);
-#define ATTN_LAUNCH(HD_, PL_)                                                                                              \
+#define ATTN_LAUNCH(HD_, PL_, FB_)                                                                                         \
   do {                                                                                                                     \
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, PL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((attn_kernel<HD_, PL_>), grid, dim3(256), smem, stream, a);                                         \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, PL_, FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((attn_kernel<HD_, PL_, FB_>), grid, dim3(256), smem, stream, a);                                    \
   } while (0)
-  if (head_dim == 64) { if (planes) ATTN_LAUNCH(64, true); else ATTN_LAUNCH(64, false); }
-  else { if (planes) ATTN_LAUNCH(32, true); else ATTN_LAUNCH(32, false); }
+  const bool fb = window_size == 0 && W == 64;   // one key block = one image row: bias terms hoisted (see kernel)
+  if (head_dim == 64) {
+    if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
+    else { if (fb) ATTN_LAUNCH(64, false, true); else ATTN_LAUNCH(64, false, false); }
+  } else {
+    if (planes) { if (fb) ATTN_LAUNCH(32, true, true); else ATTN_LAUNCH(32, true, false); }
+    else { if (fb) ATTN_LAUNCH(32, false, true); else ATTN_LAUNCH(32, false, false); }
+  }
 #undef ATTN_LAUNCH
   MMSA_CHECK_LAUNCH("attention");
   return MMSA_OK;

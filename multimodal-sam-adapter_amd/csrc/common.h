@@ -42,22 +42,31 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// Hardware conversion (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserving): 5 VALU instructions split TWO
+// floats into packed hi/lo pairs, instead of ~10 integer ops per float with the bit-twiddling form above.
+typedef __attribute__((ext_vector_type(2))) __bf16 mmsa_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float mmsa_f32x2;
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const mmsa_f32x2 v = {a, b};
+  const mmsa_bf16x2 h = __builtin_convertvector(v, mmsa_bf16x2);
+  const mmsa_f32x2 r = v - __builtin_convertvector(h, mmsa_f32x2);
+  const mmsa_bf16x2 l = __builtin_convertvector(r, mmsa_bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
-  hi = f32_to_bf16_rn(x);
-  lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+  unsigned h, l;
+  split2(x, 0.f, h, l);
+  hi = (unsigned short)(h & 0xFFFFu);
+  lo = (unsigned short)(l & 0xFFFFu);
 }
 
 // split 4 floats -> 4 hi (packed in 2 dwords) + 4 lo
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-  unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-  split_bf16(v.x, h0, l0);
-  split_bf16(v.y, h1, l1);
-  split_bf16(v.z, h2, l2);
-  split_bf16(v.w, h3, l3);
-  hi.x = (unsigned)h0 | ((unsigned)h1 << 16);
-  hi.y = (unsigned)h2 | ((unsigned)h3 << 16);
-  lo.x = (unsigned)l0 | ((unsigned)l1 << 16);
-  lo.y = (unsigned)l2 | ((unsigned)l3 << 16);
+  split2(v.x, v.y, hi.x, lo.x);
+  split2(v.z, v.w, hi.y, lo.y);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
