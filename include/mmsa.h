@@ -16,8 +16,11 @@
  *  - return 0 on success, negative on error; `mmsa_last_error()` returns a thread-local message.  Shapes,
  *    alignment and strides are validated on the host BEFORE anything is launched.
  *  - activations are fp32, token-major / NHWC: a [rows, channels] matrix with a row stride `ld*` in elements.
- *  - GEMM weights are bf16 hi/lo planes ("split3": x = hi + lo, three MFMA products, fp32 accumulate), produced
- *    once by `mmsa_split_planes`.
+ *  - GEMM weights -- and the intermediate activations that feed GEMMs / attention -- are bf16 hi/lo "planes"
+ *    ("split3": x = hi + lo, three MFMA products, fp32 accumulate) in the INTERLEAVED layout: row r of a [rows, K]
+ *    matrix (K padded to a multiple of 32) is 2K uint16: per 32-wide k-block the 32 hi values then the 32 lo values
+ *    (one 128-byte line per row per MFMA k-step).  Plane pointers are 128-byte aligned, row strides multiples of 64.
+ *    `mmsa_split_planes` converts fp32; producer kernels can emit planes directly.
  */
 #ifndef MMSA_H
 #define MMSA_H
@@ -55,7 +58,7 @@ int mmsa_ms_deform_attn_forward(const float* value, const int64_t* spatial_shape
  * loc = ref + off/(W_l,H_l), and the sampling gather.  out [N*Lq, ldo]. */
 int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                     const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
-                    uint16_t* out_hi, uint16_t* out_lo, long ldop /* optional bf16 hi/lo planes output */, int batch,
+                    uint16_t* out_planes, long ldop /* optional interleaved planes output */, int batch,
                     int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
                     mmsa_stream_t stream);
 
@@ -66,17 +69,18 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * (BK:55,324): row (b,h,w), column (i,j,co) -> row (b,2h+i,2w+j), column co; resid uses the destination index.
  * Call sites replaced: IE:488,499,162-167; TC:107-111,297-304,328-335; AM:947-950,447-451,87-89,121-126,286-290;
  * ops/modules/ms_deform_attn.py:103,107-110,129; BK:324.
- * A is EITHER fp32 (`A`, split to hi/lo while staged) OR activation planes (`Ahi`,`Alo`: bf16 hi/lo written by the
- * producing kernel; lda/strideA then count bf16 elements).  The result goes to fp32 `C`, to planes `Chi`/`Clo`, or both. */
-int mmsa_gemm_split3(const float* A, const uint16_t* Ahi, const uint16_t* Alo, long lda, long strideA,
-                     const uint16_t* Whi, const uint16_t* Wlo, long strideW,
+ * A is EITHER fp32 (`A`, split to hi/lo while staged) OR interleaved activation planes (`Ap`, written by the
+ * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
+ * The result goes to fp32 `C`, to interleaved planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both. */
+int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
+                     const uint16_t* Wp, long strideW,
                      const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,
                      long strideR, int resid_mod, float beta, float* C, long ldc, long strideC,
-                     uint16_t* Chi, uint16_t* Clo, long ldcp, long strideCp, int M, int N, int K,
+                     uint16_t* Cp, long ldcp, long strideCp, int M, int N, int K,
                      int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, mmsa_stream_t stream);
 
-/* fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad], zero padded. */
-int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* hi, uint16_t* lo,
+/* fp32 [rows, cols] (row stride ld) -> interleaved planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0). */
+int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes,
                       mmsa_stream_t stream);
 
 /* --- attention (IE:465-501 incl. window_partition/unpartition IE:504-551 and rel-pos IE:587-623) -------------
@@ -84,16 +88,16 @@ int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pa
  * window_size 0 = global.  out [B*H*W, ldo]. head_dim in {32, 64}. */
 int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo, int B,
                    int H, int W, int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
-/* same with qkv, qkv_bias and the output as bf16 hi/lo planes (strides in bf16 elements) */
-int mmsa_attention_planes(const uint16_t* qkv_hi, const uint16_t* qkv_lo, long ldq, const uint16_t* bias_hi,
-                          const uint16_t* bias_lo, const float* rp, uint16_t* out_hi, uint16_t* out_lo, long ldo, int B,
-                          int H, int W, int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
+/* same with qkv [.., 2*3D], qkv_bias [2*3D] and the output [.., 2*D] as interleaved planes (strides in uint16) */
+int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const float* rp,
+                          uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim,
+                          int window_size, float scale, mmsa_stream_t stream);
 
 /* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
  * get_rel_pos(...)  (IE:554-584), (KH,KW,QS) = (ws,ws,ws) for windowed blocks or (H,W,max) for global ones. */
 int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp, int B, int H, int W,
                      int heads, int head_dim, int window_size, mmsa_stream_t stream);
-int mmsa_relpos_bias_planes(const uint16_t* qkv_hi, const uint16_t* qkv_lo, long ldq, const float* Rh, const float* Rw,
+int mmsa_relpos_bias_planes(const uint16_t* qkv_planes, long ldq, const float* Rh, const float* Rw,
                             float* rp, int B, int H, int W, int heads, int head_dim, int window_size, mmsa_stream_t stream);
 
 /* --- normalisation / reductions ------------------------------------------------------------------------------
@@ -102,7 +106,7 @@ int mmsa_relpos_bias_planes(const uint16_t* qkv_hi, const uint16_t* qkv_lo, long
  * the ConvNeXt 2x2 s2 downsample conv, TC:328-335).  Replaces nn.LayerNorm / LN2d / WithBias_LayerNorm:
  * IE:367,377; AM:479-487,519-520,51-74; mmpretrain_custom/models/utils/norm.py:51-90. */
 int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps, float* y, long ldy,
-                        float* y2, long ldy2, uint16_t* yhi, uint16_t* ylo, long ldp /* optional planes of y */,
+                        float* y2, long ldy2, uint16_t* y_planes, long ldp /* optional interleaved planes of y */,
                         int rows, int C, int map_mode, int map_H, int map_W, mmsa_stream_t stream);
 
 /* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
@@ -120,9 +124,9 @@ int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rs
  * dwconv: weights tap-major [k*k, C]; replaces TC:69-70,102; AM:288; AM:459,464-469.
  * gconv: weights [G][k*k][cin_g][cout_g]; replaces AM:87-88,123-124.
  * im2col_nchw: out[(b,ph,pw)][(c,kh,kw)] from NCHW input channels [c0, c0+Cin) (IE:658-663, TC:297-304). */
-int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y,
-                     uint16_t* yhi, uint16_t* ylo /* optional planes, same ldy/ystrideB */, long ldy,
-                     long ystrideB, int B, int H, int W, int C, int k, int act, mmsa_stream_t stream);
+int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y, long ldy,
+                     long ystrideB, uint16_t* y_planes, long ldp, long pstrideB /* optional interleaved planes */,
+                     int B, int H, int W, int C, int k, int act, mmsa_stream_t stream);
 int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
                     int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);
 int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, int W, int p, float* out, int Kpad,
@@ -132,9 +136,9 @@ int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, in
 int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, float* G, int B, int P, int c,
                  int nblk, mmsa_stream_t stream);
 int mmsa_chanattn_build(const float* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
-                        const float* temp, const float* Wp, uint16_t* hi, uint16_t* lo, int B, int c, int cpad,
+                        const float* temp, const float* Wp, uint16_t* planes /* [B,c,2*cpad] */, int B, int c, int cpad,
                         int heads, mmsa_stream_t stream);
-int mmsa_gffm_build(const float* E, uint16_t* xhi, uint16_t* xlo, uint16_t* yhi, uint16_t* ylo, int B, int c,
+int mmsa_gffm_build(const float* E, uint16_t* x_planes, uint16_t* y_planes /* [B,c,2*cpad] each */, int B, int c,
                     int cpad, mmsa_stream_t stream);
 int mmsa_gelu_gate(const float* x, long ldx, float* y, long ldy, long rows, int C, mmsa_stream_t stream);
 int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int B, int H, int W, int C, mmsa_stream_t stream);

@@ -25,9 +25,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct AttnArgs {
   const float* qkv; long ldq;    // [B*T, 3*D]: q | k | v, channel = head*HD + c   (IE:488 memory order)
   const float* qkv_bias;         // [3*D]
-  const unsigned short* qhi; const unsigned short* qlo;      // planes form of qkv (PL kernels), same ldq
-  const unsigned short* bhi; const unsigned short* blo;      // planes form of qkv_bias
-  unsigned short* ohi; unsigned short* olo;                  // planes output (PL kernels), row stride ldo
+  const unsigned short* qp;      // ilv planes form of qkv (PL kernels), row stride ldq (bf16 units, >= 2*3D)
+  const unsigned short* bp;      // ilv planes form of qkv_bias [2*3D]
+  unsigned short* op;            // ilv planes output (PL kernels), row stride ldo (>= 2*D)
   const float* rp;               // [B, heads, T, KH+KW] rel-pos bias terms (relpos kernel below)
   float* out; long ldo;          // [B*T, D], channel = head*HD + c (IE:498)
   int B, H, W, heads, D;
@@ -74,12 +74,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
   };
 
-  const long qkv_off = (long)b * T * a.ldq + head * HD;
-  const float* qkv_b = PL ? nullptr : a.qkv + qkv_off;
+  const float* qkv_b = PL ? nullptr : a.qkv + (long)b * T * a.ldq + head * HD;
   const float* kbias = PL ? nullptr : a.qkv_bias + a.D + head * HD;
   const float* vbias = PL ? nullptr : a.qkv_bias + 2 * a.D + head * HD;
-  const unsigned short* ph_b = PL ? a.qhi + qkv_off : nullptr;
-  const unsigned short* pl_b = PL ? a.qlo + qkv_off : nullptr;
+  const unsigned short* pq_b = PL ? a.qp + (long)b * T * a.ldq : nullptr;   // image base of the ilv planes
+  const int colq = head * HD, colk = a.D + head * HD, colv = 2 * a.D + head * HD;
 
   // ---- bias tables for the block's 128 queries -> LDS
   {
@@ -107,8 +106,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if constexpr (PL) {  // planes: fragments are plain 16-byte loads; the softmax scale is applied to S instead
-        qh[sub][ks] = *reinterpret_cast<const bf16x8*>(ph_b + qrow + ks * 32 + 8 * G);
-        ql_[sub][ks] = *reinterpret_cast<const bf16x8*>(pl_b + qrow + ks * 32 + 8 * G);
+        const unsigned short* qq = pq_b + qrow + ilv(colq + ks * 32 + 8 * G);
+        qh[sub][ks] = *reinterpret_cast<const bf16x8*>(qq);
+        ql_[sub][ks] = *reinterpret_cast<const bf16x8*>(qq + 32);
         continue;
       }
       float4 v0 = *reinterpret_cast<const float4*>(qp + ks * 32 + 8 * G);
@@ -152,16 +152,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                       \
         const int c = squart * (HD / 4) + 8 * i;                                             \
         if (tk_ >= 0) {                                                                      \
-          const long o_ = (long)tk_ * a.ldq + c;                                             \
-          rkh[i] = *reinterpret_cast<const uint4*>(ph_b + o_ + a.D);                         \
-          rkl[i] = *reinterpret_cast<const uint4*>(pl_b + o_ + a.D);                         \
-          rvh[i] = *reinterpret_cast<const uint4*>(ph_b + o_ + 2 * a.D);                     \
-          rvl[i] = *reinterpret_cast<const uint4*>(pl_b + o_ + 2 * a.D);                     \
+          const unsigned short* kr_ = pq_b + (long)tk_ * a.ldq + ilv(colk + c);              \
+          const unsigned short* vr_ = pq_b + (long)tk_ * a.ldq + ilv(colv + c);              \
+          rkh[i] = *reinterpret_cast<const uint4*>(kr_);                                     \
+          rkl[i] = *reinterpret_cast<const uint4*>(kr_ + 32);                                \
+          rvh[i] = *reinterpret_cast<const uint4*>(vr_);                                     \
+          rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);                                \
         } else if (tk_ == -1) {                                                              \
-          rkh[i] = *reinterpret_cast<const uint4*>(a.bhi + a.D + head * HD + c);             \
-          rkl[i] = *reinterpret_cast<const uint4*>(a.blo + a.D + head * HD + c);             \
-          rvh[i] = *reinterpret_cast<const uint4*>(a.bhi + 2 * a.D + head * HD + c);         \
-          rvl[i] = *reinterpret_cast<const uint4*>(a.blo + 2 * a.D + head * HD + c);         \
+          rkh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c));                    \
+          rkl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c) + 32);               \
+          rvh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c));                    \
+          rvl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c) + 32);               \
         } else {                                                                             \
           rkh[i] = make_uint4(0u, 0u, 0u, 0u); rkl[i] = rkh[i]; rvh[i] = rkh[i]; rvl[i] = rkh[i]; \
         }                                                                                    \
@@ -360,8 +361,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         if constexpr (PL) {
           uint2 hh, ll;
           split4(v, hh, ll);
-          *reinterpret_cast<uint2*>(a.ohi + oo + 16 * d) = hh;
-          *reinterpret_cast<uint2*>(a.olo + oo + 16 * d) = ll;
+          unsigned short* q_ = a.op + ((long)b * T + tq) * a.ldo + ilv(head * HD + 4 * G + 16 * d);
+          *reinterpret_cast<uint2*>(q_) = hh;
+          *reinterpret_cast<uint2*>(q_ + 32) = ll;
         } else {
           *reinterpret_cast<float4*>(a.out + oo + 16 * d) = v;
         }
@@ -375,7 +377,8 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0 && window_size >= 0, "attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "attention: head_dim %d not supported (32 or 64)", head_dim);
   const int D = heads * head_dim;
-  MMSA_CHECK_ARG(a.ldq >= 3L * D && (a.ldq & 7) == 0 && a.ldo >= D && (a.ldo & 3) == 0, "attention: bad leading dimensions");
+  MMSA_CHECK_ARG(a.ldq >= (planes ? 6L : 3L) * D && (a.ldq & 7) == 0 && a.ldo >= (planes ? 2L : 1L) * D && (a.ldo & 3) == 0,
+                 "attention: bad leading dimensions");
   a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
   int ngroups;
   if (window_size > 0) {
@@ -432,15 +435,15 @@ extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias,
 }
 
 // planes form: qkv, qkv_bias and the output are bf16 hi/lo planes (same layouts, strides in elements)
-extern "C" int mmsa_attention_planes(const unsigned short* qkv_hi, const unsigned short* qkv_lo, long ldq,
-                                     const unsigned short* bias_hi, const unsigned short* bias_lo, const float* rp,
-                                     unsigned short* out_hi, unsigned short* out_lo, long ldo, int B, int H, int W,
+extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p, const float* rp,
+                                     unsigned short* out_p, long ldo, int B, int H, int W,
                                      int heads, int head_dim, int window_size, float scale, hipStream_t stream) {
-  MMSA_CHECK_ARG(qkv_hi && qkv_lo && bias_hi && bias_lo && rp && out_hi && out_lo, "attention_planes: null pointer");
-  MMSA_CHECK_ARG(((((uintptr_t)qkv_hi) | ((uintptr_t)qkv_lo) | ((uintptr_t)bias_hi) | ((uintptr_t)bias_lo)) & 15) == 0 &&
-                 ((((uintptr_t)out_hi) | ((uintptr_t)out_lo)) & 7) == 0, "attention_planes: alignment");
+  MMSA_CHECK_ARG(qkv_p && bias_p && rp && out_p, "attention_planes: null pointer");
+  MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
+                 "attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
+  MMSA_CHECK_ARG((heads * head_dim) % 32 == 0, "attention_planes: embed dim must be a multiple of 32");
   AttnArgs a = {};
-  a.qhi = qkv_hi; a.qlo = qkv_lo; a.ldq = ldq; a.bhi = bias_hi; a.blo = bias_lo; a.rp = rp; a.ohi = out_hi; a.olo = out_lo; a.ldo = ldo;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo;
   return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, true, stream);
 }
 
@@ -452,8 +455,7 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_hi, const unsigne
 // Rh/Rw are the gathered tables get_rel_pos(q,k,rel_pos)[q,k,:] (IE:554-584), built once at pack time.
 // Block = one image row (H-term) or one image column (W-term) of tokens x one head.
 template <int HD, bool PL>
-__global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ qkv, const unsigned short* __restrict__ qhi,
-                                                     const unsigned short* __restrict__ qlo, long ldq, const float* __restrict__ Rh,
+__global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ qkv, const unsigned short* __restrict__ qp, long ldq, const float* __restrict__ Rh,
                                                      const float* __restrict__ Rw, float* __restrict__ rp,
                                                      int H, int W, int heads, int ws, int KH, int KW) {
   constexpr int RS = HD + 4;
@@ -481,9 +483,10 @@ __global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ q
       const int t = i / (HD / 4), c = (i % (HD / 4)) * 4;
       const int tok = isH ? line * W + (t0 + t) : (t0 + t) * W + line;
       const long qo = ((long)b * T + tok) * ldq + head * HD + c;
-      if constexpr (PL) {  // q = hi + lo (what the attention MFMAs see)
-        const uint2 h = *reinterpret_cast<const uint2*>(qhi + qo);
-        const uint2 l = *reinterpret_cast<const uint2*>(qlo + qo);
+      if constexpr (PL) {  // q = hi + lo (what the attention MFMAs see), ilv planes
+        const unsigned short* qq = qp + ((long)b * T + tok) * ldq + ilv(head * HD + c);
+        const uint2 h = *reinterpret_cast<const uint2*>(qq);
+        const uint2 l = *reinterpret_cast<const uint2*>(qq + 32);
         float4 v;
         v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
         v.y = __uint_as_float(h.x & 0xFFFF0000u) + __uint_as_float(l.x & 0xFFFF0000u);
@@ -512,21 +515,21 @@ __global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ q
   }
 }
 
-static int relpos_launch(const float* qkv, const unsigned short* qhi, const unsigned short* qlo, long ldq, const float* Rh,
+static int relpos_launch(const float* qkv, const unsigned short* qp, long ldq, const float* Rh,
                          const float* Rw, float* rp, int B, int H, int W, int heads, int head_dim, int window_size,
                          hipStream_t stream) {
-  MMSA_CHECK_ARG((qkv || (qhi && qlo)) && Rh && Rw && rp, "relpos_bias: null pointer");
+  MMSA_CHECK_ARG((qkv || qp) && Rh && Rw && rp, "relpos_bias: null pointer");
   MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "relpos_bias: head_dim %d not supported", head_dim);
   MMSA_CHECK_ARG((ldq & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)Rh) | ((uintptr_t)Rw)) & 15) == 0 &&
-                 ((((uintptr_t)qhi) | ((uintptr_t)qlo)) & 7) == 0, "relpos_bias: alignment");
+                 (((uintptr_t)qp) & 7) == 0, "relpos_bias: alignment");
   const int KH = window_size ? window_size : H, KW = window_size ? window_size : W;
   const int KKmax = KH > KW ? KH : KW;
   const size_t smem = (size_t)(KKmax + 64) * (head_dim + 4) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 64 * 1024, "relpos_bias: table slice does not fit LDS (K=%d)", KKmax);
   dim3 grid(H + W, heads, B);
-#define RP_LAUNCH(HD_, PL_) hipLaunchKernelGGL((relpos_kernel<HD_, PL_>), grid, dim3(256), smem, stream, qkv, qhi, qlo, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW)
-  if (head_dim == 64) { if (qhi) RP_LAUNCH(64, true); else RP_LAUNCH(64, false); }
-  else { if (qhi) RP_LAUNCH(32, true); else RP_LAUNCH(32, false); }
+#define RP_LAUNCH(HD_, PL_) hipLaunchKernelGGL((relpos_kernel<HD_, PL_>), grid, dim3(256), smem, stream, qkv, qp, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW)
+  if (head_dim == 64) { if (qp) RP_LAUNCH(64, true); else RP_LAUNCH(64, false); }
+  else { if (qp) RP_LAUNCH(32, true); else RP_LAUNCH(32, false); }
 #undef RP_LAUNCH
   MMSA_CHECK_LAUNCH("relpos_bias");
   return MMSA_OK;
@@ -534,12 +537,12 @@ static int relpos_launch(const float* qkv, const unsigned short* qhi, const unsi
 
 extern "C" int mmsa_relpos_bias(const float* qkv, long ldq, const float* Rh, const float* Rw, float* rp,
                                 int B, int H, int W, int heads, int head_dim, int window_size, hipStream_t stream) {
-  return relpos_launch(qkv, nullptr, nullptr, ldq, Rh, Rw, rp, B, H, W, heads, head_dim, window_size, stream);
+  return relpos_launch(qkv, nullptr, ldq, Rh, Rw, rp, B, H, W, heads, head_dim, window_size, stream);
 }
 
-extern "C" int mmsa_relpos_bias_planes(const unsigned short* qkv_hi, const unsigned short* qkv_lo, long ldq, const float* Rh,
+extern "C" int mmsa_relpos_bias_planes(const unsigned short* qkv_p, long ldq, const float* Rh,
                                        const float* Rw, float* rp, int B, int H, int W, int heads, int head_dim,
                                        int window_size, hipStream_t stream) {
-  MMSA_CHECK_ARG(qkv_hi && qkv_lo, "relpos_bias_planes: null pointer");
-  return relpos_launch(nullptr, qkv_hi, qkv_lo, ldq, Rh, Rw, rp, B, H, W, heads, head_dim, window_size, stream);
+  MMSA_CHECK_ARG(qkv_p, "relpos_bias_planes: null pointer");
+  return relpos_launch(nullptr, qkv_p, ldq, Rh, Rw, rp, B, H, W, heads, head_dim, window_size, stream);
 }

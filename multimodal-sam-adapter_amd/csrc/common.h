@@ -80,6 +80,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- interleaved hi/lo planes ("ilv"): the storage format of every bf16-split matrix (weights and activations).
+// Row r of a [rows, K] matrix (K % 32 == 0) is 2K bf16 values: for every 32-wide k-block first the 32 hi values,
+// then the 32 lo values.  One k-block of one row is therefore ONE 128-byte line holding everything an MFMA k-step
+// needs from that row (full-line L2 requests for the LDS-DMA; two 64-byte half-line requests per row per k-step
+// was the measured limiter of the two-array layout).  Element k: hi at ilv(k), lo at ilv(k) + 32.
+__host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k & 31); }
+
 // activation codes shared by the GEMM epilogue and the conv kernels
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_HSWISH = 4, ACT_SIGMOID = 5 };
 

@@ -12,7 +12,7 @@
 __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restrict__ x, long ldx, long xstrideB,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, long ldy, long ystrideB,
-                                                          unsigned short* __restrict__ yhi, unsigned short* __restrict__ ylo,
+                                                          unsigned short* __restrict__ yp, long ldp, long pstrideB,
                                                           int B, int H, int W, int C, int k, int act) {
   const int c4n = C >> 2;
   const long total = (long)B * H * W * c4n;
@@ -40,26 +40,27 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
     acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
     const long oo = (long)b * ystrideB + ((long)hh * W + ww) * ldy + c;
     if (y) *reinterpret_cast<float4*>(y + oo) = acc;
-    if (yhi) {  // planes share ldy / ystrideB (in elements)
+    if (yp) {  // ilv planes
       uint2 h2, l2;
       split4(acc, h2, l2);
-      *reinterpret_cast<uint2*>(yhi + oo) = h2;
-      *reinterpret_cast<uint2*>(ylo + oo) = l2;
+      unsigned short* q_ = yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp + ilv(c);
+      *reinterpret_cast<uint2*>(q_) = h2;
+      *reinterpret_cast<uint2*>(q_ + 32) = l2;
     }
   }
 }
 
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
-                                float* y, unsigned short* yhi, unsigned short* ylo, long ldy, long ystrideB,
+                                float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB,
                                 int B, int H, int W, int C, int k, int act, hipStream_t stream) {
-  MMSA_CHECK_ARG(x && w && (y || (yhi && ylo)) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
-  MMSA_CHECK_ARG((yhi == nullptr) == (ylo == nullptr) && ((((uintptr_t)yhi) | ((uintptr_t)ylo)) & 7) == 0, "dwconv_nhwc: bad output planes");
+  MMSA_CHECK_ARG(x && w && (y || yp) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
+  MMSA_CHECK_ARG(!yp || ((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0 && (pstrideB & 63) == 0), "dwconv_nhwc: bad output planes");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "dwconv_nhwc: odd kernel <= 7 expected, got %d", k);
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (xstrideB & 3) == 0 && (ystrideB & 3) == 0, "dwconv_nhwc: C/ld must be multiples of 4");
   const long total = (long)B * H * W * (C >> 2);
   int blocks = cdiv(total, 256);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yhi, ylo, B, H, W, C, k, act);
+  hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, B, H, W, C, k, act);
   MMSA_CHECK_LAUNCH("dwconv_nhwc");
   return MMSA_OK;
 }

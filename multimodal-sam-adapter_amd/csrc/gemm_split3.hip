@@ -22,13 +22,13 @@
 #include "common.h"
 
 struct GemmArgs {
-  const float* A; const unsigned short* Ahi; const unsigned short* Alo; long lda; long strideA;
-  const unsigned short* Whi; const unsigned short* Wlo; long strideW;
+  const float* A; const unsigned short* Ap; long lda; long strideA;   // Ap: ilv planes (lda in bf16 units)
+  const unsigned short* Wp; long strideW;                            // ilv planes, row stride 2*K
   const float* bias; long strideBias;
   const float* colscale;
   const float* resid; long ldr; long strideR; int resid_mod; float beta;
   float* C; long ldc; long strideC;
-  unsigned short* Chi; unsigned short* Clo; long ldcp; long strideCp;
+  unsigned short* Cp; long ldcp; long strideCp;                        // ilv planes output
   int M, N, K;
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;   // out_mode 1: 2x2 pixel-shuffle store (conv-transpose 2x2 s2)
@@ -69,13 +69,12 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   const unsigned short* ah_ptr0 = nullptr; const unsigned short* ah_ptr1 = nullptr;
   const unsigned short* al_ptr0 = nullptr; const unsigned short* al_ptr1 = nullptr;
   if constexpr (AP) {
-    const unsigned short* Ahi = a.Ahi + (long)bz * a.strideA;
-    const unsigned short* Alo = a.Alo + (long)bz * a.strideA;
+    const unsigned short* Ap = a.Ap + (long)bz * a.strideA;
     int r0 = m0 + p_row, r1 = r0 + 64;
     r0 = r0 < a.M ? r0 : a.M - 1;
     r1 = r1 < a.M ? r1 : a.M - 1;
-    ah_ptr0 = Ahi + (long)r0 * a.lda + p_chunk * 8; ah_ptr1 = Ahi + (long)r1 * a.lda + p_chunk * 8;
-    al_ptr0 = Alo + (long)r0 * a.lda + p_chunk * 8; al_ptr1 = Alo + (long)r1 * a.lda + p_chunk * 8;
+    ah_ptr0 = Ap + (long)r0 * a.lda + p_chunk * 8; ah_ptr1 = Ap + (long)r1 * a.lda + p_chunk * 8;
+    al_ptr0 = ah_ptr0 + 32; al_ptr1 = ah_ptr1 + 32;
   } else {
     const float* A = a.A + (long)bz * a.strideA;
     const int a_c4 = f_chunk * 8 + f_half * 4;
@@ -86,15 +85,14 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
     a_ptr2 = A + (long)r2 * a.lda + a_c4; a_ptr3 = A + (long)r3 * a.lda + a_c4;
   }
   const int a_lds_off = f_chunk * 2048 + f_row * 16 + f_half * 8;  // fp32 path, + 512*i
-  const unsigned short* Whi = a.Whi + (long)bz * a.strideW;
-  const unsigned short* Wlo = a.Wlo + (long)bz * a.strideW;
+  const unsigned short* Wp = a.Wp + (long)bz * a.strideW;
   int wr0 = n0 + p_row, wr1 = wr0 + 64;
   wr0 = wr0 < a.N ? wr0 : a.N - 1;
   wr1 = wr1 < a.N ? wr1 : a.N - 1;
-  const unsigned short* w_hi_ptr0 = Whi + (long)wr0 * K + p_chunk * 8;
-  const unsigned short* w_hi_ptr1 = Whi + (long)wr1 * K + p_chunk * 8;
-  const unsigned short* w_lo_ptr0 = Wlo + (long)wr0 * K + p_chunk * 8;
-  const unsigned short* w_lo_ptr1 = Wlo + (long)wr1 * K + p_chunk * 8;
+  const unsigned short* w_hi_ptr0 = Wp + (long)wr0 * 2 * K + p_chunk * 8;
+  const unsigned short* w_hi_ptr1 = Wp + (long)wr1 * 2 * K + p_chunk * 8;
+  const unsigned short* w_lo_ptr0 = w_hi_ptr0 + 32;
+  const unsigned short* w_lo_ptr1 = w_hi_ptr1 + 32;
   const int p_lds_off = p_chunk * 2048 + p_row * 16;  // plane operands, + 1024*i
 
   float4 ra0, ra1, ra2, ra3;            // fp32 activations in flight
@@ -104,20 +102,20 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
 #define LOAD_GLOBAL(k0)                                                   \
   do {                                                                    \
     if constexpr (AP) {                                                   \
-      rah0 = *reinterpret_cast<const uint4*>(ah_ptr0 + (k0));             \
-      rah1 = *reinterpret_cast<const uint4*>(ah_ptr1 + (k0));             \
-      ral0 = *reinterpret_cast<const uint4*>(al_ptr0 + (k0));             \
-      ral1 = *reinterpret_cast<const uint4*>(al_ptr1 + (k0));             \
+      rah0 = *reinterpret_cast<const uint4*>(ah_ptr0 + 2 * (k0));         \
+      rah1 = *reinterpret_cast<const uint4*>(ah_ptr1 + 2 * (k0));         \
+      ral0 = *reinterpret_cast<const uint4*>(al_ptr0 + 2 * (k0));         \
+      ral1 = *reinterpret_cast<const uint4*>(al_ptr1 + 2 * (k0));         \
     } else {                                                              \
       ra0 = *reinterpret_cast<const float4*>(a_ptr0 + (k0));              \
       ra1 = *reinterpret_cast<const float4*>(a_ptr1 + (k0));              \
       ra2 = *reinterpret_cast<const float4*>(a_ptr2 + (k0));              \
       ra3 = *reinterpret_cast<const float4*>(a_ptr3 + (k0));              \
     }                                                                     \
-    rwh0 = *reinterpret_cast<const uint4*>(w_hi_ptr0 + (k0));             \
-    rwh1 = *reinterpret_cast<const uint4*>(w_hi_ptr1 + (k0));             \
-    rwl0 = *reinterpret_cast<const uint4*>(w_lo_ptr0 + (k0));             \
-    rwl1 = *reinterpret_cast<const uint4*>(w_lo_ptr1 + (k0));             \
+    rwh0 = *reinterpret_cast<const uint4*>(w_hi_ptr0 + 2 * (k0));         \
+    rwh1 = *reinterpret_cast<const uint4*>(w_hi_ptr1 + 2 * (k0));         \
+    rwl0 = *reinterpret_cast<const uint4*>(w_lo_ptr0 + 2 * (k0));         \
+    rwl1 = *reinterpret_cast<const uint4*>(w_lo_ptr1 + 2 * (k0));         \
   } while (0)
 
 #define STORE_A(base, reg, i)                                                               \
@@ -186,8 +184,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
   const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
   float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
-  unsigned short* Chi = a.Chi ? a.Chi + (long)bz * a.strideCp : nullptr;
-  unsigned short* Clo = a.Clo ? a.Clo + (long)bz * a.strideCp : nullptr;
+  unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
   const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
   // column parameters of this lane's 4x4 columns, loaded once, unconditionally (clamped index): the element loop
   // must not contain loads (each would cost a dependent s_waitcnt vmcnt(0))
@@ -235,11 +232,12 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
           o.x += a.beta * rr.x; o.y += a.beta * rr.y; o.z += a.beta * rr.z; o.w += a.beta * rr.w;
         }
         if (C) *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
-        if (Chi) {
+        if (Cp) {
           uint2 hh, ll;
           split4(o, hh, ll);
-          *reinterpret_cast<uint2*>(Chi + drow * a.ldcp + dcol) = hh;
-          *reinterpret_cast<uint2*>(Clo + drow * a.ldcp + dcol) = ll;
+          unsigned short* cp_ = Cp + drow * a.ldcp + ilv(dcol);
+          *reinterpret_cast<uint2*>(cp_) = hh;
+          *reinterpret_cast<uint2*>(cp_ + 32) = ll;
         }
       } else {
 #pragma unroll
@@ -248,11 +246,11 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
             float x = v[r];
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol + r];
             if (C) C[drow * a.ldc + dcol + r] = x;
-            if (Chi) {
+            if (Cp) {
               unsigned short hh, ll;
               split_bf16(x, hh, ll);
-              Chi[drow * a.ldcp + dcol + r] = hh;
-              Clo[drow * a.ldcp + dcol + r] = ll;
+              Cp[drow * a.ldcp + ilv(dcol + r)] = hh;
+              Cp[drow * a.ldcp + ilv(dcol + r) + 32] = ll;
             }
           }
         }
@@ -262,63 +260,63 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
 }
 
 #include <stdlib.h>
-int mmsa_gemm_v2_launch(const unsigned short* Ahi, const unsigned short* Alo, long lda, long strideA,
-                        const unsigned short* Whi, const unsigned short* Wlo, long strideW,
+int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
+                        const unsigned short* Wp, long strideW,
                         const float* bias, long strideBias, const float* colscale,
                         const float* resid, long ldr, long strideR, int resid_mod, float beta,
                         float* C, long ldc, long strideC,
-                        unsigned short* Chi, unsigned short* Clo, long ldcp, long strideCp,
+                        unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream);
 
 // C-ABI entry: see include/mmsa.h for the contract.
-extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ahi, const unsigned short* Alo, long lda, long strideA,
-                                const unsigned short* Whi, const unsigned short* Wlo, long strideW,
+extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long lda, long strideA,
+                                const unsigned short* Wp, long strideW,
                                 const float* bias, long strideBias, const float* colscale,
                                 const float* resid, long ldr, long strideR, int resid_mod, float beta,
                                 float* C, long ldc, long strideC,
-                                unsigned short* Chi, unsigned short* Clo, long ldcp, long strideCp,
+                                unsigned short* Cp, long ldcp, long strideCp,
                                 int M, int N, int K, int batch, int act, float alpha,
                                 int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream) {
-  const bool ap = Ahi != nullptr;
-  MMSA_CHECK_ARG((A || (Ahi && Alo)) && Whi && Wlo && (C || (Chi && Clo)), "gemm_split3: null pointer");
-  MMSA_CHECK_ARG(!(A && Ahi), "gemm_split3: pass either fp32 A or A planes, not both");
-  MMSA_CHECK_ARG((Chi == nullptr) == (Clo == nullptr), "gemm_split3: output planes come in pairs");
+  const bool ap = Ap != nullptr;
+  MMSA_CHECK_ARG((A || Ap) && Wp && (C || Cp), "gemm_split3: null pointer");
+  MMSA_CHECK_ARG(!(A && Ap), "gemm_split3: pass either fp32 A or A planes, not both");
   MMSA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_split3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   MMSA_CHECK_ARG(K % BK == 0, "gemm_split3: K=%d must be a multiple of %d (producers pad)", K, BK);
   if (ap) {
-    MMSA_CHECK_ARG((lda & 7) == 0 && (strideA & 7) == 0 && ((((uintptr_t)Ahi) | ((uintptr_t)Alo)) & 15) == 0,
-                   "gemm_split3: A planes must be 16-byte aligned with lda%%8==0 (lda=%ld)", lda);
+    MMSA_CHECK_ARG((lda & 63) == 0 && (strideA & 63) == 0 && (((uintptr_t)Ap) & 127) == 0,
+                   "gemm_split3: A planes must be 128-byte aligned with lda%%64==0 (lda=%ld)", lda);
+    MMSA_CHECK_ARG(lda >= 2L * K, "gemm_split3: planes lda=%ld < 2*K=%d", lda, 2 * K);
   } else {
     MMSA_CHECK_ARG((lda & 3) == 0 && (strideA & 3) == 0 && (((uintptr_t)A) & 15) == 0, "gemm_split3: A must be 16-byte aligned with lda%%4==0 (lda=%ld)", lda);
   }
   MMSA_CHECK_ARG(lda >= K, "gemm_split3: lda=%ld < K=%d", lda, K);
-  MMSA_CHECK_ARG((((uintptr_t)Whi) & 15) == 0 && (((uintptr_t)Wlo) & 15) == 0 && (strideW & 7) == 0, "gemm_split3: weight planes must be 16-byte aligned");
+  MMSA_CHECK_ARG((((uintptr_t)Wp) & 127) == 0 && (strideW & 63) == 0, "gemm_split3: weight planes must be 128-byte aligned");
   MMSA_CHECK_ARG((!C || (((uintptr_t)C) & 15) == 0) && (!resid || (((uintptr_t)resid) & 15) == 0), "gemm_split3: C/resid must be 16-byte aligned");
-  MMSA_CHECK_ARG(!Chi || ((((uintptr_t)Chi) | ((uintptr_t)Clo)) & 7) == 0, "gemm_split3: output planes must be 8-byte aligned");
+  MMSA_CHECK_ARG(!Cp || ((((uintptr_t)Cp) & 127) == 0 && (ldcp & 63) == 0 && (strideCp & 63) == 0), "gemm_split3: output planes must be 128-byte aligned, ldcp%%64==0");
   MMSA_CHECK_ARG(act >= ACT_NONE && act <= ACT_SIGMOID, "gemm_split3: bad act %d", act);
   if (out_mode == 1) {
     MMSA_CHECK_ARG(ps_H > 0 && ps_W > 0 && ps_C > 0 && N == 4 * ps_C && M % (ps_H * ps_W) == 0 && (ps_C & 3) == 0,
                    "gemm_split3: pixel-shuffle store needs N==4*C, M%%(H*W)==0");
-    MMSA_CHECK_ARG((!C || ldc >= ps_C) && (!Chi || ldcp >= ps_C), "gemm_split3: ldc < C");
+    MMSA_CHECK_ARG((!C || ldc >= ps_C) && (!Cp || ldcp >= 2L * ps_C), "gemm_split3: ldc < C");
   } else {
     MMSA_CHECK_ARG(out_mode == 0, "gemm_split3: bad out_mode %d", out_mode);
-    MMSA_CHECK_ARG((!C || ldc >= N) && (!Chi || ldcp >= N), "gemm_split3: ldc=%ld < N=%d", ldc, N);
+    MMSA_CHECK_ARG((!C || ldc >= N) && (!Cp || ldcp >= 2L * ((N + 31) / 32 * 32)), "gemm_split3: ldc=%ld < N=%d", ldc, N);
   }
   GemmArgs a;
-  a.A = A; a.Ahi = Ahi; a.Alo = Alo; a.lda = lda; a.strideA = strideA;
-  a.Whi = Whi; a.Wlo = Wlo; a.strideW = strideW;
+  a.A = A; a.Ap = Ap; a.lda = lda; a.strideA = strideA;
+  a.Wp = Wp; a.strideW = strideW;
   a.bias = bias; a.strideBias = strideBias; a.colscale = colscale;
   a.resid = resid; a.ldr = ldr; a.strideR = strideR; a.resid_mod = resid_mod; a.beta = beta;
   a.C = C; a.ldc = C ? ldc : 0; a.strideC = strideC;
-  a.Chi = Chi; a.Clo = Clo; a.ldcp = Chi ? ldcp : 0; a.strideCp = strideCp;
+  a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
   // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 forces this one
   static const bool force_v1 = getenv("MMSA_GEMM_V1") != nullptr;
   if (ap && M >= 128 && !force_v1)
-    return mmsa_gemm_v2_launch(Ahi, Alo, lda, strideA, Whi, Wlo, strideW, bias, strideBias, colscale, resid, ldr, strideR,
-                               resid_mod, beta, C, ldc, strideC, Chi, Clo, ldcp, strideCp, M, N, K, batch, act, alpha,
+    return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
+                               resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
                                out_mode, ps_H, ps_W, ps_C, stream);
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
   const bool gen = out_mode != 0 || resid_mod > 0;
@@ -333,26 +331,27 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ahi, const
   return MMSA_OK;
 }
 
-// ---- pre-pack: fp32 [rows, cols] (row stride ld) -> bf16 hi/lo planes [rows, cols_pad] (zero padded)
+// ---- pre-pack: fp32 [rows, cols] (row stride ld) -> ilv planes [rows, 2*cols_pad] (zero padded)
 __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
-                                    unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+                                    unsigned short* __restrict__ out) {
   const long total = (long)rows * cols_pad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
     unsigned short h = 0, l = 0;
     if (c < cols) split_bf16(src[(long)r * ld + c], h, l);
-    hi[i] = h;
-    lo[i] = l;
+    unsigned short* o = out + (long)r * 2 * cols_pad + ilv(c);
+    o[0] = h;
+    o[32] = l;
   }
 }
 
 extern "C" int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad,
-                                 unsigned short* hi, unsigned short* lo, hipStream_t stream) {
-  MMSA_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && cols_pad >= cols, "split_planes: bad args");
+                                 unsigned short* out, hipStream_t stream) {
+  MMSA_CHECK_ARG(src && out && rows > 0 && cols > 0 && cols_pad >= cols && cols_pad % 32 == 0, "split_planes: bad args");
   const long total = (long)rows * cols_pad;
   int blocks = cdiv(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, hi, lo);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, out);
   MMSA_CHECK_LAUNCH("split_planes");
   return MMSA_OK;
 }

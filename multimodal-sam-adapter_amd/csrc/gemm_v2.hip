@@ -10,22 +10,25 @@
 //   * PERSISTENT workgroups (grid = min(#tiles, #CUs)): each walks its output tiles and the (tile, k-tile) pairs
 //     form one continuous DMA stream, so the first k-tiles of the next output tile are already landing while the
 //     epilogue of the current one runs (no per-tile fill/drain, no workgroup relaunch);
-//   * LDS image row-major [row][32 k] (64 B rows) with the 16-byte k-chunks of a row XOR-permuted by
-//     T[(row>>2)&3], T = {0,2,3,1}: every ds_read_b128 fragment read is bank-conflict free, and since a DMA
-//     instruction writes 1 KiB linearly (16 rows x 64 B) the permutation is applied on the per-lane SOURCE address;
+//   * operands are stored as INTERLEAVED hi/lo planes (common.h: one k-block of one row = one 128-byte line), so a
+//     DMA instruction fetches 8 rows x 128 B = full lines (the two-array layout issued 64-byte half-line requests
+//     and ran at ~50 % of the L2 request rate: TCC_REQ ~ 2x bytes/128);
+//   * LDS image row-major, 128 B per row = 8 slots of 16 B (4 hi chunks | 4 lo chunks), slot index XORed with
+//     (row>>1)&7: every ds_read_b128 fragment read (hi and lo) is bank-conflict free; a DMA instruction writes
+//     1 KiB linearly, so the permutation is applied on the per-lane SOURCE address;
 //   * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) walk neighbouring (m-tile, n-tile) pairs so
 //     activation rows and weight panels are re-read from that XCD's L2 (speed only, never correctness).
 #include "common.h"
 #include <stdlib.h>
 
 struct GemmV2Args {
-  const unsigned short* Ahi; const unsigned short* Alo; long lda; long strideA;
-  const unsigned short* Whi; const unsigned short* Wlo; long strideW;
+  const unsigned short* Ap; long lda; long strideA;    // ilv planes (common.h), lda in bf16 units (>= 2K)
+  const unsigned short* Wp; long strideW;              // ilv planes, row stride 2K
   const float* bias; long strideBias;
   const float* colscale;
   const float* resid; long ldr; long strideR; int resid_mod; float beta;
   float* C; long ldc; long strideC;
-  unsigned short* Chi; unsigned short* Clo; long ldcp; long strideCp;
+  unsigned short* Cp; long ldcp; long strideCp;
   int M, N, K;
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;
@@ -36,9 +39,9 @@ struct GemmV2Args {
 #define V2_BM 256
 #define V2_BN 128
 #define V2_BK 32
-#define V2_A_PLANE (V2_BM * 64)                         // 16 KiB
-#define V2_W_PLANE (V2_BN * 64)                         // 8 KiB
-#define V2_STAGE (2 * V2_A_PLANE + 2 * V2_W_PLANE)      // 48 KiB
+#define V2_A_BYTES (V2_BM * 128)                        // 32 KiB: 256 rows x (64 B hi | 64 B lo)
+#define V2_W_BYTES (V2_BN * 128)                        // 16 KiB
+#define V2_STAGE (V2_A_BYTES + V2_W_BYTES)              // 48 KiB
 #define V2_NST 3
 
 #define GLDS16(gptr, lptr)                                                                                  \
@@ -70,13 +73,14 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   if (my_tiles <= 0) return;
   const int total = my_tiles * nk;
 
-  // ---- DMA: one instruction = 16 rows x 64 B; lane -> (row = lane>>2, slot = lane&3), k-chunk = slot ^ T[(row>>2)&3]
-  const int drow = lane >> 2;
-  const int swz = (0x1320 >> (((drow >> 2) & 3) * 4)) & 3;  // T = {0,2,3,1}
-  const int dchunk = ((lane & 3) ^ swz) * 8;
-  const int lds_a = wave * 32 * 64;   // this wave's rows in an A plane (+1024 for the second instruction)
-  const int lds_w = wave * 16 * 64;
-  const unsigned short *sa_h0, *sa_h1, *sa_l0, *sa_l1, *sw_h, *sw_l;
+  // ---- DMA: one instruction = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7); the 16-byte piece fetched
+  //      for LDS slot s of row r is piece = s ^ ((r>>1)&7)   (piece 0-3: hi chunks, 4-7: lo chunks)
+  const int drow = lane >> 3;
+  // rows 8i + drow of a 16-row tile: key = (row_in_16 >> 1) & 7 = (drow >> 1) + 4*(i & 1)
+  const int dpiece = ((lane & 7) ^ (drow >> 1)) * 8;         // even 8-row groups; odd groups use dpiece ^ 32
+  const int lds_a = wave * 32 * 128;   // this wave's 32 rows of the A image (4 instructions x 8 rows)
+  const int lds_w = wave * 16 * 128;   // 16 rows of the W image (2 instructions)
+  const unsigned short *sa0, *sa1, *sa2, *sa3, *sw0, *sw1;
 
 #define SET_TILE_SRC(tile_)                                                      \
   do {                                                                           \
@@ -85,31 +89,27 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     const int bz_ = t_ / per_b_;                                                 \
     const int r_ = t_ - bz_ * per_b_;                                            \
     const int m0_ = (r_ / a.nbn) * V2_BM, n0_ = (r_ % a.nbn) * V2_BN;            \
-    int ar0_ = m0_ + wave * 32 + drow, ar1_ = ar0_ + 16;                         \
-    ar0_ = ar0_ < a.M ? ar0_ : a.M - 1;                                          \
-    ar1_ = ar1_ < a.M ? ar1_ : a.M - 1;                                          \
-    int wr_ = n0_ + wave * 16 + drow;                                            \
-    wr_ = wr_ < a.N ? wr_ : a.N - 1;                                             \
-    const long ao_ = (long)bz_ * a.strideA + dchunk;                             \
-    const long wo_ = (long)bz_ * a.strideW + (long)wr_ * K + dchunk;             \
-    sa_h0 = a.Ahi + ao_ + (long)ar0_ * a.lda;                                    \
-    sa_h1 = a.Ahi + ao_ + (long)ar1_ * a.lda;                                    \
-    sa_l0 = a.Alo + ao_ + (long)ar0_ * a.lda;                                    \
-    sa_l1 = a.Alo + ao_ + (long)ar1_ * a.lda;                                    \
-    sw_h = a.Whi + wo_;                                                          \
-    sw_l = a.Wlo + wo_;                                                          \
+    const int ab_ = m0_ + wave * 32 + drow, wb_ = n0_ + wave * 16 + drow;        \
+    const unsigned short* ap_ = a.Ap + (long)bz_ * a.strideA;                    \
+    const unsigned short* wp_ = a.Wp + (long)bz_ * a.strideW;                    \
+    sa0 = ap_ + (long)min(ab_, a.M - 1) * a.lda + dpiece;                        \
+    sa1 = ap_ + (long)min(ab_ + 8, a.M - 1) * a.lda + (dpiece ^ 32);             \
+    sa2 = ap_ + (long)min(ab_ + 16, a.M - 1) * a.lda + dpiece;                   \
+    sa3 = ap_ + (long)min(ab_ + 24, a.M - 1) * a.lda + (dpiece ^ 32);            \
+    sw0 = wp_ + (long)min(wb_, a.N - 1) * 2 * K + dpiece;                        \
+    sw1 = wp_ + (long)min(wb_ + 8, a.N - 1) * 2 * K + (dpiece ^ 32);             \
   } while (0)
 
 #define ISSUE_DMA(kt_, st_)                                                       \
   do {                                                                            \
     unsigned char* sb_ = smem + (st_) * V2_STAGE;                                 \
-    const int ko_ = (kt_) * V2_BK;                                                \
-    GLDS16(sa_h0 + ko_, sb_ + lds_a);                                             \
-    GLDS16(sa_h1 + ko_, sb_ + lds_a + 1024);                                      \
-    GLDS16(sa_l0 + ko_, sb_ + V2_A_PLANE + lds_a);                                \
-    GLDS16(sa_l1 + ko_, sb_ + V2_A_PLANE + lds_a + 1024);                         \
-    GLDS16(sw_h + ko_, sb_ + 2 * V2_A_PLANE + lds_w);                             \
-    GLDS16(sw_l + ko_, sb_ + 2 * V2_A_PLANE + V2_W_PLANE + lds_w);                \
+    const int ko_ = (kt_) * 64;                                                   \
+    GLDS16(sa0 + ko_, sb_ + lds_a);                                               \
+    GLDS16(sa1 + ko_, sb_ + lds_a + 1024);                                        \
+    GLDS16(sa2 + ko_, sb_ + lds_a + 2048);                                        \
+    GLDS16(sa3 + ko_, sb_ + lds_a + 3072);                                        \
+    GLDS16(sw0 + ko_, sb_ + V2_A_BYTES + lds_w);                                  \
+    GLDS16(sw1 + ko_, sb_ + V2_A_BYTES + lds_w + 1024);                           \
   } while (0)
 
   f32x4 acc[4][4];  // [ni][mi]
@@ -118,11 +118,12 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets (row = l15 within a 16-row tile, chunk g, permuted)
-  const int fswz = (0x1320 >> (((l15 >> 2) & 3) * 4)) & 3;
-  const int frag_off = l15 * 64 + ((g ^ fswz) * 16);
-  const int frag_a = (wm * 64) * 64 + frag_off;                       // activation rows, + mi*1024
-  const int frag_w = 2 * V2_A_PLANE + (wn * 64) * 64 + frag_off;      // weight rows, + ni*1024
+  // fragment read offsets: row = l15 within a 16-row tile, hi chunk g at slot g ^ ((row>>1)&7), lo at slot ^ 4
+  const int fslot = g ^ ((l15 >> 1) & 7);
+  const int frag_hi = l15 * 128 + fslot * 16;
+  const int frag_lo = l15 * 128 + (fslot ^ 4) * 16;
+  const int fa = (wm * 64) * 128;                    // activation rows of this wave, + mi*2048
+  const int fw = V2_A_BYTES + (wn * 64) * 128;       // weight rows of this wave, + ni*2048
 
   // ---- prefetch cursor (runs 2 iterations ahead of the compute cursor)
   int pf_tile = rb, pf_kt = 0, pf_st = 0, pf_j = 0;
@@ -156,10 +157,10 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     bf16x8 ah[4], al[4], wh[4], wl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(base + frag_a + i * 1024);
-      al[i] = *reinterpret_cast<const bf16x8*>(base + V2_A_PLANE + frag_a + i * 1024);
-      wh[i] = *reinterpret_cast<const bf16x8*>(base + frag_w + i * 1024);
-      wl[i] = *reinterpret_cast<const bf16x8*>(base + V2_W_PLANE + frag_w + i * 1024);
+      ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);
+      al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);
+      wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);
+      wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -188,8 +189,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
       const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
       float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
-      unsigned short* Chi = a.Chi ? a.Chi + (long)bz * a.strideCp : nullptr;
-      unsigned short* Clo = a.Clo ? a.Clo + (long)bz * a.strideCp : nullptr;
+      unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
       const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of iterations j+1, j+2 (older than the stores below)
       __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; j+1, j+2 landed for all
@@ -278,11 +278,12 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
               if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
-              if (Chi) {
+              if (Cp) {
                 uint2 hh, ll;
                 split4(o, hh, ll);
-                *reinterpret_cast<uint2*>(Chi + drow_ * a.ldcp + dcol) = hh;
-                *reinterpret_cast<uint2*>(Clo + drow_ * a.ldcp + dcol) = ll;
+                unsigned short* cp_ = Cp + drow_ * a.ldcp + ilv(dcol);
+                *reinterpret_cast<uint2*>(cp_) = hh;
+                *reinterpret_cast<uint2*>(cp_ + 32) = ll;
               }
             }
           }
@@ -300,11 +301,11 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
               float x = ov[r];
               if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
               if (C) C[drow_ * a.ldc + dcol] = x;
-              if (Chi) {
+              if (Cp) {
                 unsigned short hh, ll;
                 split_bf16(x, hh, ll);
-                Chi[drow_ * a.ldcp + dcol] = hh;
-                Clo[drow_ * a.ldcp + dcol] = ll;
+                Cp[drow_ * a.ldcp + ilv(dcol)] = hh;
+                Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
               }
             }
           }
@@ -318,21 +319,21 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 static int g_num_cus = 0;
 
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
-int mmsa_gemm_v2_launch(const unsigned short* Ahi, const unsigned short* Alo, long lda, long strideA,
-                        const unsigned short* Whi, const unsigned short* Wlo, long strideW,
+int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
+                        const unsigned short* Wp, long strideW,
                         const float* bias, long strideBias, const float* colscale,
                         const float* resid, long ldr, long strideR, int resid_mod, float beta,
                         float* C, long ldc, long strideC,
-                        unsigned short* Chi, unsigned short* Clo, long ldcp, long strideCp,
+                        unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream) {
   GemmV2Args a;
-  a.Ahi = Ahi; a.Alo = Alo; a.lda = lda; a.strideA = strideA;
-  a.Whi = Whi; a.Wlo = Wlo; a.strideW = strideW;
+  a.Ap = Ap; a.lda = lda; a.strideA = strideA;
+  a.Wp = Wp; a.strideW = strideW;
   a.bias = bias; a.strideBias = strideBias; a.colscale = colscale;
   a.resid = resid; a.ldr = ldr; a.strideR = strideR; a.resid_mod = resid_mod; a.beta = beta;
   a.C = C; a.ldc = C ? ldc : 0; a.strideC = strideC;
-  a.Chi = Chi; a.Clo = Clo; a.ldcp = Chi ? ldcp : 0; a.strideCp = strideCp;
+  a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
   a.nbm = cdiv(M, V2_BM);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void msda_kernel(
     const float* __restrict__ raw, long ldraw,  // FUSED: [N*Lq, M*L*P*2 (offsets) + M*L*P (logits)]
     const float* __restrict__ ref,   // FUSED: [Lq,2] reference points (x,y) in [0,1]
     float* __restrict__ out, long ldo,
-    unsigned short* __restrict__ ohi, unsigned short* __restrict__ olo, long ldop,
+    unsigned short* __restrict__ op, long ldop,
     int N, int S, int M, int D, int L, int Lq, int P) {
   const int d4 = D >> 2;                        // lanes per (q, m) pair
   const long pair = ((long)blockIdx.x * blockDim.x + threadIdx.x) / d4;
@@ -88,11 +88,12 @@ __global__ __launch_bounds__(256) void msda_kernel(
     }
   }
   if (out) *reinterpret_cast<float4*>(out + bq * ldo + (long)m * D + c) = acc;
-  if (ohi) {
+  if (op) {  // ilv planes
     uint2 hh, ll;
     split4(acc, hh, ll);
-    *reinterpret_cast<uint2*>(ohi + bq * ldop + (long)m * D + c) = hh;
-    *reinterpret_cast<uint2*>(olo + bq * ldop + (long)m * D + c) = ll;
+    unsigned short* q_ = op + bq * ldop + ilv(m * D + c);
+    *reinterpret_cast<uint2*>(q_) = hh;
+    *reinterpret_cast<uint2*>(q_ + 32) = ll;
   }
 }
 
@@ -171,7 +172,7 @@ extern "C" int mmsa_ms_deform_attn_forward(const float* value, const int64_t* sp
   const long threads = (long)batch * num_query * num_heads * (channels >> 2);
   hipLaunchKernelGGL(msda_kernel<false>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, value, spatial_shapes,
                      level_start_index, sampling_loc, attn_weight, nullptr, 0L, nullptr, out,
-                     (long)num_heads * channels, nullptr, nullptr, 0L, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
+                     (long)num_heads * channels, nullptr, 0L, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   MMSA_CHECK_LAUNCH("ms_deform_attn_forward");
   return MMSA_OK;
 }
@@ -182,12 +183,12 @@ extern "C" int mmsa_ms_deform_attn_forward(const float* value, const int64_t* sp
 // as produced by AM:397-431).
 extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
-                               unsigned short* out_hi, unsigned short* out_lo, long ldop,
+                               unsigned short* out_p, long ldop,
                                int batch, int spatial_size, int num_heads, int channels, int num_levels,
                                int num_query, int num_point, hipStream_t stream) {
-  MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && ref_points && (out || (out_hi && out_lo)), "msda_fused: null pointer");
-  MMSA_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr) && (!out_hi || (ldop >= (long)num_heads * channels && (ldop & 3) == 0 &&
-                 ((((uintptr_t)out_hi) | ((uintptr_t)out_lo)) & 7) == 0)), "msda_fused: bad output planes");
+  MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && ref_points && (out || out_p), "msda_fused: null pointer");
+  MMSA_CHECK_ARG(!out_p || (ldop >= 2L * num_heads * channels && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
+                 "msda_fused: bad output planes");
   int rc = msda_check(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, "msda_fused");
   if (rc) return rc;
   MMSA_CHECK_ARG(ldraw >= (long)num_heads * num_levels * num_point * 3, "msda_fused: ldraw too small");
@@ -196,7 +197,7 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
   MMSA_CHECK_ARG(((((uintptr_t)value) | ((uintptr_t)out)) & 15) == 0, "msda_fused: value/out must be 16-byte aligned");
   const long threads = (long)batch * num_query * num_heads * (channels >> 2);
   hipLaunchKernelGGL(msda_kernel<true>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, value, spatial_shapes,
-                     level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_hi, out_lo, ldop, batch, spatial_size,
+                     level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, batch, spatial_size,
                      num_heads, channels, num_levels, num_query, num_point);
   MMSA_CHECK_LAUNCH("msda_fused");
   return MMSA_OK;

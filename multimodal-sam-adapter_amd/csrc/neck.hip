@@ -83,7 +83,7 @@ extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, 
 __global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __restrict__ G, const double* __restrict__ sq,
                                                              long sq_strideB, const double* __restrict__ sk, long sk_strideB,
                                                              const float* __restrict__ temp, const float* __restrict__ Wp,
-                                                             unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                             unsigned short* __restrict__ planes,
                                                              int c, int cpad, int heads) {
   extern __shared__ float attn[];  // [ch][ch+1]
   const int h = blockIdx.x, b = blockIdx.y;
@@ -119,30 +119,29 @@ __global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __rest
     for (int i = 0; i < ch; ++i) acc += wrow[i] * attn[i * st + j];
     unsigned short hh, ll;
     split_bf16(acc, hh, ll);
-    const long off = ((long)b * c + o) * cpad + h * ch + j;
-    hi[off] = hh;
-    lo[off] = ll;
+    unsigned short* q_ = planes + ((long)b * c + o) * 2 * cpad + ilv(h * ch + j);   // ilv planes [B, c, 2*cpad]
+    q_[0] = hh;
+    q_[32] = ll;
   }
 }
 
 extern "C" int mmsa_chanattn_build(const float* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
-                                   const float* temp, const float* Wp, unsigned short* hi, unsigned short* lo,
+                                   const float* temp, const float* Wp, unsigned short* planes,
                                    int B, int c, int cpad, int heads, hipStream_t stream) {
-  MMSA_CHECK_ARG(G && sq && sk && temp && Wp && hi && lo, "chanattn_build: null pointer");
+  MMSA_CHECK_ARG(G && sq && sk && temp && Wp && planes, "chanattn_build: null pointer");
   MMSA_CHECK_ARG(c % heads == 0 && cpad >= c, "chanattn_build: bad channel split");
   const int ch = c / heads;
   const size_t smem = (size_t)ch * (ch + 1) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 64 * 1024, "chanattn_build: head block too large");
-  hipLaunchKernelGGL(chanattn_build_kernel, dim3(heads, B), dim3(256), smem, stream, G, sq, sq_strideB, sk, sk_strideB, temp, Wp, hi, lo, c, cpad, heads);
+  hipLaunchKernelGGL(chanattn_build_kernel, dim3(heads, B), dim3(256), smem, stream, G, sq, sq_strideB, sk, sk_strideB, temp, Wp, planes, c, cpad, heads);
   MMSA_CHECK_LAUNCH("chanattn_build");
   return MMSA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // grid (c, B, 2): z = 0 -> Ax[i][:] = softmax_j E[i][j];  z = 1 -> Ay[i][:] = softmax_j E[j][i]
-__global__ __launch_bounds__(256) void gffm_build_kernel(const float* __restrict__ E, unsigned short* __restrict__ xhi,
-                                                         unsigned short* __restrict__ xlo, unsigned short* __restrict__ yhi,
-                                                         unsigned short* __restrict__ ylo, int c, int cpad) {
+__global__ __launch_bounds__(256) void gffm_build_kernel(const float* __restrict__ E, unsigned short* __restrict__ xp,
+                                                         unsigned short* __restrict__ yp, int c, int cpad) {
   __shared__ float red[4];
   const int i = blockIdx.x, b = blockIdx.y, tr = blockIdx.z;
   const float* Eb = E + (long)b * c * c;
@@ -160,22 +159,21 @@ __global__ __launch_bounds__(256) void gffm_build_kernel(const float* __restrict
   if (lane == 0) red[wave] = s;
   __syncthreads();
   const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
-  unsigned short* hi = tr ? yhi : xhi;
-  unsigned short* lo = tr ? ylo : xlo;
+  unsigned short* pl = tr ? yp : xp;   // ilv planes [B, c, 2*cpad]
   for (int j = threadIdx.x; j < c; j += 256) {
     const float p = expf((tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]) - mx) * inv;
     unsigned short hh, ll;
     split_bf16(p, hh, ll);
-    const long off = ((long)b * c + i) * cpad + j;
-    hi[off] = hh;
-    lo[off] = ll;
+    unsigned short* q_ = pl + ((long)b * c + i) * 2 * cpad + ilv(j);
+    q_[0] = hh;
+    q_[32] = ll;
   }
 }
 
-extern "C" int mmsa_gffm_build(const float* E, unsigned short* xhi, unsigned short* xlo, unsigned short* yhi,
-                               unsigned short* ylo, int B, int c, int cpad, hipStream_t stream) {
-  MMSA_CHECK_ARG(E && xhi && xlo && yhi && ylo && cpad >= c, "gffm_build: bad args");
-  hipLaunchKernelGGL(gffm_build_kernel, dim3(c, B, 2), dim3(256), 0, stream, E, xhi, xlo, yhi, ylo, c, cpad);
+extern "C" int mmsa_gffm_build(const float* E, unsigned short* xp, unsigned short* yp, int B, int c, int cpad,
+                               hipStream_t stream) {
+  MMSA_CHECK_ARG(E && xp && yp && cpad >= c, "gffm_build: bad args");
+  hipLaunchKernelGGL(gffm_build_kernel, dim3(c, B, 2), dim3(256), 0, stream, E, xp, yp, c, cpad);
   MMSA_CHECK_LAUNCH("gffm_build");
   return MMSA_OK;
 }

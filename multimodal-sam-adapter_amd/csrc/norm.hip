@@ -13,7 +13,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b, float eps,
     float* __restrict__ y, long ldy, float* __restrict__ y2, long ldy2,
-    unsigned short* __restrict__ yhi, unsigned short* __restrict__ ylo, long ldp, int rows, int C,
+    unsigned short* __restrict__ yp, long ldp, int rows, int C,
     int map_mode, int map_H, int map_W) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   }
   float* yr = y ? y + orow * ldy + ocol : nullptr;
   float* y2r = y2 ? y2 + (long)row * ldy2 : nullptr;
-  unsigned short* hr = yhi ? yhi + orow * ldp + ocol : nullptr;
-  unsigned short* lr = yhi ? ylo + orow * ldp + ocol : nullptr;
+  unsigned short* pr = yp ? yp + orow * ldp : nullptr;   // ilv planes row (ocol is a multiple of 32 when patchifying)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
@@ -68,11 +67,12 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
       o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
       if (yr) *reinterpret_cast<float4*>(yr + c) = o;
-      if (hr) {
+      if (pr) {
         uint2 hh, ll;
         split4(o, hh, ll);
-        *reinterpret_cast<uint2*>(hr + c) = hh;
-        *reinterpret_cast<uint2*>(lr + c) = ll;
+        unsigned short* q_ = pr + ilv((int)ocol + c);
+        *reinterpret_cast<uint2*>(q_) = hh;
+        *reinterpret_cast<uint2*>(q_ + 32) = ll;
       }
       if (y2r) {
         o.x += v[i].x; o.y += v[i].y; o.z += v[i].z; o.w += v[i].w;
@@ -84,18 +84,18 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 
 extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps,
                                    float* y, long ldy, float* y2, long ldy2,
-                                   unsigned short* yhi, unsigned short* ylo, long ldp, int rows, int C,
+                                   unsigned short* yp, long ldp, int rows, int C,
                                    int map_mode, int map_H, int map_W, hipStream_t stream) {
-  MMSA_CHECK_ARG(x && w && b && (y || yhi) && rows > 0 && C > 0, "layernorm_rows: bad args");
-  MMSA_CHECK_ARG((yhi == nullptr) == (ylo == nullptr), "layernorm_rows: output planes come in pairs");
+  MMSA_CHECK_ARG(x && w && b && (y || yp) && rows > 0 && C > 0, "layernorm_rows: bad args");
+  MMSA_CHECK_ARG(!yp || map_mode == 0 || C % 32 == 0, "layernorm_rows: patchified planes need C %% 32 == 0");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy2 & 3) == 0 && (ldp & 3) == 0, "layernorm_rows: C/ld must be multiples of 4");
-  MMSA_CHECK_ARG(((((uintptr_t)yhi) | ((uintptr_t)ylo)) & 7) == 0, "layernorm_rows: planes must be 8-byte aligned");
+  MMSA_CHECK_ARG((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0, "layernorm_rows: planes must be 128-byte aligned, ldp %% 64 == 0");
   MMSA_CHECK_ARG(C <= 4096, "layernorm_rows: C=%d > 4096", C);
   MMSA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)b) | ((uintptr_t)y2)) & 15) == 0, "layernorm_rows: pointers must be 16-byte aligned");
   if (map_mode == 1) MMSA_CHECK_ARG(map_H > 0 && map_W > 0 && (map_H & 1) == 0 && (map_W & 1) == 0 && rows % (map_H * map_W) == 0 && y2 == nullptr,
                                     "layernorm_rows: patchify map needs even H,W");
   dim3 grid(cdiv(rows, 4)), block(256);
-#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yhi, ylo, ldp, rows, C, map_mode, map_H, map_W)
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W)
   if (C <= 256) LN_LAUNCH(1);
   else if (C <= 512) LN_LAUNCH(2);
   else if (C <= 1024) LN_LAUNCH(4);

@@ -37,8 +37,9 @@ class Workspace:
         return b[:n].view(rows, cols)
 
     def planes(self, name, rows, cols, zero=False):
-        """bf16 hi/lo activation planes [rows, cols] (int16 storage)."""
-        return ops.Planes(self.get(name + ".hi", rows, cols, torch.int16, zero), self.get(name + ".lo", rows, cols, torch.int16, zero))
+        """Interleaved bf16 hi/lo activation planes of a [rows, cols] matrix (cols padded to 32)."""
+        cp = ops.pad32(cols)
+        return ops.Planes(self.get(name + ".pl", rows, 2 * cp, torch.int16, zero or cp != cols), rows, cols, cp)
 
     def nbytes(self):
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
@@ -359,8 +360,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         outs = []
         c2p = ws.planes("up_a", B * n2, D)
         for bi in range(B):
-            ops.split_planes(cbuf[bi * Nc:bi * Nc + n2], kpad=D, out=c2p[bi * n2:(bi + 1) * n2])
-        ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=n2 * D,
+            ops.split_planes(cbuf[bi * Nc:bi * Nc + n2], kpad=D, out=c2p.rows(bi * n2, (bi + 1) * n2))
+        ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=n2 * 2 * D,
                  stride_r=(H // 4) * (W // 4) * D, stride_c=(H // 4) * (W // 4) * D, pixel_shuffle=(H // 8, W // 8, D))
         f1 = torch.empty(B, D, H // 4, W // 4, device=dev)
         ops.tail_fuse(c1, (H // 4) * (W // 4) * D, xs[1], *pk["bn"][0], f1, B, H // 4, W // 4, Hp, Wp)
@@ -430,12 +431,11 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         hp = ep["fc2"].kpad  # K of fc2 padded to a multiple of 32; pad columns stay zero
         h1 = ws.get("ffn_h1", B * Nc, hid)
         h2f = ws.planes(f"ffn_h2_{hp}", B * Nc, hp, zero=True)
-        h2 = h2f[:, :hid]
         ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
         off = 0
         for (hh, wwd) in ((H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)):  # AM:462-470 token split 16n/4n/n
             ops.dwconv(h1[off:], ep["dw"], ep["dw_b"], None, B, hh, wwd, 3, act="gelu",
-                       xstride_b=Nc * hid, ystride_b=Nc * hp, out_planes=h2[off:])
+                       xstride_b=Nc * hid, out_planes=h2f.rows(off), pstride_b=Nc * 2 * hp)
             off += hh * wwd
         ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
 
@@ -537,12 +537,11 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             g = ws.get("nk_gram", B * c, c)
             ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8)
             cp = ops.pad32(c)
-            pl = ops.Planes(ws.get(f"nk_phi{c}", B * c, cp, dtype=torch.int16, zero=True),
-                            ws.get(f"nk_plo{c}", B * c, cp, dtype=torch.int16, zero=True), c, c, cp)
+            pl = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
             base = st.data_ptr()
             ops.chanattn_build(g, base + 8 * (3 * c), 9 * c, base + 8 * (3 * c + c), 9 * c, gp["temp"], gp["proj"], pl, B, c, 8)
             ops.gemm(q2[:, 2 * c:], pl, gcat[:, m * c:(m + 1) * c], alpha=gp["scale2"], resid=s, batch=B, m=HW,
-                     stride_a=HW * 3 * c, stride_w=c * cp, stride_r=HW * c, stride_c=HW * C)
+                     stride_a=HW * 3 * c, stride_w=c * 2 * cp, stride_r=HW * c, stride_c=HW * C)
             # MobileNetV2 (AM:281-295)
             lp = lv["loc"][m]
             h1 = ws.get("nk_q1", P, 2 * c)
@@ -554,16 +553,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         e = ws.get("nk_gram", B * c, c)
         ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1)
         cp = ops.pad32(c)
-        px = ops.Planes(ws.get(f"nk_phi{c}", B * c, cp, dtype=torch.int16, zero=True),
-                        ws.get(f"nk_plo{c}", B * c, cp, dtype=torch.int16, zero=True), c, c, cp)
-        py = ops.Planes(ws.get(f"nk_phi2{c}", B * c, cp, dtype=torch.int16, zero=True),
-                        ws.get(f"nk_plo2{c}", B * c, cp, dtype=torch.int16, zero=True), c, c, cp)
+        px = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
+        py = ops.Planes(ws.get(f"nk_pp2{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
         ops.gffm_build(e, px, py, B, c)
         fbuf = ws.get("nk_f", P, C)
         ops.gemm(gcat[:, c:], px, fbuf[:, :c], alpha=lv["gx"], resid=gcat[:, :c], batch=B, m=HW,
-                 stride_a=HW * C, stride_w=c * cp, stride_r=HW * C, stride_c=HW * C)
+                 stride_a=HW * C, stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
         ops.gemm(gcat[:, :c], py, fbuf[:, c:], alpha=lv["gy"], resid=gcat[:, c:], batch=B, m=HW,
-                 stride_a=HW * C, stride_w=c * cp, stride_r=HW * C, stride_c=HW * C)
+                 stride_a=HW * C, stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
         # LayerNorm over H*W (AM:265) + FFRM (AM:158-162), one apply pass
         st = ws.get("nk_st", B * 3, C, dtype=torch.float64)
         ops.colstats(fbuf, HW * C, B, HW, st, wrow=lv["lnw"])

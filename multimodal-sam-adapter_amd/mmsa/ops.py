@@ -55,23 +55,24 @@ def _mat(t, name, dtype=torch.float32):
 
 
 class Planes:
-    """bf16 hi/lo planes (int16 storage) of a matrix: weights [N, Kpad] or activations [rows, cols]."""
+    """Interleaved bf16 hi/lo planes (include/mmsa.h) of a matrix: ONE int16 tensor [rows, 2*kpad]; row r holds, per
+    32-wide k-block, the 32 hi values then the 32 lo values.  Used for weights [N, K] and for activations."""
 
-    def __init__(self, hi, lo, n=None, k=None, kpad=None):
-        self.hi, self.lo = hi, lo
-        self.n = hi.shape[0] if n is None else n
-        self.k = hi.shape[1] if k is None else k
-        self.kpad = hi.shape[1] if kpad is None else kpad
+    def __init__(self, p, n=None, k=None, kpad=None):
+        self.p = p
+        self.n = p.shape[0] if n is None else n
+        self.kpad = p.shape[1] // 2 if kpad is None else kpad
+        self.k = self.kpad if k is None else k
 
-    def __getitem__(self, idx):
-        return Planes(self.hi[idx], self.lo[idx])
+    def rows(self, lo, hi=None):
+        """Row slice (same columns)."""
+        return Planes(self.p[lo:hi], None, self.k, self.kpad)
 
-    def mats(self, name):
-        ph, rows, cols, ld = _mat(self.hi, name + ".hi", torch.int16)
-        pl, _, _, ld2 = _mat(self.lo, name + ".lo", torch.int16)
-        if ld != ld2 or self.hi.shape != self.lo.shape:
-            raise RuntimeError(f"mmsa: {name} hi/lo planes must share shape and stride")
-        return ph, pl, rows, cols, ld
+    def mat(self, name):
+        ptr, rows, cols, ld = _mat(self.p, name, torch.int16)
+        if ptr % 128 or ld % 64:
+            raise RuntimeError(f"mmsa: {name} planes must be 128-byte aligned with a row stride that is a multiple of 64")
+        return ptr, rows, cols // 2, ld
 
 
 def pad32(k):
@@ -80,7 +81,15 @@ def pad32(k):
 
 def alloc_planes(rows, cols, device, zero=False):
     f = torch.zeros if zero else torch.empty
-    return Planes(f(rows, cols, dtype=torch.int16, device=device), f(rows, cols, dtype=torch.int16, device=device))
+    return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols))
+
+
+def planes_to_float(pl, cols=None):
+    """Debug/test helper: reconstruct hi + lo as fp32 [rows, cols] (torch ops; not used on the product path)."""
+    r, w = pl.p.shape
+    v = (pl.p.to(torch.int32) << 16).view(torch.float32).view(r, w // 64, 2, 32)
+    out = (v[:, :, 0] + v[:, :, 1]).reshape(r, w // 2)
+    return out[:, :(pl.k if cols is None else cols)]
 
 
 def split_planes(w2d, kpad=None, out=None):
@@ -88,9 +97,8 @@ def split_planes(w2d, kpad=None, out=None):
     p, n, k, ld = _mat(w2d, "weight")
     kpad = kpad or pad32(k)
     if out is None:
-        out = Planes(torch.empty(n, kpad, dtype=torch.int16, device=w2d.device),
-                     torch.empty(n, kpad, dtype=torch.int16, device=w2d.device), n, k, kpad)
-    lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.hi.data_ptr(), out.lo.data_ptr(), _stream())
+        out = Planes(torch.empty(n, 2 * kpad, dtype=torch.int16, device=w2d.device), n, k, kpad)
+    lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), _stream())
     return out
 
 
@@ -100,21 +108,22 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     """out / out_planes = beta*resid + colscale*alpha*act(a @ w^T + bias).
     a: fp32 2-D view or activation Planes; w: weight Planes; out: fp32 view and/or out_planes: Planes."""
     if isinstance(a, Planes):
-        pah, pal, ma, ka, lda = a.mats("A")
+        pap, ma, ka, lda = a.mat("A")
         pa = None
+        if ka < w.kpad:
+            raise RuntimeError(f"mmsa.gemm: A planes have {ka} columns but the packed weight expects K={w.kpad}")
     else:
         pa, ma, ka, lda = _mat(a, "A")
-        pah = pal = None
+        pap = None
+        if ka < w.kpad and lda < w.kpad:
+            raise RuntimeError(f"mmsa.gemm: A has {ka} columns (ld {lda}) but the packed weight expects K={w.kpad}")
     m = ma if m is None else m
-    if ka < w.kpad and lda < w.kpad:
-        raise RuntimeError(f"mmsa.gemm: A has {ka} columns (ld {lda}) but the packed weight expects K={w.kpad}")
     pc, ldc = None, 0
     if out is not None:
         pc, _, _, ldc = _mat(out, "C")
-    pch = pcl = None
-    ldcp = 0
+    pcp, ldcp = None, 0
     if out_planes is not None:
-        pch, pcl, _, _, ldcp = out_planes.mats("Cplanes")
+        pcp, _, _, ldcp = out_planes.mat("Cplanes")
     pr, ldr = None, 0
     if resid is not None:
         pr, _, _, ldr = _mat(resid, "resid")
@@ -123,9 +132,9 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     if prof is not None:
         e0, e1 = _event(), _event()
         lib.call("mmsa_event_record", e0, _stream())
-    lib.call("mmsa_gemm_split3", pa, pah, pal, lda, stride_a, w.hi.data_ptr(), w.lo.data_ptr(), stride_w,
+    lib.call("mmsa_gemm_split3", pa, pap, lda, stride_a, w.p.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
-             pc, ldc, stride_c, pch, pcl, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
+             pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
              1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
@@ -141,12 +150,11 @@ def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None)
     p2, ld2 = None, 0
     if out2 is not None:
         p2, _, _, ld2 = _mat(out2, "y2")
-    ph = pl = None
-    ldp = 0
+    pp, ldp = None, 0
     if out_planes is not None:
-        ph, pl, _, _, ldp = out_planes.mats("y planes")
+        pp, _, _, ldp = out_planes.mat("y planes")
     mh, mw = patchify or (0, 0)
-    lib.call("mmsa_layernorm_rows", px, ldx, _chk(w), _chk(b), eps, py, ldy, p2, ld2, ph, pl, ldp, rows, c,
+    lib.call("mmsa_layernorm_rows", px, ldx, _chk(w), _chk(b), eps, py, ldy, p2, ld2, pp, ldp, rows, c,
              1 if patchify else 0, mh, mw, _stream())
     return out if out is not None else out_planes
 
@@ -173,19 +181,18 @@ def msda_fused(value2d, spatial_shapes, level_start_index, raw, ref_points, out,
     po, ldo = None, 0
     if out is not None:
         po, _, _, ldo = _mat(out, "out")
-    ph = pl = None
-    ldp = 0
+    pp, ldp = None, 0
     if out_planes is not None:
-        ph, pl, _, _, ldp = out_planes.mats("out planes")
+        pp, _, _, ldp = out_planes.mat("out planes")
     lib.call("mmsa_msda_fused", pv, _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64), pr, ldraw,
-             _chk(ref_points), po, ldo, ph, pl, ldp, batch, spatial, heads, d, levels, lq, points, _stream())
+             _chk(ref_points), po, ldo, pp, ldp, batch, spatial, heads, d, levels, lq, points, _stream())
     return out if out is not None else out_planes
 
 
 def relpos_bias(qkv, rh, rw, rp, b, h, w, heads, hd, ws):
     if isinstance(qkv, Planes):
-        ph, pl, _, _, ldq = qkv.mats("qkv")
-        lib.call("mmsa_relpos_bias_planes", ph, pl, ldq, _chk(rh), _chk(rw), _chk(rp), b, h, w, heads, hd, ws, _stream())
+        pq, _, _, ldq = qkv.mat("qkv")
+        lib.call("mmsa_relpos_bias_planes", pq, ldq, _chk(rh), _chk(rw), _chk(rp), b, h, w, heads, hd, ws, _stream())
     else:
         pq, _, _, ldq = _mat(qkv, "qkv")
         lib.call("mmsa_relpos_bias", pq, ldq, _chk(rh), _chk(rw), _chk(rp), b, h, w, heads, hd, ws, _stream())
@@ -194,10 +201,10 @@ def relpos_bias(qkv, rh, rw, rp, b, h, w, heads, hd, ws):
 
 def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
     if isinstance(qkv, Planes):
-        ph, pl, _, _, ldq = qkv.mats("qkv")
-        oh, ol, _, _, ldo = out.mats("out")
-        lib.call("mmsa_attention_planes", ph, pl, ldq, _chk(qkv_bias.hi, torch.int16), _chk(qkv_bias.lo, torch.int16), _chk(rp),
-                 oh, ol, ldo, b, h, w, heads, hd, ws, scale, _stream())
+        pq, _, _, ldq = qkv.mat("qkv")
+        po, _, _, ldo = out.mat("out")
+        lib.call("mmsa_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(rp),
+                 po, ldo, b, h, w, heads, hd, ws, scale, _stream())
     else:
         pq, _, _, ldq = _mat(qkv, "qkv")
         po, _, _, ldo = _mat(out, "out")
@@ -223,21 +230,19 @@ def lnhw_apply(x, mean, rstd, mult, w, bias, out, b, hw):
     return out
 
 
-def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=None, out_planes=None):
-    """Depthwise conv; result to fp32 `out` and/or `out_planes` (which then share the row stride)."""
+def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=None, out_planes=None, pstride_b=None):
+    """Depthwise conv; result to fp32 `out` and/or interleaved `out_planes`."""
     px, _, c, ldx = _mat(x, "x")
     po, ldo = None, 0
     if out is not None:
         po, _, _, ldo = _mat(out, "y")
-    ph = pl = None
+    pp, ldp = None, 0
     if out_planes is not None:
-        ph, pl, _, _, ldp = out_planes.mats("y planes")
-        if out is not None and ldp != ldo:
-            raise RuntimeError("mmsa.dwconv: fp32 output and planes must share the row stride")
-        ldo = ldp
+        pp, _, _, ldp = out_planes.mat("y planes")
     xs = h * wd * ldx if xstride_b is None else xstride_b
     ys = h * wd * ldo if ystride_b is None else ystride_b
-    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ph, pl, ldo, ys, b, h, wd, c, k, ACT[act], _stream())
+    ps = h * wd * ldp if pstride_b is None else pstride_b
+    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, b, h, wd, c, k, ACT[act], _stream())
     return out if out is not None else out_planes
 
 
@@ -268,12 +273,11 @@ def gram_tn(x, y, stride_b, g, b, p, nblk=1):
 
 def chanattn_build(g, sq, sq_stride, sk, sk_stride, temp, wp, planes, b, c, heads):
     lib.call("mmsa_chanattn_build", _chk(g), sq, sq_stride, sk, sk_stride, _chk(temp), _chk(wp),
-             planes.hi.data_ptr(), planes.lo.data_ptr(), b, c, planes.kpad, heads, _stream())
+             planes.p.data_ptr(), b, c, planes.kpad, heads, _stream())
 
 
 def gffm_build(e, px_, py_, b, c):
-    lib.call("mmsa_gffm_build", _chk(e), px_.hi.data_ptr(), px_.lo.data_ptr(), py_.hi.data_ptr(), py_.lo.data_ptr(),
-             b, c, px_.kpad, _stream())
+    lib.call("mmsa_gffm_build", _chk(e), px_.p.data_ptr(), py_.p.data_ptr(), b, c, px_.kpad, _stream())
 
 
 def gelu_gate(x, out, c):

@@ -70,11 +70,10 @@ def test_gemm_batched_and_pixel_shuffle(ops):
     a = torch.randn(B, M, K, generator=g(11))
     w = torch.randn(B, N, K, generator=g(12)) / 8
     ref = torch.bmm(a, w.transpose(1, 2))
-    hi = torch.empty(B * N, K, dtype=torch.int16, device=DEV)
     pls = ops.split_planes(w.reshape(B * N, K).to(DEV))
     pls.n = N
     out = torch.empty(B * M, N, device=DEV)
-    ops.gemm(a.reshape(B * M, K).to(DEV), pls, out, batch=B, m=M, stride_a=M * K, stride_w=N * K, stride_c=M * N)
+    ops.gemm(a.reshape(B * M, K).to(DEV), pls, out, batch=B, m=M, stride_a=M * K, stride_w=N * 2 * K, stride_c=M * N)
     assert_close(out.view(B, M, N), ref, what="batched")
     # ConvTranspose2d(C, C, 2, 2) as GEMM + pixel shuffle (BK:55,324)
     Bc, C, H, W = 2, 32, 5, 7
@@ -347,13 +346,13 @@ def test_gfe_module(ops, c, H, W):
     ops.colstats(q2, HW * 3 * c, B, HW, st)
     gm = torch.empty(B * c, c, device=DEV)
     ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, gm, B, HW, nblk=8)
-    pl = ops.Planes(torch.zeros(B * c, c, dtype=torch.int16, device=DEV), torch.zeros(B * c, c, dtype=torch.int16, device=DEV), c, c, c)
+    pl = ops.Planes(torch.zeros(B * c, 2 * c, dtype=torch.int16, device=DEV), c, c, c)
     base = st.data_ptr()
     ops.chanattn_build(gm, base + 8 * 3 * c, 9 * c, base + 8 * 4 * c, 9 * c, sd["attn.scale"].reshape(8).contiguous().to(DEV),
                        sd["attn.proj.weight"].reshape(c, c).contiguous().to(DEV), pl, B, c, 8)
     out = torch.empty(B * HW, c, device=DEV)
     ops.gemm(q2[:, 2 * c:], pl, out, alpha=float(sd["attn.scale2"]), resid=s, batch=B, m=HW, stride_a=HW * 3 * c,
-             stride_w=c * c, stride_r=HW * c, stride_c=HW * c)
+             stride_w=c * 2 * c, stride_r=HW * c, stride_c=HW * c)
     assert_close(out.view(B, H, W, c).permute(0, 3, 1, 2), ref, what="GFE")
 
 
@@ -369,11 +368,11 @@ def test_gffm_gemms(ops):
     gc = gin.permute(0, 2, 3, 1).reshape(B * HW, 2 * c).contiguous().to(DEV)
     e = torch.empty(B * c, c, device=DEV)
     ops.gram_tn(gc[:, :c], gc[:, c:], HW * 2 * c, e, B, HW)
-    mk = lambda: ops.Planes(torch.zeros(B * c, c, dtype=torch.int16, device=DEV), torch.zeros(B * c, c, dtype=torch.int16, device=DEV), c, c, c)
+    mk = lambda: ops.Planes(torch.zeros(B * c, 2 * c, dtype=torch.int16, device=DEV), c, c, c)
     px, py = mk(), mk()
     ops.gffm_build(e, px, py, B, c)
     f = torch.empty(B * HW, 2 * c, device=DEV)
-    kw = dict(batch=B, m=HW, stride_a=HW * 2 * c, stride_w=c * c, stride_r=HW * 2 * c, stride_c=HW * 2 * c)
+    kw = dict(batch=B, m=HW, stride_a=HW * 2 * c, stride_w=c * 2 * c, stride_r=HW * 2 * c, stride_c=HW * 2 * c)
     ops.gemm(gc[:, c:], px, f[:, :c], alpha=gx, resid=gc[:, :c], **kw)
     ops.gemm(gc[:, :c], py, f[:, c:], alpha=gy, resid=gc[:, c:], **kw)
     assert_close(f.view(B, HW, 2 * c).permute(0, 2, 1), ref, what="GFFM energies")

@@ -22,18 +22,24 @@ def g(seed):
 
 
 def planes_to_float(p):
-    hi = (p.hi.to(torch.int32) << 16).view(torch.float32)
-    lo = (p.lo.to(torch.int32) << 16).view(torch.float32)
-    return hi + lo
+    import mmsa
+    return mmsa.ops.planes_to_float(p)
 
 
 def test_split_planes_roundtrip(ops):
     x = torch.randn(37, 50, generator=g(1)) * 3
     p = ops.split_planes(x.to(DEV))
-    assert p.hi.shape == (37, 64) and p.kpad == 64
-    back = planes_to_float(p).cpu()
+    assert p.p.shape == (37, 128) and p.kpad == 64 and p.k == 50
+    back = ops.planes_to_float(p, cols=64).cpu()
     assert torch.all(back[:, 50:] == 0)
     assert ((back[:, :50] - x).abs() <= x.abs() * 2 ** -15).all()  # ~16 mantissa bits
+    # interleaved layout: hi of element k at (k>>5)*64 + (k&31), lo 32 further
+    raw = p.p.cpu()
+    hi0 = (raw[:, 0].to(torch.int32) << 16).view(torch.float32)
+    lo0 = (raw[:, 32].to(torch.int32) << 16).view(torch.float32)
+    assert torch.equal(hi0 + lo0, back[:, 0])
+    hi33 = (raw[:, 64 + 1].to(torch.int32) << 16).view(torch.float32)
+    assert ((hi33 - x[:, 33]).abs() <= x[:, 33].abs() * 2 ** -8).all()
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 96, 64), (1000, 576, 1024), (4096, 1024, 768), (77, 28, 96)])
@@ -100,7 +106,7 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table):
     rp = torch.empty(B * heads * T, kk, device=DEV)
     ops.relpos_bias(qkv, rh, rw, rp, B, H, W, heads, hd, ws)
     ao = ops.alloc_planes(B * T, D, DEV)
-    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).to(DEV), kpad=3 * D)
+    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV), kpad=3 * D)
     ops.attention(qkv, biasp, rp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
