@@ -33,7 +33,7 @@ struct GemmV2Args {
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;
   int nbm, nbn, ntiles;
-  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all
+  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands)
 };
 
 #define V2_BM 256
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 #define ISSUE_DMA(kt_, st_)                                                       \
   do {                                                                            \
     unsigned char* sb_ = smem + (st_) * V2_STAGE;                                 \
-    const int ko_ = (kt_) * 64;                                                   \
+    const int ko_ = a.debug == 3 ? 0 : (kt_) * 64;   /* debug 3: timing experiment, re-read k-tile 0 */ \
     GLDS16(sa0 + ko_, sb_ + lds_a);                                               \
     GLDS16(sa1 + ko_, sb_ + lds_a + 1024);                                        \
     GLDS16(sa2 + ko_, sb_ + lds_a + 2048);                                        \
@@ -152,24 +152,57 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     else if (j + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (pf_j < total) PREFETCH_NEXT();   // ring slot (j+2)%3 was last read in iteration j-1: free after the barrier
+    // The 6 DMA instructions of iteration j+2 (ring slot (j+2)%3, last read in iteration j-1: free after the
+    // barrier) are issued BETWEEN the MFMA chunks, two per chunk: an LDS-DMA costs ~100 issue cycles (M0 write,
+    // address arithmetic, the instruction) which disappear under the 16-cycle passes of the MFMAs already queued
+    // on the matrix pipe; issued in a block right after the barrier they sat on the critical path of both waves of
+    // every SIMD (measured: ~3000 cycles per k-tile for 1536 cycles of MFMA work).
+    const bool do_pf = pf_j < total;
+    unsigned char* pfb = smem + pf_st * V2_STAGE;
+    const int pko = a.debug == 3 ? 0 : pf_kt * 64;
     const unsigned char* base = smem + st * V2_STAGE;
+    // all 16 fragment reads up front (spreading the weight-fragment reads over the chunks measured slower)
     bf16x8 ah[4], al[4], wh[4], wl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);
       al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);
-      wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);
-      wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);
     }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+#define READ_W(i)                                                                        \
+  wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + (i) * 2048 + frag_hi);             \
+  wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + (i) * 2048 + frag_lo);
+    READ_W(0) READ_W(1) READ_W(2) READ_W(3)
+#define MFMA_CHUNK(ni)                                                                                      \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                        \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);            \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
+  }
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_CHUNK(0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_pf) { GLDS16(sa0 + pko, pfb + lds_a); GLDS16(sa1 + pko, pfb + lds_a + 1024); }
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_CHUNK(1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_pf) { GLDS16(sa2 + pko, pfb + lds_a + 2048); GLDS16(sa3 + pko, pfb + lds_a + 3072); }
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_CHUNK(2)
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_pf) { GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w); GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024); }
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_CHUNK(3)
+#undef MFMA_CHUNK
+#undef READ_W
+    if (do_pf) {   // advance the prefetch cursor (source pointers of the next output tile when the k loop wraps)
+      pf_st = pf_st == 2 ? 0 : pf_st + 1;
+      ++pf_j;
+      if (++pf_kt == nk) {
+        pf_kt = 0;
+        pf_tile += G;
+        if (pf_j < total) SET_TILE_SRC(pf_tile);
       }
+    }
     const int st_cur = st;
     st = st == 2 ? 0 : st + 1;
     if (++kt < nk) continue;
