@@ -50,6 +50,63 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
   }
 }
 
+// 7x7 depthwise conv (ConvNeXt, TC:69-70,102), LDS-tiled: one workgroup = 8 x 8 output pixels x 64 channels.
+// The 14 x 14 x 64 input halo tile is staged once in LDS (50 KiB, channel-contiguous so a 16-lane group reads 256
+// contiguous bytes: conflict free); each lane owns a 1 x 4 pixel strip of one 4-channel vector and, per kernel row,
+// reads 10 input vectors once for 7 taps x 4 outputs (70 LDS reads instead of 196 global/L1 reads per 4 outputs).
+__global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restrict__ x, long ldx, long xstrideB,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long ldy, long ystrideB,
+                                                            int H, int W, int C, int tilesX) {
+  constexpr int TW = 14, CB = 64;
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [14][14][64]
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CB;
+  const int tx0 = (blockIdx.x % tilesX) * 8, ty0 = (blockIdx.x / tilesX) * 8;
+  const float* xb = x + (long)b * xstrideB;
+  const int cvalid = min(CB, C - c0);   // multiple of 4
+  for (int i = threadIdx.x; i < TW * TW * (CB / 4); i += 256) {
+    const int cv = i & 15, pos = i >> 4;
+    const int ly = pos / TW, lx = pos - ly * TW;
+    const int iy = ty0 + ly - 3, ix = tx0 + lx - 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cv * 4 < cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W)
+      v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx + c0 + cv * 4);
+    *reinterpret_cast<float4*>(tile + pos * CB + cv * 4) = v;
+  }
+  __syncthreads();
+  const int cv = threadIdx.x & 15, strip = threadIdx.x >> 4;   // 16 strips: row = strip>>1, x0 = (strip&1)*4
+  const int oy = strip >> 1, ox0 = (strip & 1) * 4;
+  const int c = c0 + cv * 4;
+  if (cv * 4 >= cvalid) return;
+  float4 acc[4];
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) acc[p] = bv;
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {   // not unrolled: 7 weight vectors live at a time instead of 49 (occupancy)
+    float4 in[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) in[i] = *reinterpret_cast<const float4*>(tile + ((oy + kh) * TW + ox0 + i) * CB + cv * 4);
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const float4 f = *reinterpret_cast<const float4*>(w + (long)(kh * 7 + kw) * C + c);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        acc[p].x += in[p + kw].x * f.x; acc[p].y += in[p + kw].y * f.y;
+        acc[p].z += in[p + kw].z * f.z; acc[p].w += in[p + kw].w * f.w;
+      }
+    }
+  }
+  const int gy = ty0 + oy;
+  if (gy >= H) return;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int gx = tx0 + ox0 + p;
+    if (gx < W) *reinterpret_cast<float4*>(y + (long)b * ystrideB + ((long)gy * W + gx) * ldy + c) = acc[p];
+  }
+}
+
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
                                 float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB,
                                 int B, int H, int W, int C, int k, int act, hipStream_t stream) {
@@ -57,6 +114,13 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   MMSA_CHECK_ARG(!yp || ((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0 && (pstrideB & 63) == 0), "dwconv_nhwc: bad output planes");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "dwconv_nhwc: odd kernel <= 7 expected, got %d", k);
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (xstrideB & 3) == 0 && (ystrideB & 3) == 0, "dwconv_nhwc: C/ld must be multiples of 4");
+  if (k == 7 && y && !yp && act == ACT_NONE && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)bias)) & 15) == 0) {
+    const int tx = cdiv(W, 8), ty = cdiv(H, 8);
+    dim3 grid(tx * ty, cdiv(C, 64), B);
+    hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, H, W, C, tx);
+    MMSA_CHECK_LAUNCH("dwconv_nhwc(7x7 tiled)");
+    return MMSA_OK;
+  }
   const long total = (long)B * H * W * (C >> 2);
   int blocks = cdiv(total, 256);
   if (blocks > 16384) blocks = 16384;

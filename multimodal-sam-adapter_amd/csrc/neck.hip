@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __rest
     for (int j = 0; j < ch; ++j) attn[i * st + j] *= inv;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < c * ch; idx += 256) {
+  // output rows are split over gridDim.z workgroups (each recomputes the small softmax block above)
+  const int o_per = (c + gridDim.z - 1) / gridDim.z;
+  const int o_beg = blockIdx.z * o_per, o_end = min(c, o_beg + o_per);
+  for (int idx = o_beg * ch + threadIdx.x; idx < o_end * ch; idx += 256) {
     const int o = idx / ch, j = idx - o * ch;
     const float* wrow = Wp + (long)o * c + h * ch;
     float acc = 0.f;
@@ -133,7 +136,7 @@ extern "C" int mmsa_chanattn_build(const float* G, const double* sq, long sq_str
   const int ch = c / heads;
   const size_t smem = (size_t)ch * (ch + 1) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 64 * 1024, "chanattn_build: head block too large");
-  hipLaunchKernelGGL(chanattn_build_kernel, dim3(heads, B), dim3(256), smem, stream, G, sq, sq_strideB, sk, sk_strideB, temp, Wp, planes, c, cpad, heads);
+  hipLaunchKernelGGL(chanattn_build_kernel, dim3(heads, B, c >= 192 ? 16 : 4), dim3(256), smem, stream, G, sq, sq_strideB, sk, sk_strideB, temp, Wp, planes, c, cpad, heads);
   MMSA_CHECK_LAUNCH("chanattn_build");
   return MMSA_OK;
 }

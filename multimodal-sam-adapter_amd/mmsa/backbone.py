@@ -450,9 +450,12 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # (M = 8192 rows at 1/16 resolution fills only ~1/3 of the CUs per GEMM), so they run on separate HIP
         # streams (fork/join with events; captured as parallel branches of the HIP graph) with private workspaces.
         main = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None or self._side[0].device != x.device:
-            self._side = [torch.cuda.Stream(device=x.device) for _ in range(3)]
-        side = self._side
+        if not getattr(self, "multistream", True):   # profiling aid: everything on the current stream
+            side = [main, main, main]
+        else:
+            if getattr(self, "_side", None) is None or self._side[0].device != x.device:
+                self._side = [torch.cuda.Stream(device=x.device) for _ in range(3)]
+            side = self._side
         fork = torch.cuda.Event()
         fork.record(main)
         # --- TwinConvNeXt (TC:445-476): rgb stream on the current stream, auxiliary stream on a side stream
