@@ -5,16 +5,20 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" = one forward of the drop-in backbone `SAMAdapterbimodalMixModNewInTwinConvNEW` (ViT-L SAM encoder +
-RGB+LiDAR adapter, BASELINE configs[1]: 1024x1024, batch 2 per GPU) on synthetic tensors that are already resident
-in HBM, random-init weights of that architecture.  N > 1: one process per GPU, the batch is sharded (weak scaling:
-2 images per rank), and -- when the Segformer head stage is enabled -- one RCCL all-gather of the logits per step.
+RGB+LiDAR adapter, BASELINE configs[1]: 1024x1024, batch 2 per GPU) followed by the drop-in `SegformerHead`
+(-> logits [B,25,256,256]) on synthetic tensors that are already resident in HBM, random-init weights of that
+architecture.  N > 1: one process per GPU, the batch is sharded (weak scaling: 2 images per rank, nothing shared on
+the data path) and every step ends with the pipeline's ONE exchange: an RCCL all-gather of the per-rank logits
+(SURVEY 8e).  The step is the same at every N (at N=1 the gather is the identity), so per-N values are comparable.
+`--no-head` times the encoder forward alone; the default run also reports it as `encoder_only`.
 Rank 0 prints ONE JSON line; `value` is the whole-job images/s (max-over-ranks time, barrier + synchronize on both
 sides of exactly K steps).
 
 Extra objects:
-  roofline     -- the dominant kernel (gemm_split3_kernel): algorithmic FLOPs (2*M*N*K per launch, NOT counting the
-                  3x split products) / HIP-event time of those launches, measured live in a profiled pass of one
-                  step right after the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  roofline     -- the dominant kernel family (the split3 GEMM: gemm_v2_kernel / gemm_split3_kernel): algorithmic FLOPs
+                  (2*M*N*K per launch, NOT counting the 3x split products) / HIP-event time of those launches,
+                  measured live in a single-stream profiled pass of one step right after the timed region (events on
+                  the launch stream), against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline -- the CPU oracle (oracle/ref_encoder.py, a PyTorch-CPU restatement validated against the reference)
                   timed on this box's host cores on ONE 1024x1024 image (rank 0, N=1 only).
 """
@@ -46,79 +50,115 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-head", action="store_true", help="time the encoder forward only (no decode head, no all-gather)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    use_dist = world > 1 or os.environ.get("MMSA_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import mmsa
-    from tests.configs import CONFIGS, make_input
+    from mmsa.dist import allgather_logits
+    from tests.configs import CONFIGS, HEAD_CONFIGS, make_input
 
     cfg = CONFIGS[a.config]
     torch.manual_seed(1234)
     model = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
     x = make_input(cfg, batch=a.batch, seed=1234 + rank).to(dev)
 
-    def step():
-        return model(x)
+    head = None
+    if not a.no_head:
+        hkw = dict(HEAD_CONFIGS["head_vitl"]["kwargs"])
+        hkw["in_channels"] = [cfg["kwargs"]["embed_dim"]] * 4
+        head = mmsa.build_head(dict(type="SegformerHead", **hkw))
 
-    # warm-up (packs weights, sizes the workspace), then optional HIP-graph capture of the whole forward
-    for _ in range(max(a.warmup, 1)):
-        step()
-    torch.cuda.synchronize()
-    graph = None
-    if not a.no_graph:
+    def encoder_step():
+        return model(x)[0]
+
+    def local_step():                      # everything that is captured in the HIP graph
+        fs = encoder_step()
+        return head(fs) if head is not None else fs[0]
+
+    def capture(fn):
+        """warm-up (packs weights, sizes the workspace), then HIP-graph capture of the whole local step."""
+        for _ in range(max(a.warmup, 1)):
+            out = fn()
+        torch.cuda.synchronize()
+        if a.no_graph:
+            return fn, out, False
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                step()
+                fn()
             torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            graph.replay()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            g.replay()
             torch.cuda.synchronize()
+            return g.replay, out, True
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
             torch.cuda.synchronize()
+            return fn, fn(), False
 
-    run = graph.replay if graph is not None else step
-    for _ in range(a.warmup):
-        run()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(run):
+        for _ in range(a.warmup):
+            run()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    replay, local_out, graphed = capture(local_step)
+    gathered = [None]
+
+    def run():
+        replay()
+        if head is not None and use_dist:   # the pipeline's only exchange step; outside the graph (RCCL owns its stream)
+            gathered[0] = allgather_logits(local_out)
+
+    dt = timed(run)
+    graph = graphed or None
     imgs = a.batch * world * a.steps
     value = imgs / dt
+    if head is not None and use_dist and rank == 0:
+        assert gathered[0].shape[0] == world * a.batch
+
+    encoder_only = None
+    if head is not None and world == 1:
+        ereplay, _, _ = capture(encoder_step)
+        edt = timed(ereplay)
+        encoder_only = {"value": round(a.batch * a.steps / edt, 3), "unit": "images/s", "ms_per_step": round(edt / a.steps * 1e3, 3)}
 
     roofline = None
     if not a.no_roofline and rank == 0:
         prof = []
         model.multistream = False   # one stream: an event pair then brackets exactly one kernel, nothing runs beside it
-        step()
+        local_step()
         torch.cuda.synchronize()
         mmsa.ops.GEMM_PROFILE = prof
-        step()
+        local_step()
         torch.cuda.synchronize()
         mmsa.ops.GEMM_PROFILE = None
         model.multistream = True
@@ -151,13 +191,17 @@ def main():
             "dtype": "bf16x3-split MFMA (fp32 accumulate, fp32 activations)", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if a.config == "vitl1024" else f"{a.config} (not the BASELINE workload)",
+                       "stage": "encoder forward only" if head is None else
+                                "encoder forward + SegformerHead logits [B,25,H/4,W/4] + all-gather of logits across ranks",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                       "collective": "none in the encoder (images independent)"},
+                       "collective": ("one RCCL all_gather_into_tensor of the logits per step" if (head is not None and use_dist)
+                                      else "none (single rank)" if head is not None else "none (encoder only)")},
+            "encoder_only": encoder_only,
             "end_to_end_algorithmic_tflops": round(end_to_end_tflops, 1) if end_to_end_tflops else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

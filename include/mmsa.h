@@ -150,6 +150,17 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
                    const float* bn_shift, float* out, int B, int Hc, int Wc, int Hx, int Wx, int C,
                    mmsa_stream_t stream);
 
+/* --- Segformer decode head (segmentation/mmseg_custom/models/decode_heads/segformer_head.py:47-66; the 1x1 convs are
+ *     mmsa_gemm_split3 calls).  nchw_to_planes: backbone map [B,C,HW] fp32 (image b at b*strideB) -> interleaved planes
+ *     [B*HW, C].  head_fuse: planes/out32 [B*H*W, C] = act((z0 + sum_i bilinear_{align_corners=False}(z_i -> HxW)) * bn_scale
+ *     + bn_shift); z_i token-major [B*H_i*W_i, ld] fp32, NULL levels skipped.  tokens_to_nchw: [B*HW, ld] -> [B,C,HW]. --- */
+int mmsa_nchw_to_planes(const float* src, long strideB, uint16_t* planes, long ldp, int B, int C, long HW,
+                        mmsa_stream_t stream);
+int mmsa_head_fuse(const float* z0, const float* z1, int H1, int W1, const float* z2, int H2, int W2, const float* z3,
+                   int H3, int W3, long ld, const float* bn_scale, const float* bn_shift, uint16_t* planes, long ldp,
+                   float* out32, long ldo, int B, int H, int W, int C, int act, mmsa_stream_t stream);
+int mmsa_tokens_to_nchw(const float* src, long ld, float* dst, int B, long HW, int C, mmsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,10 +5,13 @@ classes under the reference's names."""
 from . import lib  # noqa: F401  (raises if the HIP library is missing)
 from . import ops  # noqa: F401
 from .backbone import SAMAdapterbimodalMixModNewInTwinConvNEW, SAMAdapterbimodalMixModNewInTwinConvNEWwithcp
-from .registry import BACKBONES, build_backbone
+from .head import SegformerHead
+from .registry import BACKBONES, HEADS, build_backbone, build_head
 
 for _cls in (SAMAdapterbimodalMixModNewInTwinConvNEW, SAMAdapterbimodalMixModNewInTwinConvNEWwithcp):
     BACKBONES.register_module(force=True)(_cls)
 
-__all__ = ["SAMAdapterbimodalMixModNewInTwinConvNEW", "SAMAdapterbimodalMixModNewInTwinConvNEWwithcp",
+HEADS.register_module(force=True)(SegformerHead)  # segformer_head.py:11 registers with force=True as well
+
+__all__ = ["SegformerHead", "HEADS", "build_head", "SAMAdapterbimodalMixModNewInTwinConvNEW", "SAMAdapterbimodalMixModNewInTwinConvNEWwithcp",
            "BACKBONES", "build_backbone", "ops", "lib"]

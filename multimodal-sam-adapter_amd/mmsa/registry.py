@@ -31,13 +31,19 @@ class _LocalRegistry:
 
 
 try:  # pragma: no cover - mmseg is not installed in the build image
-    from mmseg.models.builder import BACKBONES  # type: ignore
+    from mmseg.models.builder import BACKBONES, HEADS  # type: ignore
     HAVE_MMSEG = True
 except Exception:  # noqa: BLE001
     BACKBONES = _LocalRegistry("backbone")
+    HEADS = _LocalRegistry("head")
     HAVE_MMSEG = False
 
 
 def build_backbone(cfg):
     """Equivalent of mmseg.models.builder.build_backbone for the local registry."""
     return BACKBONES.build(cfg)
+
+
+def build_head(cfg):
+    """Equivalent of mmseg.models.builder.build_head (ED:44) for the local registry."""
+    return HEADS.build(cfg)

@@ -47,3 +47,23 @@ def weights_checksum(sd):
 def probe_index(numel, n, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, numel, (n,), generator=g)
+
+
+# decode head: CFG-L decode_head dict (configs/DELIVER/..._RGBLIDAR_hard.py:57-66); `size` = side of f1 (img/4)
+_HEAD_KW = dict(in_index=[0, 1, 2, 3], dropout_ratio=0.1, norm_cfg=dict(type="SyncBN", requires_grad=True),
+                align_corners=False, loss_decode=dict(type="OhemCrossEntropy"))
+HEAD_CONFIGS = {
+    "head_tiny": dict(kwargs=dict(_HEAD_KW, in_channels=[64, 64, 64, 64], channels=64, num_classes=7), size=56, batch=2,
+                      seed=11, in_seed=12),
+    "head_odd": dict(kwargs=dict(_HEAD_KW, in_channels=[40, 40, 40, 40], channels=48, num_classes=25), size=40, batch=1,
+                     seed=13, in_seed=14),
+    "head_vitl": dict(kwargs=dict(_HEAD_KW, in_channels=[1024, 1024, 1024, 1024], channels=512, num_classes=25), size=256,
+                      batch=1, seed=15, in_seed=16),
+}
+
+
+def make_head_inputs(cfg, batch=None, seed=None):
+    """Seeded stand-ins for the backbone maps f1..f4: [B, C_i, size/2^i, size/2^i] ~ N(0,1)."""
+    b = batch or cfg["batch"]
+    g = torch.Generator().manual_seed(cfg["in_seed"] if seed is None else seed)
+    return [torch.randn(b, c, cfg["size"] >> i, cfg["size"] >> i, generator=g) for i, c in enumerate(cfg["kwargs"]["in_channels"])]

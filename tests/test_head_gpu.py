@@ -1,0 +1,70 @@
+"""GPU parity of the on-device Segformer head (mmsa.SegformerHead, C ABI: nchw_to_planes / gemm / head_fuse /
+tokens_to_nchw) against the goldens captured from the reference's SegformerHead and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_encoder as R
+from oracle import ref_head as RH
+from tests.configs import HEAD_CONFIGS, make_head_inputs, probe_index
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(name):
+    import mmsa
+    cfg = HEAD_CONFIGS[name]
+    orc = RH.OracleSegformerHead(**cfg["kwargs"])
+    sd = R.seeded_state_dict(orc, seed=cfg["seed"])
+    orc.load_state_dict(sd)
+    head = mmsa.build_head(dict(type="SegformerHead", **cfg["kwargs"]))
+    head.load_state_dict(sd)
+    return cfg, orc, head.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["head_tiny", "head_odd"])
+def test_head_matches_reference_golden_and_oracle(name):
+    cfg, orc, head = build(name)
+    xs = make_head_inputs(cfg)
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    out = head([x.to(DEV) for x in xs])
+    assert tuple(out.shape) == tuple(gold["shape"])
+    assert_close(out, torch.from_numpy(gold["logits"]), what=f"{name} vs reference golden")
+    assert_close(out, orc(xs), what=f"{name} vs oracle")
+
+
+def test_head_other_batch_and_determinism():
+    cfg, orc, head = build("head_tiny")
+    xs = make_head_inputs(cfg, batch=3, seed=77)
+    a = head([x.to(DEV) for x in xs]).clone()
+    b = head([x.to(DEV) for x in xs]).clone()
+    assert torch.equal(a, b)
+    assert_close(a, orc(xs), what="head batch 3")
+
+
+def test_head_vitl_probes():
+    cfg, _, head = build("head_vitl")
+    gold = np.load(os.path.join(GOLD, "head_vitl.npz"))
+    out = head([x.to(DEV) for x in make_head_inputs(cfg)])
+    assert tuple(out.shape) == tuple(gold["shape"])
+    probe = out.flatten()[probe_index(out.numel(), 4096, seed=200).to(DEV)]
+    assert_close(probe, torch.from_numpy(gold["probe"]), what="head_vitl probes vs reference golden")
+    st = gold["stats"]
+    assert abs(out.double().abs().mean().item() - st[1]) <= 1e-3 * st[1]
+
+
+def test_head_rejects():
+    import mmsa
+    kw = HEAD_CONFIGS["head_tiny"]["kwargs"]
+    with pytest.raises(NotImplementedError):
+        mmsa.build_head(dict(type="SegformerHead", **dict(kw, align_corners=True)))
+    head = mmsa.build_head(dict(type="SegformerHead", **kw))
+    with pytest.raises(RuntimeError):
+        head(make_head_inputs(HEAD_CONFIGS["head_tiny"]))  # CPU tensors: no CPU path
+    with pytest.raises(NotImplementedError):
+        head.train()

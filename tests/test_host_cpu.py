@@ -144,3 +144,20 @@ def test_data_parallel_harness_gloo_world2():
     assert torch.equal(g0, g1) and g0.shape == (6, 2, 3)
     assert g0[:, 0, 0].tolist() == [0.0, 10.0, 20.0, 31.0, 41.0, 51.0]  # rank-major order
     assert s0 == s1 == 1.5
+
+
+def test_head_registry_and_state_dict_contract(golden_dir):
+    """SegformerHead drop-in: registry name, reference state_dict keys/shapes/order, loud failure without a GPU."""
+    import mmsa
+    from tests.configs import HEAD_CONFIGS, make_head_inputs
+    cfg = HEAD_CONFIGS["head_tiny"]
+    head = mmsa.build_head(dict(type="SegformerHead", **cfg["kwargs"]))
+    assert mmsa.HEADS.get("SegformerHead") is mmsa.SegformerHead
+    want = [ln.strip().split(" ", 1) for ln in open(os.path.join(golden_dir, "state_dict_keys_head.txt"))]
+    got = [(k, str(list(v.shape))) for k, v in head.state_dict().items()]
+    assert [k for k, _ in got] == [k for k, _ in want]
+    assert [s for _, s in got] == [s for _, s in want]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        head(make_head_inputs(cfg))
+    with pytest.raises(NotImplementedError):
+        mmsa.build_head(dict(type="SegformerHead", **dict(cfg["kwargs"], interpolate_mode="nearest")))

@@ -9,6 +9,7 @@ import torch
 
 from oracle import ref_encoder as R
 from tests.configs import CONFIGS, make_input, probe_index, weights_checksum
+from tests.util import assert_close
 
 
 def _load(golden_dir, name):
@@ -103,3 +104,25 @@ def test_state_dict_keys_match_reference(golden_dir):
     m = R.OracleEncoder(**CONFIGS["tiny224"]["kwargs"])
     want = [l.split(" ")[0] for l in open(os.path.join(golden_dir, "state_dict_keys_tiny.txt"))]
     assert list(m.state_dict().keys()) == want
+
+
+@pytest.mark.parametrize("name", ["head_tiny", "head_odd", "head_vitl"])
+def test_oracle_head_matches_reference_golden(name, golden_dir):
+    """oracle/ref_head.py vs the reference's SegformerHead (goldens from tools/oracle/make_golden.py:gen_head)."""
+    from oracle import ref_head as RH
+    from tests.configs import HEAD_CONFIGS, make_head_inputs
+    cfg = HEAD_CONFIGS[name]
+    orc = RH.OracleSegformerHead(**cfg["kwargs"])
+    sd = R.seeded_state_dict(orc, seed=cfg["seed"])
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    assert abs(weights_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point}) - float(gold["weights_checksum"])) < 1e-6 * float(gold["weights_checksum"])
+    orc.load_state_dict(sd)
+    y = orc(make_head_inputs(cfg))
+    assert tuple(y.shape) == tuple(gold["shape"])
+    if "logits" in gold:
+        assert_close(y, torch.from_numpy(gold["logits"]), tol=1e-5, what=f"oracle {name}")
+    probe = y.flatten()[probe_index(y.numel(), 4096, seed=200)]
+    assert_close(probe, torch.from_numpy(gold["probe"]), tol=1e-5, what=f"oracle {name} probes")
+    keys = [ln.split(" ")[0] for ln in open(os.path.join(golden_dir, "state_dict_keys_head.txt"))]
+    if name == "head_tiny":
+        assert list(orc.state_dict().keys()) == keys

@@ -22,7 +22,7 @@ warnings.filterwarnings("ignore")
 
 import ref_import  # noqa: E402
 from oracle import ref_encoder as R  # noqa: E402
-from tests.configs import CONFIGS, make_input, weights_checksum, probe_index  # noqa: E402
+from tests.configs import CONFIGS, HEAD_CONFIGS, make_head_inputs, make_input, weights_checksum, probe_index  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -110,6 +110,28 @@ def gen_model(name, full):
     print(name, [tuple(f.shape) for f in fs], flush=True)
 
 
+def gen_head(name, full):
+    """Reference SegformerHead (imported unmodified; see ref_import.build_reference_head) on seeded weights + inputs."""
+    cfg = HEAD_CONFIGS[name]
+    ref = ref_import.build_reference_head(**cfg["kwargs"])
+    sd = R.seeded_state_dict(ref, seed=cfg["seed"])
+    ref.load_state_dict(sd)
+    xs = make_head_inputs(cfg)
+    with torch.no_grad():
+        y = ref(xs).contiguous()
+    out = dict(weights_checksum=np.float64(weights_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})),
+               shape=np.array(y.shape),
+               stats=np.array([y.double().mean().item(), y.double().abs().mean().item(), y.abs().max().item()]),
+               probe=y.flatten()[probe_index(y.numel(), 4096, seed=200)].numpy())
+    if full:
+        out["logits"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    with open(os.path.join(OUT, "state_dict_keys_head.txt"), "w") as fh:
+        for k, v in ref.state_dict().items():
+            fh.write(f"{k} {list(v.shape)}\n")
+    print(name, tuple(y.shape), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also ViT-B@512 and ViT-L@1024 (minutes, GBs of RAM)")
@@ -120,6 +142,9 @@ def main():
     gen_bookkeeping()
     for n in ("tiny224", "tiny256", "tiny320"):
         gen_model(n, full=True)
+    gen_head("head_vitl", full=False)
+    gen_head("head_odd", full=True)
+    gen_head("head_tiny", full=True)
     if a.big:
         gen_model("vitb512", full=False)
         gen_model("vitl1024", full=False)

@@ -220,3 +220,59 @@ def build_reference(**cfg):
         model = cls(**cfg)
     model.eval()
     return model
+
+
+def build_reference_head(**cfg):
+    """Construct the reference's `SegformerHead` (decode_heads/segformer_head.py:11-66, imported UNMODIFIED).
+
+    Its base class `mmseg.models.decode_heads.decode_head.BaseDecodeHead` (mmsegmentation==0.20.2, README.md:98-111)
+    is not vendored and not installed, so the harness supplies the ~30 lines of it that the inference path touches
+    (constructor attributes, `_transform_inputs('multiple_select')`, `cls_seg` = Dropout2d + 1x1 `conv_seg`), restated
+    from the published 0.20.2 behaviour.  `mmcv.cnn.ConvModule` is served by the reference's own vendored
+    `mmcv_custom.cnn.ConvModule`; `mmseg.ops.resize` is the `F.interpolate` wrapper it is upstream."""
+    import contextlib
+    import io
+    import torch.nn as nn
+    import torch.nn.functional as F
+    install()
+
+    class BaseDecodeHead(nn.Module):
+        def __init__(self, in_channels, channels, *, num_classes, dropout_ratio=0.1, conv_cfg=None, norm_cfg=None,
+                     act_cfg=dict(type="ReLU"), in_index=-1, input_transform=None, loss_decode=None, ignore_index=255,
+                     sampler=None, align_corners=False, init_cfg=None):
+            super().__init__()
+            assert input_transform == "multiple_select" and len(in_channels) == len(in_index)
+            self.input_transform, self.in_index, self.in_channels = input_transform, in_index, in_channels
+            self.channels, self.num_classes, self.dropout_ratio = channels, num_classes, dropout_ratio
+            self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
+            self.ignore_index, self.align_corners = ignore_index, align_corners
+            self.conv_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
+            self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+
+        def _transform_inputs(self, inputs):
+            return [inputs[i] for i in self.in_index]
+
+        def cls_seg(self, feat):
+            if self.dropout is not None:
+                feat = self.dropout(feat)
+            return self.conv_seg(feat)
+
+    def resize(input, size=None, scale_factor=None, mode="nearest", align_corners=None, warning=True):
+        return F.interpolate(input, size, scale_factor, mode, align_corners)
+
+    import mmseg.models.decode_heads.decode_head as dh  # mock module
+    dh.BaseDecodeHead = BaseDecodeHead
+    import mmseg.ops as mo
+    mo.resize = resize
+    from mmcv_custom.cnn import ConvModule  # the reference's vendored copy
+    import mmcv.cnn as mc
+    mc.ConvModule = ConvModule
+    if "mmseg_custom.models.decode_heads" not in sys.modules:
+        m = types.ModuleType("mmseg_custom.models.decode_heads")
+        m.__path__ = [os.path.join(SEG, "mmseg_custom/models/decode_heads")]
+        sys.modules["mmseg_custom.models.decode_heads"] = m
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod = importlib.import_module("mmseg_custom.models.decode_heads.segformer_head")
+        head = mod.SegformerHead(**cfg)
+    head.eval()
+    return head
