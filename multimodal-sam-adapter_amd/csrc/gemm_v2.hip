@@ -125,12 +125,11 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   const int fa = (wm * 64) * 128;                    // activation rows of this wave, + mi*2048
   const int fw = V2_A_BYTES + (wn * 64) * 128;       // weight rows of this wave, + ni*2048
 
-  // ---- prefetch cursor (runs 2 iterations ahead of the compute cursor)
+  // ---- DMA cursor (runs 3 iterations ahead of the compute cursor; ring slot of iteration i is i % 3)
   int pf_tile = rb, pf_kt = 0, pf_st = 0, pf_j = 0;
   SET_TILE_SRC(pf_tile);
-#define PREFETCH_NEXT()                                     \
+#define ADVANCE_PF()                                        \
   do {                                                      \
-    ISSUE_DMA(pf_kt, pf_st);                                \
     pf_st = pf_st == 2 ? 0 : pf_st + 1;                     \
     ++pf_j;                                                 \
     if (++pf_kt == nk) {                                    \
@@ -139,213 +138,40 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       if (pf_j < total) SET_TILE_SRC(pf_tile);              \
     }                                                       \
   } while (0)
-  PREFETCH_NEXT();
-  if (total > 1) PREFETCH_NEXT();
+#pragma unroll 1
+  for (int i = 0; i < 3 && i < total; ++i) {
+    ISSUE_DMA(pf_kt, pf_st);
+    ADVANCE_PF();
+  }
 
-  int st = 0, kt = 0, tile = rb, nowait = 0;
-  for (int j = 0; j < total; ++j) {
-    // the DMAs of iteration j must have landed; those of j+1 (6 instructions, issued later) may stay in flight.
-    // vmcnt retires in order and counts stores too, so a wait issued after an epilogue would also wait for that
-    // epilogue's whole store burst; instead the epilogue first drains the (older) DMAs of j+1 and j+2 and the next
-    // two iterations skip the wait, which gives the stores ~3 k-tiles of MFMA work to retire behind.
-    if (nowait > 0) --nowait;
-    else if (j + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  // ---- fragments are DOUBLE-BUFFERED IN REGISTERS: while the 48 MFMAs of iteration j run on set j&1, the 16
+  // ds_read_b128 of iteration j+1 (ring slot (j+1)%3, landed before this iteration's barrier) fill the other set,
+  // four reads in front of each 12-MFMA chunk.  Reading a k-tile's fragments right after the barrier that publishes
+  // it (previous version) parked all 8 waves on the same ~1000-cycle LDS burst (128 ds_read_b128 per k-tile per CU
+  // at 8 cycles each) with an idle matrix pipe; now the matrix pipe starts on registers the moment the barrier opens.
+  bf16x8 ah[2][4], al[2][4], wh[2][4], wl[2][4];
+#define READ_FRAGS(set, base_, i)                                                          \
+  ah[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fa + (i) * 2048 + frag_hi);       \
+  al[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fa + (i) * 2048 + frag_lo);       \
+  wh[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fw + (i) * 2048 + frag_hi);       \
+  wl[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fw + (i) * 2048 + frag_lo);
+  {
+    // iteration 0's fragments: its 6 DMA instructions are the oldest of the (up to) 18 in flight
+    if (total >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (total == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // The 6 DMA instructions of iteration j+2 (ring slot (j+2)%3, last read in iteration j-1: free after the
-    // barrier) are issued BETWEEN the MFMA chunks, two per chunk: an LDS-DMA costs ~100 issue cycles (M0 write,
-    // address arithmetic, the instruction) which disappear under the 16-cycle passes of the MFMAs already queued
-    // on the matrix pipe; issued in a block right after the barrier they sat on the critical path of both waves of
-    // every SIMD (measured: ~3000 cycles per k-tile for 1536 cycles of MFMA work).
-    const bool do_pf = pf_j < total;
-    unsigned char* pfb = smem + pf_st * V2_STAGE;
-    const int pko = a.debug == 3 ? 0 : pf_kt * 64;
-    const unsigned char* base = smem + st * V2_STAGE;
-    // all 16 fragment reads up front (spreading the weight-fragment reads over the chunks measured slower)
-    bf16x8 ah[4], al[4], wh[4], wl[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);
-      al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);
-    }
-#define READ_W(i)                                                                        \
-  wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + (i) * 2048 + frag_hi);             \
-  wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + (i) * 2048 + frag_lo);
-    READ_W(0) READ_W(1) READ_W(2) READ_W(3)
-#define MFMA_CHUNK(ni)                                                                                      \
-  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                        \
-    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
-    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);            \
-    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
+    READ_FRAGS(0, smem, 0) READ_FRAGS(0, smem, 1) READ_FRAGS(0, smem, 2) READ_FRAGS(0, smem, 3)
   }
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_CHUNK(0)
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_pf) { GLDS16(sa0 + pko, pfb + lds_a); GLDS16(sa1 + pko, pfb + lds_a + 1024); }
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_CHUNK(1)
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_pf) { GLDS16(sa2 + pko, pfb + lds_a + 2048); GLDS16(sa3 + pko, pfb + lds_a + 3072); }
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_CHUNK(2)
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_pf) { GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w); GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024); }
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_CHUNK(3)
-#undef MFMA_CHUNK
-#undef READ_W
-    if (do_pf) {   // advance the prefetch cursor (source pointers of the next output tile when the k loop wraps)
-      pf_st = pf_st == 2 ? 0 : pf_st + 1;
-      ++pf_j;
-      if (++pf_kt == nk) {
-        pf_kt = 0;
-        pf_tile += G;
-        if (pf_j < total) SET_TILE_SRC(pf_tile);
-      }
-    }
-    const int st_cur = st;
-    st = st == 2 ? 0 : st + 1;
-    if (++kt < nk) continue;
-    kt = 0;
 
-    if (a.debug == 2) { tile += G; continue; }
-    // ---- epilogue of `tile`.  MFMA layout: lane holds C[m = ..+l15][n = ..+4g .. +3].  The column-wise part
-    // (bias, activation, alpha, gamma) is applied in registers; each wave then transposes 16 x 64 sub-tiles through
-    // the ring slot it has just finished computing from (free until the DMA of iteration j+3), so that residual
-    // loads and output stores are FULL 256-byte row segments (4 rows per wave-instruction) instead of 64-byte
-    // (fp32) / 32-byte (planes) fragments.
-    {
-      const int per_b = a.nbm * a.nbn;
-      const int bz = tile / per_b;
-      const int rt = tile - bz * per_b;
-      const int m0 = (rt / a.nbn) * V2_BM, n0 = (rt % a.nbn) * V2_BN;
-      const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
-      const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
-      float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
-      unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
-      const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of iterations j+1, j+2 (older than the stores below)
-      __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; j+1, j+2 landed for all
-      nowait = 2;
-      float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
-      const int nb_ = n0 + wn * 64;
-      // column parameters of this lane's 4x4 columns (n = nb_ + ni*16 + 4g + r): loaded ONCE per tile, unconditionally
-      // (clamped index), so the element loop below has no loads, no waits and no divergent branches.
-      float bv[4][4], cv[4][4];
-      if (bias) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bv[ni][r] = bias[min(nb_ + ni * 16 + 4 * g + r, a.N - 1)];
-      } else {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bv[ni][r] = 0.f;
-      }
-      if (a.colscale) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int ci = min(nb_ + ni * 16 + 4 * g + r, a.N - 1);
-            if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-            cv[ni][r] = a.colscale[ci] * a.alpha;
-          }
-      } else {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cv[ni][r] = a.alpha;
-      }
-      // row mapping (destination row / column, residual row); identity unless GEN
-      auto map_row = [&](int m, int n, long& drow_, int& dcol, long& rrow) {
-        drow_ = m; dcol = n; rrow = m;
-        if constexpr (GEN) {
-          if (a.out_mode == 1) {
-            const int ij = n / a.ps_C;
-            dcol = n - ij * a.ps_C;
-            const int w_ = m % a.ps_W;
-            const int t_ = m / a.ps_W;
-            const int h_ = t_ % a.ps_H;
-            const int b_ = t_ / a.ps_H;
-            drow_ = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
-          }
-          rrow = a.resid_mod > 0 ? (long)((int)drow_ % a.resid_mod) : drow_;
-        }
-      };
-      const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
-      const int cl = (lane & 15) * 4;
-      const int n = nb_ + cl;
-      const bool fast = vec_ok && (nb_ + 64 <= a.N);   // wave-uniform: whole 64-column strip inside N, 16-byte aligned
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 16;
-        // residual rows first: 4 independent 16-byte loads in flight, no waits inside the element loops
-        float4 rr[4];
-        if (fast && resid) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            long drow_, rrow; int dcol;
-            map_row(min(mb + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
-            rr[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
-          }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-          acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r] + bv[ni][r], a.act) * cv[ni][r];
-          *reinterpret_cast<float4*>(stg + l15 * 68 + ni * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        if (a.debug == 1) continue;
-        if (fast) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int rl = rl0 + 4 * i;
-            float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
-            const int m = mb + rl;
-            if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
-            if (m < a.M) {
-              long drow_, rrow; int dcol;
-              map_row(m, n, drow_, dcol, rrow);
-              if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
-              if (Cp) {
-                uint2 hh, ll;
-                split4(o, hh, ll);
-                unsigned short* cp_ = Cp + drow_ * a.ldcp + ilv(dcol);
-                *reinterpret_cast<uint2*>(cp_) = hh;
-                *reinterpret_cast<uint2*>(cp_ + 32) = ll;
-              }
-            }
-          }
-        } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare
-          for (int i = 0; i < 4; ++i) {
-            const int rl = rl0 + 4 * i;
-            const float4 o4 = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
-            const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
-            const int m = mb + rl;
-            if (m >= a.M) continue;
-            for (int r = 0; r < 4; ++r) {
-              if (n + r >= a.N) continue;
-              long drow_, rrow; int dcol;
-              map_row(m, n + r, drow_, dcol, rrow);
-              float x = ov[r];
-              if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
-              if (C) C[drow_ * a.ldc + dcol] = x;
-              if (Cp) {
-                unsigned short hh, ll;
-                split_bf16(x, hh, ll);
-                Cp[drow_ * a.ldcp + ilv(dcol)] = hh;
-                Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
-              }
-            }
-          }
-        }
-      }
-    }
-    tile += G;
+  int st = 0, kt = 0, tile = rb, nowait = 0;
+  for (int j0 = 0; j0 < total; j0 += 2) {
+#define P 0
+#include "gemm_v2_step.inc"
+#undef P
+#define P 1
+#include "gemm_v2_step.inc"
+#undef P
   }
 }
 

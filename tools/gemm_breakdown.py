@@ -8,12 +8,13 @@ from tests.configs import CONFIGS, make_input
 cfg = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "vitl1024"]
 m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
 x = make_input(cfg, batch=2).cuda()
+m.multistream = False
 m(x); torch.cuda.synchronize()
 ops = mmsa.ops
 shapes = []
 orig = ops.gemm
 def rec(a, w, *args, **kw):
-    mm = kw.get("m") or (a.hi.shape[0] if isinstance(a, ops.Planes) else a.shape[0])
+    mm = kw.get("m") or (a.p.shape[0] if isinstance(a, ops.Planes) else a.shape[0])
     shapes.append((mm, w.n, w.kpad, kw.get("batch", 1), isinstance(a, ops.Planes), kw.get("out_planes") is not None, kw.get("act", "none")))
     return orig(a, w, *args, **kw)
 prof = []
@@ -21,6 +22,7 @@ ops.GEMM_PROFILE = prof
 ops.gemm = rec
 import mmsa.backbone as bb
 bb.ops.gemm = rec
+m.multistream = False
 m(x); torch.cuda.synchronize()
 ops.GEMM_PROFILE = None
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
