@@ -150,6 +150,16 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
                    const float* bn_shift, float* out, int B, int Hc, int Wc, int Hx, int Wx, int C,
                    mmsa_stream_t stream);
 
+/* --- windowed attention with the rel-pos bias fused (Block.forward IE:382-423 on a window_size > 0 block: window_partition ->
+ *     Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 -> window_unpartition).  qkv / bias / out as in
+ *     mmsa_attention_planes; relpos_planes = interleaved planes of a [64, 64] matrix whose rows 0..2ws-2 are the block's
+ *     rel_pos_h table (already resized to 2ws-1 rows, IE:568-575) and rows 32..32+2ws-2 its rel_pos_w.  selector =
+ *     [208, 32] bf16 (row-major, 128-byte aligned): selector[j][j / ws] = selector[j][14 + j % ws] = 1.0 for j < ws*ws,
+ *     0 elsewhere (a constant of the window size).  head_dim 64, window_size <= 14.  No mmsa_relpos_bias pass. --- */
+int mmsa_window_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes,
+                                 const uint16_t* relpos_planes, const uint16_t* selector, uint16_t* out_planes, long ldo, int B, int H, int W,
+                                 int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
+
 /* --- Segformer decode head (segmentation/mmseg_custom/models/decode_heads/segformer_head.py:47-66; the 1x1 convs are
  *     mmsa_gemm_split3 calls).  nchw_to_planes: backbone map [B,C,HW] fp32 (image b at b*strideB) -> interleaved planes
  *     [B*HW, C].  head_fuse: planes/out32 [B*H*W, C] = act((z0 + sum_i bilinear_{align_corners=False}(z_i -> HxW)) * bn_scale

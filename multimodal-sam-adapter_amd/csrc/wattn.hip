@@ -1,0 +1,342 @@
+// Windowed SAM attention (window_size <= 14, head_dim 64) with the decomposed relative-position bias FUSED, gfx950.
+//
+// Reference: Block.forward IE:382-423 (window_partition -> Attention -> window_unpartition), Attention.forward
+// IE:465-501, add_decomposed_rel_pos IE:587-623, get_rel_pos IE:554-584.  Same math as attention.hip (which stays the
+// kernel for global blocks, head_dim 32 and fp32 inputs); this one is shaped for the 20 windowed blocks of ViT-L:
+//
+//   * ONE workgroup per (window, head, image): 13 waves, wave w owns the 16 queries 16w .. 16w+15 of the 196 (<= 208).
+//   * The window's whole K and V (all <= 196 keys, hi/lo planes) are brought into LDS ONCE by LDS-DMA straight from the
+//     interleaved qkv planes -- a (token, 32 channels) unit is one 128-byte line in HBM and one 128-byte row in LDS
+//     (the GEMM's LDS image and swizzle for K; V row-major with a 32-byte-unit swizzle for the transposed reads).
+//     Window partition, the 64->70 padding and the un-partition are index arithmetic on the DMA source / output rows;
+//     pad tokens read the qkv BIAS row (their k and v, IE:401-407,519-520) and are attended to like in the reference.
+//   * One barrier.  After it every wave runs alone: S^T = K Q^T for all 13 key tiles (scores stay in 52 registers, so
+//     the softmax is the exact two-pass form, no online rescaling), then O^T = V^T P^T.
+//   * The rel-pos terms are no longer a separate pass: T[i][q] = rel_pos[i] . q for the 2*ws-1 relative offsets of each
+//     axis is 4 more MFMA tiles per wave (unscaled q, split3 like everything else), re-indexed per query by key
+//     coordinate (the integer gather of get_rel_pos, bit-exact) into a 32-entry row Bq[q] = [by kh | by kw]; the bias
+//     then enters the score accumulators as one extra MFMA k-step per key tile against a constant 0/1 selector
+//     sel[j] = onehot(kh(j)) | onehot(14 + kw(j)) -- the first version gathered two table entries per score element
+//     with ~15 VALU instructions each and was VALU-bound (1500 VALU vs 186 MFMA per wave).
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#define LDS_AS __attribute__((address_space(3)))
+#define GLDS16(gptr, lptr)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+#define WA_WAVES 13
+#define WA_NKEY 208                      // key rows of the K image (13 tiles of 16)
+#define WA_NKV 224                       // key rows of the V image (7 MFMA k-groups of 32)
+#define WA_K_BYTES (2 * WA_NKEY * 128)   // [ks][key] rows of 128 B (4 hi chunks | 4 lo chunks of 32 channels)
+#define WA_V_BYTES (WA_NKV * 128)        // per plane: [key] rows of 64 channels
+#define WA_E_BYTES (WA_NKEY * 64)        // key -> (kh, 14 + kw) selector rows, 32 bf16 each
+#define WA_B_BYTES (16 * 128)            // per wave: 16 queries x 32 floats (bias by kh | by kw)
+#define WA_LDS (WA_K_BYTES + 2 * WA_V_BYTES + WA_E_BYTES + WA_WAVES * WA_B_BYTES)
+
+struct WAttnArgs {
+  const unsigned short* qp; long ldq;   // qkv planes [B*T, >= 2*3D]
+  const unsigned short* bp;             // qkv bias planes [2*3D]
+  const unsigned short* relp;           // rel-pos planes [64 rows, 2*64]: rows 0..2ws-2 = rel_pos_h, 32..32+2ws-2 = rel_pos_w
+  const unsigned short* sel;            // [208, 32] bf16 selector: sel[j][kh(j)] = sel[j][14 + kw(j)] = 1 for j < ws*ws, else 0
+  unsigned short* op; long ldo;         // output planes [B*T, >= 2*D]
+  int B, H, W, heads, D, ws, nWw;
+  int debug;                            // MMSA_WATTN_DEBUG timing ablations: 1 = stop after the barrier, 2 = no K/V DMA
+  unsigned magic;                       // ceil(65536 / ws): j / ws == (j * magic) >> 16 for j < 224 (checked on the host)
+  float scale;
+};
+
+__global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vhi = smem + WA_K_BYTES;
+  unsigned char* Vlo = Vhi + WA_V_BYTES;
+  unsigned char* Es = Vlo + WA_V_BYTES;
+  if (a.debug == 3) return;   // launch cost only
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Bw = reinterpret_cast<float*>(Es + WA_E_BYTES + wave * WA_B_BYTES);
+  const int l15 = lane & 15, G = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int wi = blockIdx.x / a.nWw, wj = blockIdx.x - wi * a.nWw;
+  const int T = a.H * a.W, ws = a.ws, Nk = ws * ws;
+  const unsigned short* pq_b = a.qp + (long)b * T * a.ldq;
+  const int colq = head * 64, colk = a.D + head * 64, colv = 2 * a.D + head * 64;
+
+  // window-local index j -> token, -1 for a zero-pad token (inside the window, outside the image), -2 beyond the window
+  auto token_of = [&](int j) -> int {
+    if (j >= Nk) return -2;
+    const int r = (int)(__umul24(j, a.magic) >> 16), c = j - __umul24(r, ws);
+    const int hh = wi * ws + r, ww = wj * ws + c;
+    return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
+  };
+  // source row of a key: the token's qkv planes, or the bias planes for pad / non-existent keys (finite values; the
+  // scores of non-existent keys are masked to -inf below)
+  auto key_row = [&](int j) -> const unsigned short* {
+    const int t = token_of(j);
+    return t >= 0 ? pq_b + (long)t * a.ldq : a.bp;
+  };
+
+  // ---- this wave's 16 queries: Q fragments (B operand: B[k = 8G + j][col = query l15]), straight from HBM/L2
+  const int jq = 16 * wave + l15;
+  const int tq = token_of(jq);
+  bf16x8 qh[2], ql[2];
+  {
+    const unsigned short* qrow = pq_b + (long)(tq >= 0 ? tq : 0) * a.ldq;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned short* qq = qrow + 2 * (colq + 32 * ks) + 8 * G;
+      qh[ks] = *reinterpret_cast<const bf16x8*>(qq);
+      ql[ks] = *reinterpret_cast<const bf16x8*>(qq + 32);
+    }
+  }
+  // ---- rel-pos table fragments (A operand: A[row = i][k = 8G + j]) straight from the packed planes (16 KiB, L2-resident)
+  bf16x8 rh[4][2], rl[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned short* rr = a.relp + (16 * t + l15) * 128 + 64 * ks + 8 * G;
+      rh[t][ks] = *reinterpret_cast<const bf16x8*>(rr);
+      rl[t][ks] = *reinterpret_cast<const bf16x8*>(rr + 32);
+    }
+  if (a.debug == 4) return;   // + address setup, Q / table loads issued
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- K, V, selector -> LDS by LDS-DMA (one wave-instruction = 1 KiB).  Wave w brings in "its" 16 keys 16w..16w+15:
+  //      4 instructions for K (2 k-steps x 2 groups of 8 rows), 4 for V (hi/lo x 2 groups), 1 for the selector tile;
+  //      wave 12 also fills the 16 V rows beyond the last tile (bias rows: finite, their probabilities are zero).
+  if (a.debug != 2) {
+    const int dr = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int key = 16 * wave + 8 * half + dr;
+      const unsigned short* row = key_row(key);
+      const int piece = slot ^ ((key & 15) >> 1);                 // GEMM LDS image: slot = piece ^ ((row >> 1) & 7)
+      const int c = slot ^ (((key >> 1) & 3) << 1);               // V: 16-B chunk held by this LDS slot (32-B unit swizzle)
+      const unsigned short* vsrc = row + 2 * (colv + 32 * (c >> 2)) + (c & 3) * 8;
+      GLDS16(row + 2 * colk + piece * 8, Ks + (16 * wave + 8 * half) * 128);
+      GLDS16(row + 2 * (colk + 32) + piece * 8, Ks + (WA_NKEY + 16 * wave + 8 * half) * 128);
+      GLDS16(vsrc, Vhi + (16 * wave + 8 * half) * 128);
+      GLDS16(vsrc + 32, Vlo + (16 * wave + 8 * half) * 128);
+    }
+    {   // selector tile of this wave's keys: 16 rows x 64 B; LDS chunk = chunk ^ ((row >> 2) & 3)
+      const int row = lane >> 2, ch = (lane & 3) ^ ((row >> 2) & 3);
+      GLDS16(a.sel + (16 * wave + row) * 32 + ch * 8, Es + 16 * wave * 64);
+    }
+    if (wave == WA_WAVES - 1) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int key = WA_NKEY + 8 * half + dr;
+        const int c = slot ^ (((key >> 1) & 3) << 1);
+        const unsigned short* vsrc = a.bp + 2 * (colv + 32 * (c >> 2)) + (c & 3) * 8;
+        GLDS16(vsrc, Vhi + (WA_NKEY + 8 * half) * 128);
+        GLDS16(vsrc + 32, Vlo + (WA_NKEY + 8 * half) * 128);
+      }
+    }
+  }
+
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- rel-pos terms of the wave's queries: T[i][q] = rel_pos[i] . q (unscaled q), 4 MFMA tiles (2 per axis).  The Q and
+  //      table loads were issued BEFORE the DMA instructions and vmcnt retires in order, so the wait in front of these
+  //      MFMAs is a counted one that leaves the DMA in flight (hipcc counts the 9 / 13 younger DMA instructions itself;
+  //      check the .s for "s_waitcnt vmcnt(9)" when touching this): the MFMAs and the table build below run in the
+  //      shadow of the K/V transfer.
+  f32x4 tt[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    tt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl[t][ks], qh[ks], tt[t], 0, 0, 0);
+      tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[t][ks], ql[ks], tt[t], 0, 0, 0);
+      tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[t][ks], qh[ks], tt[t], 0, 0, 0);
+    }
+  }
+
+  // ---- bias operand of this wave's queries, in the shadow of the DMA flight.  The MFMA left T[i = 16t + 4G + r][q = l15]
+  //      in this lane; re-indexed by KEY coordinate (get_rel_pos's gather, IE:579-584: i = (q - k) + (ws - 1)) it goes
+  //      to the wave's table  Bq[q][kh] = T_h[q][qh - kh + ws-1] / scale,  Bq[q][14 + kw] = T_w[q][qw - kw + ws-1] / scale
+  //      (zero elsewhere); the score accumulators then get the bias through ONE extra MFMA k-step per key tile,
+  //      bias^T[j][q] = sum_i sel[j][i] Bq[q][i]  (sel = 0/1 selector, exact in bf16), instead of 2 LDS gathers and ~15
+  //      VALU instructions per score element.
+  bf16x8 bqh, bql;
+  {
+    const float rscale = 1.0f / a.scale;
+    const int jqc = jq < Nk ? jq : 0;
+    const int qr = (int)(__umul24(jqc, a.magic) >> 16), qc = jqc - __umul24(qr, ws);
+    *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * (t & 1) + 4 * G + r;
+        const int kc = ((t >> 1) ? qc : qr) + (ws - 1) - i;          // key coordinate served by table entry i
+        if (kc >= 0 && kc < ws) Bw[l15 * 32 + (t >> 1) * 14 + kc] = tt[t][r] * rscale;
+      }
+    // B operand of the extra k-step: B[k = 8G + j][col = query l15] = Bq[l15][8G + j]
+    const float4 b0 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G);
+    const float4 b1 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G + 4);
+    uint4 hh, ll;
+    split2(b0.x, b0.y, hh.x, ll.x);
+    split2(b0.z, b0.w, hh.y, ll.y);
+    split2(b1.x, b1.y, hh.z, ll.z);
+    split2(b1.z, b1.w, hh.w, ll.w);
+    bqh = __builtin_bit_cast(bf16x8, hh);
+    bql = __builtin_bit_cast(bf16x8, ll);
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA instructions have landed
+  __syncthreads();                                    // ... and everyone else's
+
+  if (a.debug == 1) return;
+  const bool live = tq >= 0;   // pad / non-existent queries are computed by the reference too, but cropped away (IE:547-550)
+  if (!__builtin_amdgcn_readfirstlane(__any(live) ? 1 : 0)) return;
+
+  // ---- S^T = sel Bq^T + K Q^T: 13 key tiles x (1 + 2) k-steps; lane holds keys 16t + 4G + r (r = reg) of query column l15
+  f32x4 s[13];
+  const int fslot = G ^ ((l15 >> 1) & 7);
+  const int frag_hi = l15 * 128 + fslot * 16, frag_lo = l15 * 128 + (fslot ^ 4) * 16;
+  const int frag_e = l15 * 64 + ((G ^ ((l15 >> 2) & 3)) << 4);
+#pragma unroll
+  for (int t = 0; t < 13; ++t) {
+    const bf16x8 e_ = *reinterpret_cast<const bf16x8*>(Es + 16 * t * 64 + frag_e);
+    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bql, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bqh, s[t], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned char* kb = Ks + (ks * WA_NKEY + 16 * t) * 128;
+      const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(kb + frag_hi);
+      const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(kb + frag_lo);
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], s[t], 0, 0, 0);
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], s[t], 0, 0, 0);
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], s[t], 0, 0, 0);
+    }
+  }
+
+  // ---- exact softmax over the Nk keys of the window (log2 domain); key slots beyond the window are masked
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sc2 = a.scale * LOG2E;
+  float mxs;
+  {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+      s[t] *= sc2;
+      if (16 * t + 16 > Nk) {   // wave-uniform: only the tile(s) straddling the end of the window
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * G + r) < Nk ? s[t][r] : -INFINITY;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mxs = mx;
+  }
+
+  // ---- O^T = V^T P^T over 7 groups of 32 keys.  MFMA k-slot (G, j): j < 4 -> key 32g + 4G + j (tile 2g),
+  //      j >= 4 -> key 32g + 16 + 4G + (j - 4) (tile 2g+1); the transposed V reads use the same key order.
+  f32x4 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float psum = 0.f;
+#pragma unroll
+  for (int g = 0; g < 7; ++g) {
+    // exponentials of this group's two key tiles right in front of the MFMAs that consume them: the VALU work of group
+    // g+1 can issue under the matrix-pipe time of group g (unnormalised; the row sum divides the output)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (2 * g + hf < 13) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
+          s[2 * g + hf][r] = p;
+          psum += p;
+        }
+      }
+    }
+    uint4 hh, ll;
+    split2(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
+    split2(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
+    if (2 * g + 1 < 13) {
+      split2(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
+      split2(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
+    } else {
+      hh.z = hh.w = ll.z = ll.w = 0u;   // keys 208..223 do not exist
+    }
+    const bf16x8 ph = __builtin_bit_cast(bf16x8, hh), pl = __builtin_bit_cast(bf16x8, ll);
+    const int row0 = 32 * g + 4 * G + (l15 >> 2);           // lane 4q'+p of a 16-lane group: key row q', columns 4p..4p+3
+    const int sw = (row0 >> 1) & 3;                          // same for row0 + 16
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int voff = row0 * 128 + ((d ^ sw) << 5) + 8 * (l15 & 3);
+      const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
+      const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + 16 * 128));
+      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
+      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + 16 * 128));
+      const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d], 0, 0, 0);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d], 0, 0, 0);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d], 0, 0, 0);
+    }
+  }
+
+  psum += __shfl_xor(psum, 16, 64);
+  psum += __shfl_xor(psum, 32, 64);
+  const float inv = 1.0f / psum;
+  // ---- O[q][16d + 4G .. +3] / sum -> out planes row token(q), columns head*64 + ...  (window_unpartition + crop: IE:534-551)
+  if (live) {
+    unsigned short* orow = a.op + ((long)b * T + tq) * a.ldo;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      uint2 hh, ll;
+      split4(make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), hh, ll);
+      unsigned short* q_ = orow + ilv(head * 64 + 16 * d + 4 * G);
+      *reinterpret_cast<uint2*>(q_) = hh;
+      *reinterpret_cast<uint2*>(q_ + 32) = ll;
+    }
+  }
+}
+
+extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, long ldq, const unsigned short* bias_planes,
+                                            const unsigned short* relpos_planes, const unsigned short* selector,
+                                            unsigned short* out_planes, long ldo,
+                                            int B, int H, int W, int heads, int head_dim, int window_size, float scale,
+                                            hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
+  MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0, "window_attention: bad shape");
+  MMSA_CHECK_ARG(head_dim == 64, "window_attention: head_dim %d not supported by this kernel (64)", head_dim);
+  MMSA_CHECK_ARG(window_size >= 1 && window_size <= 14, "window_attention: window_size %d not supported (1..14)", window_size);
+  const int D = heads * head_dim;
+  MMSA_CHECK_ARG(ldq >= 6L * D && (ldq & 63) == 0 && ldo >= 2L * D && (ldo & 63) == 0, "window_attention: bad leading dimensions");
+  MMSA_CHECK_ARG(((reinterpret_cast<uintptr_t>(qkv_planes) | reinterpret_cast<uintptr_t>(bias_planes) |
+                   reinterpret_cast<uintptr_t>(relpos_planes) | reinterpret_cast<uintptr_t>(selector) | reinterpret_cast<uintptr_t>(out_planes)) & 127) == 0,
+                 "window_attention: planes must be 128-byte aligned");
+  WAttnArgs a;
+  a.qp = qkv_planes; a.ldq = ldq; a.bp = bias_planes; a.relp = relpos_planes; a.sel = selector; a.op = out_planes; a.ldo = ldo;
+  a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
+  a.nWw = cdiv(W, window_size);
+  static const int dbg = getenv("MMSA_WATTN_DEBUG") ? atoi(getenv("MMSA_WATTN_DEBUG")) : 0;
+  a.debug = dbg;
+  a.magic = (unsigned)((65536 + window_size - 1) / window_size);
+  for (int j = 0; j < WA_NKV; ++j)   // the kernel's multiply-shift division must be exact for every index it divides
+    if ((int)(((unsigned)j * a.magic) >> 16) != j / window_size) {
+      mmsa_set_error("window_attention: index arithmetic not exact for window_size %d", window_size);
+      return MMSA_ERR_ARG;
+    }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(H, window_size) * a.nWw, heads, B);
+  hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
+  MMSA_CHECK_LAUNCH("window_attention");
+  return MMSA_OK;
+}

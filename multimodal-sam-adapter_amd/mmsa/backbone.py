@@ -159,6 +159,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 lin2=planes(sd[b + "mlp.lin2.weight"]), lin2_b=sd[b + "mlp.lin2.bias"],
                 rph=sd[b + "attn.rel_pos_h"], rpw=sd[b + "attn.rel_pos_w"],
                 ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"]))
+        hd_ = D // cfg["num_heads"]
+        for blk in pk["blocks"]:   # windowed blocks with head_dim 64: rel-pos tables packed for the fused window kernel
+            wsz = blk["ws"]
+            if wsz and wsz <= 14 and hd_ == 64:
+                L = 2 * wsz - 1
+                th = blk["rph"] if blk["rph"].shape[0] == L else _linear_resize_rows(blk["rph"], L)
+                tw = blk["rpw"] if blk["rpw"].shape[0] == L else _linear_resize_rows(blk["rpw"], L)
+                blk["relp"] = ops.window_relpos_planes(th, tw, wsz)
         # --- TwinConvNeXt
         t = "spm.twin_conv."
         pk["twin"] = {}
@@ -387,11 +395,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         qkv = ws.planes("blk_qkv", B * T, 3 * D)
         ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
-        kk = 2 * wsz if wsz else Hp + Wp
-        rp = ws.get("blk_rp", B * heads * T, kk)
-        ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
         ao = ws.planes("blk_ao", B * T, D)
-        ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+        if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
+            ops.window_attention(qkv, bp["qkv_bp"], bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+        else:
+            kk = 2 * wsz if wsz else Hp + Wp
+            rp = ws.get("blk_rp", B * heads * T, kk)
+            ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
+            ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
         ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
         ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
         h = ws.planes("blk_h", B * T, bp["lin1"].n)

@@ -212,6 +212,44 @@ def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
     return out
 
 
+def window_relpos_planes(rel_pos_h, rel_pos_w, ws):
+    """Pack a windowed block's rel-pos tables for window_attention: [64, hd] fp32 -> Planes; rows 0..2ws-2 = rel_pos_h,
+    rows 32.. = rel_pos_w (tables must already have 2*ws-1 rows: get_rel_pos's resize, IE:568-575, is the caller's)."""
+    L = 2 * ws - 1
+    if rel_pos_h.shape[0] != L or rel_pos_w.shape[0] != L or L > 27:
+        raise RuntimeError(f"mmsa.window_relpos_planes: tables must have {L} <= 27 rows")
+    m = torch.zeros(64, rel_pos_h.shape[1], dtype=torch.float32, device=rel_pos_h.device)
+    m[:L] = rel_pos_h
+    m[32:32 + L] = rel_pos_w
+    return split_planes(m)
+
+
+_SELECTORS = {}
+
+
+def window_selector(ws, device):
+    """[208, 32] bf16 0/1 matrix of mmsa_window_attention_planes: row j selects key row j // ws and key column 14 + j % ws."""
+    key = (ws, str(device))
+    if key not in _SELECTORS:
+        sel = torch.zeros(208, 32, dtype=torch.int16)
+        j = torch.arange(min(ws * ws, 208))
+        sel[j, j // ws] = 0x3F80
+        sel[j, 14 + j % ws] = 0x3F80
+        _SELECTORS[key] = sel.to(device)
+    return _SELECTORS[key]
+
+
+def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
+    """Windowed attention with the rel-pos bias fused (planes in, planes out); head_dim 64, ws <= 14."""
+    if not 1 <= ws <= 14:
+        raise RuntimeError(f"mmsa.window_attention: window_size {ws} not supported (1..14)")
+    pq, _, _, ldq = qkv.mat("qkv")
+    po, _, _, ldo = out.mat("out")
+    lib.call("mmsa_window_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relp.p, torch.int16),
+             _chk(window_selector(ws, qkv.p.device), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, _stream())
+    return out
+
+
 def colstats(x, stride_b, b, hw, out, wrow=None):
     px, _, c, ldx = _mat(x, "x")
     lib.call("mmsa_colstats", px, ldx, stride_b, _chk(wrow), b, hw, c, _chk(out, torch.float64), _stream())

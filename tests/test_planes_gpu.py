@@ -133,3 +133,34 @@ def test_msda_and_dwconv_planes_outputs(ops):
     ops.dwconv(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), conv.weight.detach().reshape(C, 9).t().contiguous().to(DEV),
                conv.bias.detach().to(DEV), None, 2, H, W, 3, act="gelu", out_planes=p)
     assert_close(planes_to_float(p), ref, tol=5e-5, what="dwconv planes")
+
+
+@pytest.mark.parametrize("H,W,heads,ws", [(16, 16, 2, 14), (20, 20, 2, 14), (64, 64, 2, 14), (30, 22, 3, 7), (14, 14, 1, 14),
+                                          (9, 33, 2, 5)])
+def test_window_attention_fused_relpos(ops, H, W, heads, ws):
+    """K/V-resident windowed kernel (rel-pos fused, no mmsa_relpos_bias pass) vs the oracle's Attention on partitioned windows."""
+    hd, B = 64, 2
+    D = heads * hd
+    L = 2 * ws - 1
+    att = R.Attention(D, heads, (ws, ws))
+    sd = R.seeded_state_dict(att, 17)
+    sd["rel_pos_h"] = torch.randn(L, hd, generator=g(70)) * 0.3
+    sd["rel_pos_w"] = torch.randn(L, hd, generator=g(71)) * 0.3
+    sd["qkv.bias"] = torch.randn(3 * D, generator=g(72)) * 0.5
+    att.load_state_dict(sd)
+    x = torch.randn(B, H, W, D, generator=g(73))
+    with torch.no_grad():
+        xw, pad_hw = R.window_partition(x, ws)
+        ref = R.window_unpartition(att(xw), ws, pad_hw, (H, W))
+    T = H * W
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV)
+    ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
+    relp = ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws)
+    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV), kpad=3 * D)
+    ao = ops.alloc_planes(B * T, D, DEV)
+    ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
+    out = torch.empty(B * T, D, device=DEV)
+    ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
+    assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws}")
+    with pytest.raises(RuntimeError):
+        ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, 15, hd ** -0.5)
