@@ -164,8 +164,16 @@ def main():
         model.multistream = True
         flops, ms = mmsa.ops.collect_gemm_profile(prof)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, tnote = None, "not measured"
+        tfile = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")   # written by tools/pmc_traffic.sh (rocprofv3 --pmc passes)
+        if os.path.exists(tfile) and a.config == "vitl1024":
+            tj = json.load(open(tfile))
+            traffic = round(tj["traffic_bytes_per_launch"])
+            tnote = ("HBM-side bytes per launch (average over the step's GEMM launches) from profiles/r01_gemm_traffic.json: rocprofv3 "
+                     "--pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes of this workload")
         roofline = {"bound": "mfma", "kernel": "split3 GEMM (gemm_v2_kernel + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
+                    "compulsory_bytes_per_launch": round(mmsa.ops.collect_gemm_profile.bytes / max(len(prof), 1)),
                     "launches_per_step": len(prof), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
                     "kernel_ms_per_step": round(ms, 3),
                     "note": "algorithmic 2*M*N*K FLOPs; the kernel issues 3x that on MFMA (bf16 hi/lo split for fp32-level parity)"}

@@ -21,9 +21,11 @@ def _event():
 
 
 def collect_gemm_profile(prof):
-    """-> (total algorithmic FLOPs, total kernel milliseconds) of the recorded launches; frees the events."""
+    """-> (total algorithmic FLOPs, total kernel milliseconds) of the recorded launches; frees the events.
+    collect_gemm_profile.bytes = compulsory bytes of the same launches (operands read once, outputs written once)."""
     flops, ms = 0.0, 0.0
-    for f, e0, e1 in prof:
+    collect_gemm_profile.bytes = sum(p[3] for p in prof)
+    for f, e0, e1, _ in prof:
         t = ctypes.c_float()
         lib.call("mmsa_event_elapsed_ms", e0, e1, ctypes.byref(t))
         flops += f
@@ -138,7 +140,9 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
              1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
-        prof.append((2.0 * m * w.n * w.k * batch, e0, e1))
+        nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)
+        prof.append((2.0 * m * w.n * w.k * batch, e0, e1,
+                     4.0 * batch * (m * w.kpad + w.n * w.kpad + m * w.n * (nout + (1 if resid is not None else 0)))))
     return out if out is not None else out_planes
 
 

@@ -26,7 +26,7 @@ m.multistream = False
 m(x); torch.cuda.synchronize()
 ops.GEMM_PROFILE = None
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for s, (f, e0, e1) in zip(shapes, prof):
+for s, (f, e0, e1, _) in zip(shapes, prof):
     t = ctypes.c_float(); lib.call("mmsa_event_elapsed_ms", e0, e1, ctypes.byref(t))
     a = agg[s]; a[0] += 1; a[1] += t.value; a[2] += f
 tot = sum(v[1] for v in agg.values())
