@@ -41,7 +41,7 @@ struct AttnArgs {
 };
 
 template <int HD, bool PL, bool FB>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
   constexpr int DT = HD / 16;            // output d tiles
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   unsigned char* Vhi = Klo + KPL;
   unsigned char* Vlo = Vhi + VPL;
   float* bh = reinterpret_cast<float*>(Vlo + VPL);
-  float* bw = bh + 128 * a.KHs;
+  float* bw = bh + 128 * a.KHs;   // FB: not allocated (the W-term goes straight from HBM to registers)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, G = lane >> 4;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       const int tq = token_of(q0 + ql);
       const float v = tq >= 0 ? rpb[(long)tq * ncol + cidx] : 0.f;
       if (cidx < a.KH) bh[ql * a.KHs + cidx] = v;
-      else bw[ql * a.KWs + (cidx - a.KH)] = v;
+      else if constexpr (!FB) bw[ql * a.KWs + (cidx - a.KH)] = v;
     }
   }
 
@@ -127,14 +127,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   // FB: W-term of the bias for this lane's fixed key columns (kw = 16t + 4G + r), pre-multiplied by log2(e)
   float bwr[2][4][4];
   if constexpr (FB) {
-    __syncthreads();  // bias tables are in LDS
+    // straight from the rel-pos prepass output (no LDS copy: the table is read exactly once per lane), which leaves
+    // 36 KiB K/V + 33 KiB H-term table per workgroup = two workgroups per CU
+    const float* rpb = a.rp + ((long)b * a.heads + head) * T * (a.KH + a.KW) + a.KH;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < 2; ++sub) {
+      const int tq = tq_sub[sub];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          bwr[sub][t][r] = bw[(wave * 32 + sub * 16 + l15) * a.KWs + 16 * t + 4 * G + r] * 1.4426950408889634f;
+      for (int t = 0; t < 4; ++t) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tq >= 0) v = *reinterpret_cast<const float4*>(rpb + (long)tq * (a.KH + a.KW) + 16 * t + 4 * G);
+        bwr[sub][t][0] = v.x * 1.4426950408889634f;
+        bwr[sub][t][1] = v.y * 1.4426950408889634f;
+        bwr[sub][t][2] = v.z * 1.4426950408889634f;
+        bwr[sub][t][3] = v.w * 1.4426950408889634f;
+      }
+    }
   }
 
   // ---- K/V staging: thread -> (key, quarter of the head dim), HD/4 channels of K and of V.  Lanes 0-7 of every
@@ -403,7 +411,8 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
     }
   }
   const int VSTR = head_dim == 64 ? 160 : 96;
-  const size_t smem = 2 * (head_dim / 8) * 64 * 16 + 2 * 64 * VSTR + (size_t)128 * (a.KHs + a.KWs) * sizeof(float);
+  const bool fb = window_size == 0 && W == 64 && (H % 4) == 0;   // one key block = one image row: bias terms hoisted (see kernel)
+  const size_t smem = 2 * (head_dim / 8) * 64 * 16 + 2 * 64 * VSTR + (size_t)128 * (a.KHs + (fb ? 0 : a.KWs)) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 160 * 1024, "attention: bias tables do not fit LDS (KH=%d KW=%d)", a.KH, a.KW);
   dim3 grid(ngroups * cdiv(a.Nk, 128), heads, B);
 #define ATTN_LAUNCH(HD_, PL_, FB_)                                                                                         \
@@ -411,7 +420,6 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, PL_, FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((attn_kernel<HD_, PL_, FB_>), grid, dim3(256), smem, stream, a);                                    \
   } while (0)
-  const bool fb = window_size == 0 && W == 64;   // one key block = one image row: bias terms hoisted (see kernel)
   if (head_dim == 64) {
     if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
     else { if (fb) ATTN_LAUNCH(64, false, true); else ATTN_LAUNCH(64, false, false); }
