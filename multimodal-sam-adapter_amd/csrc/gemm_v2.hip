@@ -16,6 +16,8 @@
 //   * LDS image row-major, 128 B per row = 8 slots of 16 B (4 hi chunks | 4 lo chunks), slot index XORed with
 //     (row>>1)&7: every ds_read_b128 fragment read (hi and lo) is bank-conflict free; a DMA instruction writes
 //     1 KiB linearly, so the permutation is applied on the per-lane SOURCE address;
+//   * compact epilogue: a ROLLED loop over the four 16-row sub-tiles (accumulator columns rotated by register moves),
+//     one activation branch per 4 values: it must stay well inside the 64 KiB instruction cache (see the epilogue);
 //   * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) walk neighbouring (m-tile, n-tile) pairs so
 //     activation rows and weight panels are re-read from that XCD's L2 (speed only, never correctness).
 #include "common.h"
@@ -33,7 +35,7 @@ struct GemmV2Args {
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;
   int nbm, nbn, ntiles;
-  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands)
+  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 10 = epilogue without its global stores
 };
 
 #define V2_BM 256
@@ -125,11 +127,12 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   const int fa = (wm * 64) * 128;                    // activation rows of this wave, + mi*2048
   const int fw = V2_A_BYTES + (wn * 64) * 128;       // weight rows of this wave, + ni*2048
 
-  // ---- DMA cursor (runs 3 iterations ahead of the compute cursor; ring slot of iteration i is i % 3)
+  // ---- prefetch cursor (runs 2 iterations ahead of the compute cursor)
   int pf_tile = rb, pf_kt = 0, pf_st = 0, pf_j = 0;
   SET_TILE_SRC(pf_tile);
-#define ADVANCE_PF()                                        \
+#define PREFETCH_NEXT()                                     \
   do {                                                      \
+    ISSUE_DMA(pf_kt, pf_st);                                \
     pf_st = pf_st == 2 ? 0 : pf_st + 1;                     \
     ++pf_j;                                                 \
     if (++pf_kt == nk) {                                    \
@@ -138,41 +141,220 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       if (pf_j < total) SET_TILE_SRC(pf_tile);              \
     }                                                       \
   } while (0)
+  PREFETCH_NEXT();
+  if (total > 1) PREFETCH_NEXT();
+
+  int st = 0, tile = rb, nowait = 0, j = 0;
+
+  // One k-tile.  The DMAs of iteration j must have landed; those of j+1 (6 instructions, issued later) may stay in
+  // flight.  vmcnt retires in order and counts stores too, so a wait issued after an epilogue would also wait for that
+  // epilogue's stores; instead the epilogue first drains the (older) DMAs of j+1 and j+2 and the next two iterations skip
+  // the wait.  The 6 DMA instructions of iteration j+2 (ring slot (j+2)%3, last read in iteration j-1: free after the
+  // barrier) are issued BETWEEN the MFMA chunks, two per chunk: an LDS-DMA costs ~100 issue cycles (M0 write, address
+  // arithmetic, the instruction) which disappear under the 16-cycle passes of the MFMAs already queued.
+#define MFMA_CHUNK(ni)                                                                                      \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                        \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);            \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
+  }
+#define K_STEP()                                                                                            \
+  {                                                                                                         \
+    if (nowait > 0) --nowait;                                                                               \
+    else if (j + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                 \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    const bool do_pf = pf_j < total;                                                                        \
+    unsigned char* pfb = smem + pf_st * V2_STAGE;                                                           \
+    const int pko = a.debug == 3 ? 0 : pf_kt * 64;                                                          \
+    const unsigned char* base = smem + st * V2_STAGE;                                                       \
+    bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);                             \
+      al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
+    }                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                             \
+      wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                             \
+    }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    MFMA_CHUNK(0)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (do_pf) { GLDS16(sa0 + pko, pfb + lds_a); GLDS16(sa1 + pko, pfb + lds_a + 1024); }                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    MFMA_CHUNK(1)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (do_pf) { GLDS16(sa2 + pko, pfb + lds_a + 2048); GLDS16(sa3 + pko, pfb + lds_a + 3072); }            \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    MFMA_CHUNK(2)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (do_pf) { GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w); GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024); } \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    MFMA_CHUNK(3)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (do_pf) {   /* advance the prefetch cursor (source pointers of the next output tile when the k loop wraps) */ \
+      pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                   \
+      ++pf_j;                                                                                               \
+      if (++pf_kt == nk) {                                                                                  \
+        pf_kt = 0;                                                                                          \
+        pf_tile += G;                                                                                       \
+        if (pf_j < total) SET_TILE_SRC(pf_tile);                                                            \
+      }                                                                                                     \
+    }                                                                                                       \
+    st = st == 2 ? 0 : st + 1;                                                                              \
+    ++j;                                                                                                    \
+  }
+
+  for (int tdone = 0; tdone < my_tiles; ++tdone) {
 #pragma unroll 1
-  for (int i = 0; i < 3 && i < total; ++i) {
-    ISSUE_DMA(pf_kt, pf_st);
-    ADVANCE_PF();
-  }
+    for (int kt = 0; kt < nk; ++kt) K_STEP()
+    const int st_cur = st == 0 ? 2 : st - 1;   // ring slot of the k-tile just consumed: free until the DMA of iteration j+2
 
-  // ---- fragments are DOUBLE-BUFFERED IN REGISTERS: while the 48 MFMAs of iteration j run on set j&1, the 16
-  // ds_read_b128 of iteration j+1 (ring slot (j+1)%3, landed before this iteration's barrier) fill the other set,
-  // four reads in front of each 12-MFMA chunk.  Reading a k-tile's fragments right after the barrier that publishes
-  // it (previous version) parked all 8 waves on the same ~1000-cycle LDS burst (128 ds_read_b128 per k-tile per CU
-  // at 8 cycles each) with an idle matrix pipe; now the matrix pipe starts on registers the moment the barrier opens.
-  bf16x8 ah[2][4], al[2][4], wh[2][4], wl[2][4];
-#define READ_FRAGS(set, base_, i)                                                          \
-  ah[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fa + (i) * 2048 + frag_hi);       \
-  al[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fa + (i) * 2048 + frag_lo);       \
-  wh[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fw + (i) * 2048 + frag_hi);       \
-  wl[set][i] = *reinterpret_cast<const bf16x8*>((base_) + fw + (i) * 2048 + frag_lo);
-  {
-    // iteration 0's fragments: its 6 DMA instructions are the oldest of the (up to) 18 in flight
-    if (total >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (total == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    READ_FRAGS(0, smem, 0) READ_FRAGS(0, smem, 1) READ_FRAGS(0, smem, 2) READ_FRAGS(0, smem, 3)
+    if (a.debug == 2) { tile += G; continue; }
+    // ---- tile boundary.  MFMA layout: lane holds C[m = ..+l15][n = ..+4g .. +3].  Each wave transposes 16 x 64
+    // sub-tiles through the ring slot it has just finished computing from, so that residual loads and output stores
+    // are FULL 256-byte row segments (4 rows per wave-instruction).  After the transpose a lane owns the SAME 4
+    // columns in every row, so the column-wise part needs 8 registers.
+    {
+      const int per_b = a.nbm * a.nbn;
+      const int bz = tile / per_b;
+      const int rt = tile - bz * per_b;
+      const int m0 = (rt / a.nbn) * V2_BM, n0 = (rt % a.nbn) * V2_BN;
+      const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
+      const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
+      float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
+      unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
+      const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of j, j+1 (already issued) and every store issued so far
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; the next two k-tiles landed for all
+      nowait = 2;
+      float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
+      const int nb_ = n0 + wn * 64;
+      const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
+      const int cl = (lane & 15) * 4;
+      const int n = nb_ + cl;
+      // column parameters of this lane's 4 columns: loaded ONCE per tile, unconditionally (clamped index)
+      float bv[4], cv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = min(n + r, a.N - 1);
+        bv[r] = bias ? bias[ci] : 0.f;
+        if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
+        cv[r] = a.colscale ? a.colscale[ci] * a.alpha : a.alpha;
+      }
+      // row mapping (destination row / column, residual row); identity unless GEN
+      auto map_row = [&](int m, int nn, long& drow_, int& dcol, long& rrow) {
+        drow_ = m; dcol = nn; rrow = m;
+        if constexpr (GEN) {
+          if (a.out_mode == 1) {
+            const int ij = nn / a.ps_C;
+            dcol = nn - ij * a.ps_C;
+            const int w_ = m % a.ps_W;
+            const int t_ = m / a.ps_W;
+            const int h_ = t_ % a.ps_H;
+            const int b_ = t_ / a.ps_H;
+            drow_ = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
+          }
+          rrow = a.resid_mod > 0 ? (long)((int)drow_ % a.resid_mod) : drow_;
+        }
+      };
+      // wave-uniform: whole 64-column strip inside N, 16-byte aligned (and, for the planes output of a pixel-shuffle
+      // store, inside one destination row: ps_C a multiple of 64)
+      const bool fast = vec_ok && (nb_ + 64 <= a.N) && (!GEN || !Cp || a.out_mode != 1 || (a.ps_C & 63) == 0);
+      // The four 16-row sub-tiles are handled by a ROLLED loop: the code always takes accumulator column 0 and then
+      // rotates the columns down by register moves (48 v_mov per pass).  Fully unrolled -- with the activation switch
+      // expanded per element -- the epilogue was ~100 KiB of straight-line code, far beyond the 64 KiB instruction
+      // cache two CUs share, and ran at instruction-fetch speed: ~45 of the kernel's ~200 us at K = 1024 with
+      // only ~13 us of that being the stores themselves (MMSA_GEMM_DEBUG 1 / 10 / 2 ablations).
+#pragma unroll 1
+      for (int mi = 0; mi < 4; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 16;
+        // residual rows first: 4 independent 16-byte loads in flight, no waits inside the element loops
+        float4 rr[4];
+        if (fast && resid) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            long drow_, rrow; int dcol;
+            map_row(min(mb + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
+            rr[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][0];
+          acc[ni][0] = acc[ni][1];
+          acc[ni][1] = acc[ni][2];
+          acc[ni][2] = acc[ni][3];
+          acc[ni][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.debug == 1) continue;
+        if (fast) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rl = rl0 + 4 * i;
+            float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
+            o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
+            if (a.act != ACT_NONE) {   // ONE wave-uniform branch per 4 values
+              o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+            }
+            o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
+            if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
+            // planes output: split in registers, re-stage the bf16 pairs in the INTERLEAVED layout (hi 32 | lo 32 per
+            // k-block) in the same LDS row and read them back 16 bytes per lane, so that a row-group leaves as ONE
+            // instruction of 4 x 256 contiguous bytes = full 128-byte lines (8-byte hi / lo stores wrote every line as
+            // two half-lines from two instructions).  LDS executes a wave's instructions in order: the row was fully
+            // read (above) before it is overwritten here.
+            uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+            if (Cp) {
+              uint2 hh, ll;
+              split4(o, hh, ll);
+              unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
+              *reinterpret_cast<uint2*>(srow + ilv(cl)) = hh;
+              *reinterpret_cast<uint2*>(srow + ilv(cl) + 32) = ll;
+              pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
+            }
+            const int m = mb + rl;
+            if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
+            else if (m < a.M) {
+              long drow_, rrow; int dcol;
+              map_row(m, n, drow_, dcol, rrow);
+              if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
+              if (Cp) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
+            }
+          }
+        } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare
+#pragma unroll 1
+          for (int e = 0; e < 16; ++e) {
+            const int i = e >> 2, r = e & 3;
+            const int rl = rl0 + 4 * i;
+            const int m = mb + rl;
+            if (m >= a.M || n + r >= a.N) continue;
+            float x = stg[rl * 68 + cl + r];
+            {
+              int ci = n + r;
+              const float b_ = bias ? bias[ci] : 0.f;
+              if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
+              x = apply_act(x + b_, a.act) * (a.colscale ? a.colscale[ci] * a.alpha : a.alpha);
+            }
+            long drow_, rrow; int dcol;
+            map_row(m, n + r, drow_, dcol, rrow);
+            if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
+            if (C) C[drow_ * a.ldc + dcol] = x;
+            if (Cp) {
+              unsigned short hh, ll;
+              split_bf16(x, hh, ll);
+              Cp[drow_ * a.ldcp + ilv(dcol)] = hh;
+              Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
+            }
+          }
+        }
+      }
+    }
+    tile += G;
   }
-
-  int st = 0, kt = 0, tile = rb, nowait = 0;
-  for (int j0 = 0; j0 < total; j0 += 2) {
-#define P 0
-#include "gemm_v2_step.inc"
-#undef P
-#define P 1
-#include "gemm_v2_step.inc"
-#undef P
-  }
+#undef K_STEP
+#undef MFMA_CHUNK
 }
 
 static int g_num_cus = 0;

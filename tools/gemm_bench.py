@@ -25,12 +25,15 @@ def bench(M, N, K, planes, reps=20):
     b = torch.randn(N, device=DEV)
     out = torch.empty(M, N, device=DEV)
     ain = ops.split_planes(a, kpad=K) if planes else a
+    kw = dict(out=out)
+    if os.environ.get("GEMM_BENCH_OUT") == "planes":   # what qkv / lin1 / pw1 do in the model: planes-only output
+        kw = dict(out_planes=ops.alloc_planes(M, N, DEV))
     for _ in range(3):
-        ops.gemm(ain, w, out, bias=b)
+        ops.gemm(ain, w, bias=b, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        ops.gemm(ain, w, out, bias=b)
+        ops.gemm(ain, w, bias=b, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     return 2.0 * M * N * K / dt / 1e12, dt * 1e6
