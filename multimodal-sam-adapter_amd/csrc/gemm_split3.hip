@@ -199,15 +199,27 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
       bv[ni][r] = bias ? bias[nn] : 0.f;
       cv[ni][r] = a.colscale ? a.colscale[ci] * a.alpha : a.alpha;
     }
-#pragma unroll
+  // ROLLED over the four 16-row sub-tiles (the code always takes accumulator column 0, the columns are then rotated down
+  // by register moves), one activation branch per 4 values: fully unrolled with the activation switch expanded per
+  // element this epilogue was > 100 KiB of straight-line code -- beyond the 64 KiB instruction cache -- and ran at
+  // instruction-fetch speed (same finding as gemm_v2.hip).
+#pragma unroll 1
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + l15;
+    f32x4 col[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      col[ni] = acc[ni][0];
+      acc[ni][0] = acc[ni][1];
+      acc[ni][1] = acc[ni][2];
+      acc[ni][2] = acc[ni][3];
+    }
     if (m >= a.M) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wn * 64 + ni * 16 + 4 * g;
       if (n >= a.N) continue;
-      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+      float v[4] = {col[ni][0], col[ni][1], col[ni][2], col[ni][3]};
       long drow = m;
       int dcol = n;
       long rrow = m;
@@ -224,7 +236,13 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
         rrow = a.resid_mod > 0 ? (long)((int)drow % a.resid_mod) : drow;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r] + bv[ni][r], a.act) * cv[ni][r];
+      for (int r = 0; r < 4; ++r) v[r] += bv[ni][r];
+      if (a.act != ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= cv[ni][r];
       if (vec_ok && n + 3 < a.N) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (resid) {
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
           *reinterpret_cast<uint2*>(cp_ + 32) = ll;
         }
       } else {
-#pragma unroll
+#pragma unroll 1
         for (int r = 0; r < 4; ++r) {
           if (n + r < a.N) {
             float x = v[r];
