@@ -208,6 +208,11 @@ def main():
             "end_to_end_algorithmic_tflops": round(end_to_end_tflops, 1) if end_to_end_tflops else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        try:   # RCCL prints a banner through C stdio; flush it so that the JSON line is the LAST line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
