@@ -65,14 +65,26 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
   const int tx0 = (blockIdx.x % tilesX) * 8, ty0 = (blockIdx.x / tilesX) * 8;
   const float* xb = x + (long)b * xstrideB;
   const int cvalid = min(CB, C - c0);   // multiple of 4
-  for (int i = threadIdx.x; i < TW * TW * (CB / 4); i += 256) {
-    const int cv = i & 15, pos = i >> 4;
-    const int ly = pos / TW, lx = pos - ly * TW;
-    const int iy = ty0 + ly - 3, ix = tx0 + lx - 3;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cv * 4 < cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W)
-      v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx + c0 + cv * 4);
-    *reinterpret_cast<float4*>(tile + pos * CB + cv * 4) = v;
+  // halo tile: all 13 loads of a lane are issued before the first LDS write (a rolled load -> store loop serialised 13
+  // global round trips per lane and was most of the kernel's time)
+  {
+    constexpr int NIT = (TW * TW * (CB / 4) + 255) / 256;   // 13
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + it * 256;
+      const int cv = i & 15, pos = i >> 4;
+      const int ly = pos / TW, lx = pos - ly * TW;
+      const int iy = ty0 + ly - 3, ix = tx0 + lx - 3;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < TW * TW * (CB / 4) && cv * 4 < cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v[it] = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx + c0 + cv * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + it * 256;
+      if (i < TW * TW * (CB / 4)) *reinterpret_cast<float4*>(tile + (i >> 4) * CB + (i & 15) * 4) = v[it];
+    }
   }
   __syncthreads();
   const int cv = threadIdx.x & 15, strip = threadIdx.x >> 4;   // 16 strips: row = strip>>1, x0 = (strip&1)*4

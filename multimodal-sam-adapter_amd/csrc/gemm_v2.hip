@@ -52,8 +52,11 @@ struct GemmV2Args {
 
 // GEN = true compiles in the rarely used index arithmetic (pixel-shuffle store, broadcast residual: integer
 // divisions per output row); the common epilogue (GEN = false) has none.
-template <bool GEN>
+// ACT >= 0: the activation is a compile-time constant (the epilogue then has no activation switch and is small enough to be
+// unrolled over the four sub-tiles inside the instruction cache); ACT = -1: runtime a.act, rolled epilogue.
+template <bool GEN, int ACT>
 __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
+  constexpr bool EPI_UNROLL = ACT >= 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -267,8 +270,10 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       // expanded per element -- the epilogue was ~100 KiB of straight-line code, far beyond the 64 KiB instruction
       // cache two CUs share, and ran at instruction-fetch speed: ~45 of the kernel's ~200 us at K = 1024 with
       // only ~13 us of that being the stores themselves (MMSA_GEMM_DEBUG 1 / 10 / 2 ablations).
-#pragma unroll 1
-      for (int mi = 0; mi < 4; ++mi) {
+      const int act = ACT >= 0 ? ACT : a.act;
+      if constexpr (EPI_UNROLL) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
         const int mb = m0 + wm * 64 + mi * 16;
         // residual rows first: 4 independent 16-byte loads in flight, no waits inside the element loops
         float4 rr[4];
@@ -282,11 +287,8 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][0];
-          acc[ni][0] = acc[ni][1];
-          acc[ni][1] = acc[ni][2];
-          acc[ni][2] = acc[ni][3];
-          acc[ni][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][mi];
+          acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (a.debug == 1) continue;
         if (fast) {
@@ -295,8 +297,8 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             const int rl = rl0 + 4 * i;
             float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
             o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
-            if (a.act != ACT_NONE) {   // ONE wave-uniform branch per 4 values
-              o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+            if (act != ACT_NONE) {   // ONE wave-uniform branch per 4 values (none when ACT is a template constant)
+              o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
             }
             o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
             if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
               int ci = n + r;
               const float b_ = bias ? bias[ci] : 0.f;
               if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-              x = apply_act(x + b_, a.act) * (a.colscale ? a.colscale[ci] * a.alpha : a.alpha);
+              x = apply_act(x + b_, act) * (a.colscale ? a.colscale[ci] * a.alpha : a.alpha);
             }
             long drow_, rrow; int dcol;
             map_row(m, n + r, drow_, dcol, rrow);
@@ -348,6 +350,91 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
               Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
             }
           }
+        }
+        }
+      } else {
+#pragma unroll 1
+        for (int mi = 0; mi < 4; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 16;
+        // residual rows first: 4 independent 16-byte loads in flight, no waits inside the element loops
+        float4 rr[4];
+        if (fast && resid) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            long drow_, rrow; int dcol;
+            map_row(min(mb + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
+            rr[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][0];
+          acc[ni][0] = acc[ni][1];
+          acc[ni][1] = acc[ni][2];
+          acc[ni][2] = acc[ni][3];
+          acc[ni][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.debug == 1) continue;
+        if (fast) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rl = rl0 + 4 * i;
+            float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
+            o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
+            if (act != ACT_NONE) {   // ONE wave-uniform branch per 4 values (none when ACT is a template constant)
+              o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
+            }
+            o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
+            if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
+            // planes output: split in registers, re-stage the bf16 pairs in the INTERLEAVED layout (hi 32 | lo 32 per
+            // k-block) in the same LDS row and read them back 16 bytes per lane, so that a row-group leaves as ONE
+            // instruction of 4 x 256 contiguous bytes = full 128-byte lines (8-byte hi / lo stores wrote every line as
+            // two half-lines from two instructions).  LDS executes a wave's instructions in order: the row was fully
+            // read (above) before it is overwritten here.
+            uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+            if (Cp) {
+              uint2 hh, ll;
+              split4(o, hh, ll);
+              unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
+              *reinterpret_cast<uint2*>(srow + ilv(cl)) = hh;
+              *reinterpret_cast<uint2*>(srow + ilv(cl) + 32) = ll;
+              pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
+            }
+            const int m = mb + rl;
+            if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
+            else if (m < a.M) {
+              long drow_, rrow; int dcol;
+              map_row(m, n, drow_, dcol, rrow);
+              if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
+              if (Cp) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
+            }
+          }
+        } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare
+#pragma unroll 1
+          for (int e = 0; e < 16; ++e) {
+            const int i = e >> 2, r = e & 3;
+            const int rl = rl0 + 4 * i;
+            const int m = mb + rl;
+            if (m >= a.M || n + r >= a.N) continue;
+            float x = stg[rl * 68 + cl + r];
+            {
+              int ci = n + r;
+              const float b_ = bias ? bias[ci] : 0.f;
+              if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
+              x = apply_act(x + b_, act) * (a.colscale ? a.colscale[ci] * a.alpha : a.alpha);
+            }
+            long drow_, rrow; int dcol;
+            map_row(m, n + r, drow_, dcol, rrow);
+            if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
+            if (C) C[drow_ * a.ldc + dcol] = x;
+            if (Cp) {
+              unsigned short hh, ll;
+              split_bf16(x, hh, ll);
+              Cp[drow_ * a.ldcp + ilv(dcol)] = hh;
+              Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
+            }
+          }
+        }
         }
       }
     }
@@ -390,14 +477,26 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
       return MMSA_ERR_LAUNCH;
     }
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
   }
   const int grid = a.ntiles < g_num_cus ? a.ntiles : g_num_cus;   // one resident workgroup per CU (144 KiB LDS each)
-  if (out_mode != 0 || resid_mod > 0)
-    hipLaunchKernelGGL(gemm_v2_kernel<true>, dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a);
-  else
-    hipLaunchKernelGGL(gemm_v2_kernel<false>, dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a);
+  const bool gen = out_mode != 0 || resid_mod > 0;
+#define V2_LAUNCH(GEN_, ACT_) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_>), dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a)
+  if (gen) {
+    V2_LAUNCH(true, -1);
+  } else {
+    switch (act) {
+      case ACT_NONE: V2_LAUNCH(false, ACT_NONE); break;
+      case ACT_GELU: V2_LAUNCH(false, ACT_GELU); break;
+      case ACT_RELU: V2_LAUNCH(false, ACT_RELU); break;
+      default: V2_LAUNCH(false, -1); break;
+    }
+  }
+#undef V2_LAUNCH
   MMSA_CHECK_LAUNCH("gemm_split3(v2)");
   return MMSA_OK;
 }
