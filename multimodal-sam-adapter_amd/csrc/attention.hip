@@ -81,7 +81,31 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
   const int colq = head * HD, colk = a.D + head * HD, colv = 2 * a.D + head * HD;
 
   // ---- bias tables for the block's 128 queries -> LDS
-  {
+  if constexpr (FB) {
+    // H-term only (KH % 4 == 0, checked by the launcher): float4 loads, four per lane IN FLIGHT before the first LDS
+    // write -- the rolled load -> store loop below serialises one global round trip per element
+    const int ncol = a.KH + a.KW, nf4 = a.KH >> 2, total4 = 128 * nf4;
+    const float* rpb = a.rp + ((long)b * a.heads + head) * T * ncol;
+    for (int i0 = tid; i0 < total4; i0 += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        const int ql = i / nf4, c4 = i - ql * nf4;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total4 && q0 + ql < a.Nk) v[u] = *reinterpret_cast<const float4*>(rpb + (long)(q0 + ql) * ncol + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < total4) {
+          const int ql = i / nf4, c4 = i - ql * nf4;
+          float* d = bh + ql * a.KHs + 4 * c4;
+          d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+      }
+    }
+  } else {
     const int ncol = a.KH + a.KW;
     const float* rpb = a.rp + ((long)b * a.heads + head) * T * ncol;
     for (int i = tid; i < 128 * ncol; i += 256) {
@@ -89,7 +113,7 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
       const int tq = token_of(q0 + ql);
       const float v = tq >= 0 ? rpb[(long)tq * ncol + cidx] : 0.f;
       if (cidx < a.KH) bh[ql * a.KHs + cidx] = v;
-      else if constexpr (!FB) bw[ql * a.KWs + (cidx - a.KH)] = v;
+      else bw[ql * a.KWs + (cidx - a.KH)] = v;
     }
   }
 
