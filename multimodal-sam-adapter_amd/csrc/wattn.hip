@@ -304,6 +304,321 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT variant (the default): one workgroup per CU walks the (window, head, image) items.  Measured on the
+// one-shot kernel above: half of a workgroup's life was the cold start (launch, Q / table loads, the K/V transfer of
+// 110 KiB that every CU requests at the same moment), during which nothing computes.  Here the next item's K is brought in
+// while the current item's softmax and PV run (the K image is free once every wave has its scores), the V image while
+// the next S runs, the next Q fragments are loaded into the registers the current ones vacate, and the rel-pos table and
+// the selector are loaded once per workgroup.  Three barriers per item:
+//   #1  K(i) landed for everyone, everyone is past PV(i-1)     -> V(i) DMA issued;   T / bias operand / S(i)
+//   #2  everyone has its scores (K image free)                 -> K(i+1) DMA issued;   softmax statistics
+//   #3  V(i) landed for everyone (counted vmcnt: K(i+1) stays in flight)             PV(i), store, Q(i+1) loads
+#define WP_NKV 208
+#define WP_V_BYTES (WP_NKV * 128)
+#define WP_R_BYTES (2 * 64 * 128)        // rel-pos table image: [ks][64 rows] of 128 B (GEMM LDS image)
+#define WP_LDS (WA_K_BYTES + 2 * WP_V_BYTES + WA_E_BYTES + WP_R_BYTES + WA_WAVES * WA_B_BYTES)
+
+__global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs a, int nWin, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vhi = smem + WA_K_BYTES;
+  unsigned char* Vlo = Vhi + WP_V_BYTES;
+  unsigned char* Es = Vlo + WP_V_BYTES;
+  unsigned char* Rs = Es + WA_E_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Bw = reinterpret_cast<float*>(Rs + WP_R_BYTES + wave * WA_B_BYTES);
+  const int l15 = lane & 15, G = lane >> 4;
+  const int T = a.H * a.W, ws = a.ws, Nk = ws * ws;
+  const int dr = lane >> 3, slot = lane & 7;
+
+  // item -> (window row, window column, head, image); window-local index j -> token (-1 pad, -2 beyond the window)
+  int wi, wj, head, b;
+  // Items are ordered window-major with the windows that overhang the image (bottom row / right column: padded, fewer live
+  // query tiles, cheaper) LAST: with a static round-robin the workgroups that get one item more than the others get these.
+  const int nWh = nWin / a.nWw, nHB = a.heads * a.B;
+  auto decode = [&](int it) {
+    const int r = it / nHB;
+    const int hb = it - r * nHB;
+    head = hb % a.heads;
+    b = hb / a.heads;
+    const int nI = (nWh - 1) * (a.nWw - 1);
+    if (r < nI) {
+      wi = r / (a.nWw - 1);
+      wj = r - wi * (a.nWw - 1);
+    } else if (r - nI < nWh - 1) {
+      wi = r - nI;
+      wj = a.nWw - 1;
+    } else {
+      wi = nWh - 1;
+      wj = r - nI - (nWh - 1);
+    }
+  };
+  auto token_of = [&](int j) -> int {
+    if (j >= Nk) return -2;
+    const int r = (int)(__umul24(j, a.magic) >> 16), c = j - __umul24(r, ws);
+    const int hh = wi * ws + r, ww = wj * ws + c;
+    return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
+  };
+  // (uses the CURRENT decode state)
+#define WP_ISSUE_K()                                                                                          \
+  {                                                                                                           \
+    int lo_ = lane;   /* opaque: keep the per-lane address parts inside the item loop (register budget) */    \
+    asm volatile("" : "+v"(lo_));                                                                             \
+    const int dr = lo_ >> 3, slot = lo_ & 7;                                                                  \
+    const unsigned short* pq_b_ = a.qp + (long)b * T * a.ldq;                                                 \
+    const int colk_ = a.D + head * 64;                                                                        \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
+      const int key = 16 * wave + 8 * half + dr;                                                              \
+      const int t_ = token_of(key);                                                                           \
+      const unsigned short* row = t_ >= 0 ? pq_b_ + (long)t_ * a.ldq : a.bp;                                  \
+      const int piece = slot ^ ((key & 15) >> 1);                                                             \
+      GLDS16(row + 2 * colk_ + piece * 8, Ks + (16 * wave + 8 * half) * 128);                                 \
+      GLDS16(row + 2 * (colk_ + 32) + piece * 8, Ks + (WA_NKEY + 16 * wave + 8 * half) * 128);                \
+    }                                                                                                         \
+  }
+#define WP_ISSUE_V()                                                                                          \
+  {                                                                                                           \
+    int lo_ = lane;                                                                                           \
+    asm volatile("" : "+v"(lo_));                                                                             \
+    const int dr = lo_ >> 3, slot = lo_ & 7;                                                                  \
+    const unsigned short* pq_b_ = a.qp + (long)b * T * a.ldq;                                                 \
+    const int colv_ = 2 * a.D + head * 64;                                                                    \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
+      const int key = 16 * wave + 8 * half + dr;                                                              \
+      const int t_ = token_of(key);                                                                           \
+      const unsigned short* row = t_ >= 0 ? pq_b_ + (long)t_ * a.ldq : a.bp;                                  \
+      const int c = slot ^ (((key >> 1) & 3) << 1);                                                           \
+      const unsigned short* vsrc = row + 2 * (colv_ + 32 * (c >> 2)) + (c & 3) * 8;                           \
+      GLDS16(vsrc, Vhi + (16 * wave + 8 * half) * 128);                                                       \
+      GLDS16(vsrc + 32, Vlo + (16 * wave + 8 * half) * 128);                                                  \
+    }                                                                                                         \
+  }
+#define WP_LOAD_Q()                                                                                           \
+  {                                                                                                           \
+    tq = token_of(16 * wave + l15);                                                                           \
+    const unsigned short* qrow = a.qp + ((long)b * T + (tq >= 0 ? tq : 0)) * a.ldq;                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                        \
+      const unsigned short* qq = qrow + 2 * (head * 64 + 32 * ks) + 8 * G;                                    \
+      qh[ks] = *reinterpret_cast<const bf16x8*>(qq);                                                          \
+      ql[ks] = *reinterpret_cast<const bf16x8*>(qq + 32);                                                     \
+    }                                                                                                         \
+  }
+
+  // ---- once per workgroup: selector tiles and the rel-pos table image
+  {
+    const int row = lane >> 2, ch = (lane & 3) ^ ((row >> 2) & 3);
+    GLDS16(a.sel + (16 * wave + row) * 32 + ch * 8, Es + 16 * wave * 64);
+#pragma unroll 1
+    for (int u = wave; u < 16; u += WA_WAVES) {   // 16 groups of 8 rows: group u -> k-step u >> 3, rows 8*(u & 7) ..
+      const int ks = u >> 3, r0 = 8 * (u & 7);
+      const int rrow = r0 + dr;
+      const int piece = slot ^ ((rrow & 15) >> 1);
+      GLDS16(a.relp + rrow * 128 + 64 * ks + piece * 8, Rs + (ks * 64 + r0) * 128);
+    }
+  }
+  int it = blockIdx.x;
+  if (it >= nitems) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+  decode(it);
+  bf16x8 qh[2], ql[2];
+  int tq;
+  WP_ISSUE_K()
+  WP_LOAD_Q()
+
+  const int fslot = G ^ ((l15 >> 1) & 7);
+  const int frag_hi = l15 * 128 + fslot * 16, frag_lo = l15 * 128 + (fslot ^ 4) * 16;
+  const int frag_e = l15 * 64 + ((G ^ ((l15 >> 2) & 3)) << 4);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sc2 = a.scale * LOG2E, rscale = 1.0f / a.scale;
+  bool first = true;
+
+#pragma unroll 1
+  for (;;) {
+    const int jq = 16 * wave + l15;
+    const bool live = tq >= 0;
+    const bool any_live = __builtin_amdgcn_readfirstlane(__any(live) ? 1 : 0) != 0;   // wave-uniform
+    const int tq_cur = tq;
+    const int head_cur = head, b_cur = b;
+    // rel-pos terms and the bias operand need only Q and the table image: done BEFORE barrier #1, in the time a wave
+    // would otherwise wait for the slowest wave's PV / K transfer
+    bf16x8 bqh = {0, 0, 0, 0, 0, 0, 0, 0}, bql = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q(i) (and this wave's K(i) DMA: older, so it has landed too)
+    if (first) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); first = false; }   // table image of all waves
+    if (any_live) {
+      // rel-pos terms T[i][q] = rel_pos[i] . q (table fragments from the LDS image), re-indexed per query by key coordinate
+      f32x4 tt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        tt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned char* rb = Rs + (ks * 64 + 16 * t) * 128;
+          const bf16x8 rh_ = *reinterpret_cast<const bf16x8*>(rb + frag_hi);
+          const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rb + frag_lo);
+          tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[ks], tt[t], 0, 0, 0);
+          tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql[ks], tt[t], 0, 0, 0);
+          tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[ks], tt[t], 0, 0, 0);
+        }
+      }
+      {
+        // lane indices through an opaque copy: LICM would otherwise hoist ~20 per-lane addresses of this block out of the
+        // item loop and spill them (128-VGPR budget at 13 waves)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int l15 = lane_o & 15, G = lane_o >> 4;
+        const int jqc = jq < Nk ? jq : 0;
+        const int qr = (int)(__umul24(jqc, a.magic) >> 16), qc = jqc - __umul24(qr, ws);
+        *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * (t & 1) + 4 * G + r;
+            const int kc = ((t >> 1) ? qc : qr) + (ws - 1) - i;
+            if (kc >= 0 && kc < ws) Bw[l15 * 32 + (t >> 1) * 14 + kc] = tt[t][r] * rscale;
+          }
+        const float4 b0 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G);
+        const float4 b1 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G + 4);
+        uint4 hh, ll;
+        split2(b0.x, b0.y, hh.x, ll.x);
+        split2(b0.z, b0.w, hh.y, ll.y);
+        split2(b1.x, b1.y, hh.z, ll.z);
+        split2(b1.z, b1.w, hh.w, ll.w);
+        bqh = __builtin_bit_cast(bf16x8, hh);
+        bql = __builtin_bit_cast(bf16x8, ll);
+      }
+    }
+    // ---- barrier #1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    WP_ISSUE_V()
+
+    f32x4 s[13];
+    if (any_live) {
+      // S^T = sel Bq^T + K Q^T
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        const bf16x8 e_ = *reinterpret_cast<const bf16x8*>(Es + 16 * t * 64 + frag_e);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bql, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bqh, s[t], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned char* kb = Ks + (ks * WA_NKEY + 16 * t) * 128;
+          const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(kb + frag_hi);
+          const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(kb + frag_lo);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], s[t], 0, 0, 0);
+        }
+        if (t & 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 13 tiles' fragment reads (spills at 128 VGPRs)
+      }
+    }
+    // ---- barrier #2: the K image and this wave's Q registers are free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int it_next = it + gridDim.x;
+    const bool has_next = it_next < nitems;
+    if (has_next) {
+      decode(it_next);
+      WP_ISSUE_K()
+    }
+    float mxs = 0.f;
+    if (any_live) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int G = lane_o >> 4;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        s[t] *= sc2;
+        if (16 * t + 16 > Nk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * G + r) < Nk ? s[t][r] : -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mxs = mx;
+    }
+    // ---- barrier #3: V(i) landed (the 4 K DMA instructions of the next item, issued later, stay in flight)
+    if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (any_live) {
+      int lane_o = lane;   // opaque copy: the 28 transposed-read addresses below must not be hoisted out of the item loop
+      asm volatile("" : "+v"(lane_o));
+      const int l15 = lane_o & 15, G = lane_o >> 4;
+      f32x4 o[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float psum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          if (2 * g + hf < 13) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
+              s[2 * g + hf][r] = p;
+              psum += p;
+            }
+          }
+        }
+        uint4 hh, ll;
+        split2(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
+        split2(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
+        if (2 * g + 1 < 13) {
+          split2(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
+          split2(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
+        } else {
+          hh.z = hh.w = ll.z = ll.w = 0u;   // keys 208..223 do not exist
+        }
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, hh), pl = __builtin_bit_cast(bf16x8, ll);
+        const int row0 = 32 * g + 4 * G + (l15 >> 2);
+        const int sw = (row0 >> 1) & 3;
+        const int second = (2 * g + 1 < 13) ? 16 * 128 : 0;   // no V rows beyond 207: re-read valid rows (their P is zero)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int voff = row0 * 128 + ((d ^ sw) << 5) + 8 * (l15 & 3);
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + second));
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + second));
+          const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      const float inv = 1.0f / psum;
+      if (tq_cur >= 0) {
+        unsigned short* orow = a.op + ((long)b_cur * T + tq_cur) * a.ldo;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          uint2 hh, ll;
+          split4(make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), hh, ll);
+          unsigned short* q_ = orow + ilv(head_cur * 64 + 16 * d + 4 * G);
+          *reinterpret_cast<uint2*>(q_) = hh;
+          *reinterpret_cast<uint2*>(q_ + 32) = ll;
+        }
+      }
+    }
+    if (!has_next) break;
+    it = it_next;
+    WP_LOAD_Q()   // (register pressure: loading them before PV spilled)
+  }
+}
+
 extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, long ldq, const unsigned short* bias_planes,
                                             const unsigned short* relpos_planes, const unsigned short* selector,
                                             unsigned short* out_planes, long ldo,
@@ -330,13 +645,27 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
       mmsa_set_error("window_attention: index arithmetic not exact for window_size %d", window_size);
       return MMSA_ERR_ARG;
     }
+  static const bool v1 = getenv("MMSA_WATTN_V1") != nullptr;   // one workgroup per item (A/B timing)
   static bool attr_set = false;
+  static int num_cus = 256;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
+    (void)hipFuncSetAttribute((const void*)wattn_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cus = prop.multiProcessorCount;
     attr_set = true;
   }
-  dim3 grid(cdiv(H, window_size) * a.nWw, heads, B);
-  hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
+  const int nWin = cdiv(H, window_size) * a.nWw;
+  if (v1) {
+    dim3 grid(nWin, heads, B);
+    hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
+  } else {
+    const int nitems = nWin * heads * B;
+    const int grid = nitems < num_cus ? nitems : num_cus;
+    hipLaunchKernelGGL(wattn_persist_kernel, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
+  }
   MMSA_CHECK_LAUNCH("window_attention");
   return MMSA_OK;
 }
