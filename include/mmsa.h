@@ -129,6 +129,10 @@ int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, co
                      int B, int H, int W, int C, int k, int act, mmsa_stream_t stream);
 int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
                     int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);
+/* gated pair stage of the neck Mlp (AM:127-132): y = gelu(dw3x3(x)[:, :C]) * dw3x3(x)[:, C:], x token-major [B*H*W, 2C], the
+ * depthwise conv has 2 channels per group (C groups), weights TAP-major [9][C][ci=2][co=2]; fp32 and/or interleaved-planes output */
+int mmsa_dwpair_gate(const float* x, long ldx, const float* w, float* y, long ldy, uint16_t* y_planes, long ldp, int B, int H,
+                     int W, int C, mmsa_stream_t stream);
 int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, int W, int p, float* out, int Kpad,
                      mmsa_stream_t stream);
 

@@ -24,14 +24,16 @@ __global__ __launch_bounds__(256) void msda_kernel(
     unsigned short* __restrict__ op, long ldop,
     int N, int S, int M, int D, int L, int Lq, int P) {
   const int d4 = D >> 2;                        // lanes per (q, m) pair
-  const long pair = ((long)blockIdx.x * blockDim.x + threadIdx.x) / d4;
+  // 32-bit index arithmetic (N*Lq*M*d4 < 2^32, checked by the launcher): the four 64-bit div/mod of the first version
+  // were a quarter of the kernel's instructions
+  const unsigned pair = (blockIdx.x * blockDim.x + threadIdx.x) / (unsigned)d4;
   const int c = ((threadIdx.x) % d4) * 4;       // blockDim.x is a multiple of d4
-  const long npairs = (long)N * Lq * M;
+  const unsigned npairs = (unsigned)N * (unsigned)Lq * (unsigned)M;
   if (pair >= npairs) return;
-  const int m = (int)(pair % M);
-  const long bq = pair / M;
-  const int q = (int)(bq % Lq);
-  const int b = (int)(bq / Lq);
+  const unsigned bq = pair / (unsigned)M;
+  const int m = (int)(pair - bq * (unsigned)M);
+  const int b = (int)(bq / (unsigned)Lq);
+  const int q = (int)(bq - (unsigned)b * (unsigned)Lq);
   const int LP = L * P;
 
   const float* offp = nullptr;
@@ -170,6 +172,7 @@ extern "C" int mmsa_ms_deform_attn_forward(const float* value, const int64_t* sp
     return MMSA_OK;
   }
   const long threads = (long)batch * num_query * num_heads * (channels >> 2);
+  MMSA_CHECK_ARG(threads < (1L << 31), "ms_deform_attn_forward: problem too large for the 32-bit index arithmetic");
   hipLaunchKernelGGL(msda_kernel<false>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, value, spatial_shapes,
                      level_start_index, sampling_loc, attn_weight, nullptr, 0L, nullptr, out,
                      (long)num_heads * channels, nullptr, 0L, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
@@ -196,6 +199,7 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
   MMSA_CHECK_ARG((channels & 3) == 0 && channels <= 1024 && 256 % (channels >> 2) == 0, "msda_fused: channels per head D=%d must be a multiple of 4 with 256 %% (D/4) == 0", channels);
   MMSA_CHECK_ARG(((((uintptr_t)value) | ((uintptr_t)out)) & 15) == 0, "msda_fused: value/out must be 16-byte aligned");
   const long threads = (long)batch * num_query * num_heads * (channels >> 2);
+  MMSA_CHECK_ARG(threads < (1L << 31), "msda_fused: problem too large for the 32-bit index arithmetic");
   hipLaunchKernelGGL(msda_kernel<true>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, value, spatial_shapes,
                      level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, batch, spatial_size,
                      num_heads, channels, num_levels, num_query, num_point);

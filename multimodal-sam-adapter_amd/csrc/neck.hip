@@ -184,10 +184,11 @@ extern "C" int mmsa_gffm_build(const float* E, unsigned short* xp, unsigned shor
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
                                                         int C, long total4) {
-  const int c4n = C >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const long row = i / c4n;
+  const unsigned c4n = C >> 2;   // 32-bit index arithmetic (total4 < 2^32, checked by the launcher): 64-bit div/mod cost more than the op
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total4; i += gridDim.x * blockDim.x) {
+    const unsigned rowu = i / c4n;
+    const int c = (int)(i - rowu * c4n) * 4;
+    const long row = rowu;
     const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
     const float4 g = *reinterpret_cast<const float4*>(x + row * ldx + C + c);
     float4 o;
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* __restrict_
 extern "C" int mmsa_gelu_gate(const float* x, long ldx, float* y, long ldy, long rows, int C, hipStream_t stream) {
   MMSA_CHECK_ARG(x && y && rows > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0, "gelu_gate: bad args");
   const long total4 = rows * (C >> 2);
+  MMSA_CHECK_ARG(total4 < (1L << 31), "gelu_gate: too many elements for the 32-bit index arithmetic");
   int blocks = cdiv(total4, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(gelu_gate_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, C, total4);
@@ -239,14 +241,15 @@ extern "C" int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int 
 // out = z + z * a_w[b,w,c] * a_h[b,h,c];  att: [B, H+W, C] rows 0..H-1 = a_h, H.. = a_w
 __global__ __launch_bounds__(256) void ca_apply_kernel(const float* __restrict__ z, long ldz, const float* __restrict__ att, long lda,
                                                        float* __restrict__ out, long ldo, int H, int W, int C, long total4) {
-  const int c4n = C >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const long row = i / c4n;
-    const int w = (int)(row % W);
-    const long t = row / W;
-    const int h = (int)(t % H);
-    const int b = (int)(t / H);
+  const unsigned c4n = C >> 2;   // 32-bit index arithmetic (total4 < 2^32, checked by the launcher)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total4; i += gridDim.x * blockDim.x) {
+    const unsigned rowu = i / c4n;
+    const int c = (int)(i - rowu * c4n) * 4;
+    const long row = rowu;
+    const unsigned t = rowu / (unsigned)W;
+    const int w = (int)(rowu - t * (unsigned)W);
+    const int b = (int)(t / (unsigned)H);
+    const int h = (int)(t - (unsigned)b * (unsigned)H);
     const float4 v = *reinterpret_cast<const float4*>(z + row * ldz + c);
     const float4 ah = *reinterpret_cast<const float4*>(att + ((long)b * (H + W) + h) * lda + c);
     const float4 aw = *reinterpret_cast<const float4*>(att + ((long)b * (H + W) + H + w) * lda + c);
@@ -263,6 +266,7 @@ extern "C" int mmsa_ca_apply(const float* z, long ldz, const float* att, long ld
                              int B, int H, int W, int C, hipStream_t stream) {
   MMSA_CHECK_ARG(z && att && out && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && (ldo & 3) == 0, "ca_apply: bad args");
   const long total4 = (long)B * H * W * (C >> 2);
+  MMSA_CHECK_ARG(total4 < (1L << 31), "ca_apply: too many elements for the 32-bit index arithmetic");
   int blocks = cdiv(total4, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(ca_apply_kernel, dim3(blocks), dim3(256), 0, stream, z, ldz, att, lda, out, ldo, H, W, C, total4);

@@ -246,12 +246,13 @@ __global__ __launch_bounds__(256) void lnhw_apply_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, const float* __restrict__ mult,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ y, long ldy, int HW, int C, long total4) {
-  const int c4n = C >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const long row = i / c4n;
-    const int p = (int)(row % HW);
-    const int b = (int)(row / HW);
+  const unsigned c4n = C >> 2;   // 32-bit index arithmetic (total4 < 2^32, checked by the launcher)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total4; i += gridDim.x * blockDim.x) {
+    const unsigned rowu = i / c4n;
+    const int c = (int)(i - rowu * c4n) * 4;
+    const long row = rowu;
+    const int b = (int)(rowu / (unsigned)HW);
+    const int p = (int)(rowu - (unsigned)b * (unsigned)HW);
     const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
     const float4 m = *reinterpret_cast<const float4*>(mean + (long)b * C + c);
     const float4 r = *reinterpret_cast<const float4*>(rstd + (long)b * C + c);
@@ -272,6 +273,7 @@ extern "C" int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, cons
   MMSA_CHECK_ARG(x && mean && rstd && mult && w && bias && y, "lnhw_apply: null pointer");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0, "lnhw_apply: C/ld must be multiples of 4");
   const long total4 = (long)B * HW * (C >> 2);
+  MMSA_CHECK_ARG(total4 < (1L << 31), "lnhw_apply: too many elements for the 32-bit index arithmetic");
   int blocks = cdiv(total4, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(lnhw_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, mean, rstd, mult, w, bias, y, ldy, HW, C, total4);

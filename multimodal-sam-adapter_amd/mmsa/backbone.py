@@ -227,7 +227,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             b = f + f"detail_feature_extractions.{i}."
             dw = sd[b + "dwconv.weight"]  # [2C, 2, 3, 3], groups=C -> [G=C][tap][ci=2][co=2]
             lv["mlp_in"] = planes(sd[b + "project_in.weight"].reshape(2 * C, C))
-            lv["mlp_dw"] = dw.reshape(C, 2, 2, 9).permute(0, 3, 2, 1).contiguous()
+            lv["mlp_dw"] = dw.reshape(C, 2, 2, 9).permute(3, 0, 2, 1).contiguous()   # tap-major [9][g][ci][co]
             lv["mlp_out"] = planes(sd[b + "project_out.weight"].reshape(C, C))
             lv["s1"], lv["s2"] = scalar(f + f"scale_layers.{i}.scale1"), scalar(f + f"scale_layers.{i}.scale2")
             b = f + f"ca_blocks.{i}.coord_atten."
@@ -587,11 +587,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.lnhw_apply(fbuf, mean, rstd, mult, lv["lnw"], lv["lnb"], fn, B, HW)
         # gated MLP on the local branch (AM:127-132) and Scale2 (AM:279-280)
         hm = ws.get("nk_hm", P, 2 * C)
-        hd = ws.get("nk_hd", P, 2 * C)
         ops.gemm(lcat, lv["mlp_in"], hm)
-        ops.gconv(hm, lv["mlp_dw"], None, hd, B, h, w, C, 2, 2, 3)
-        hg = ws.get("nk_l", P, C)  # lcat is dead now
-        ops.gelu_gate(hd, hg, C)
+        hg = ws.planes("nk_hg", P, C)   # dw 3x3 pair conv + chunk + gelu gate fused, emitted as planes for the GEMM
+        ops.dwpair_gate(hm, lv["mlp_dw"], None, B, h, w, C, out_planes=hg)
         z = ws.get("nk_f", P, C)  # fbuf is dead now
         ops.gemm(hg, lv["mlp_out"], z, alpha=lv["s2"], resid=fn, beta=lv["s1"])
         # CoordinateAttention (AM:187-201) + residual (AM:218-221)

@@ -295,6 +295,19 @@ def gconv(x, w, bias, out, b, h, wd, groups, cin_g, cout_g, k, act="none"):
     return out
 
 
+def dwpair_gate(x, w_tap, out, b, h, wd, c, out_planes=None):
+    """Neck Mlp middle (AM:127-132): gelu(dw3x3(x)[:, :C]) * dw3x3(x)[:, C:]; weights tap-major [9, C, 2, 2]."""
+    px, _, _, ldx = _mat(x, "x")
+    po, ldo = (None, 0)
+    if out is not None:
+        po, _, _, ldo = _mat(out, "y")
+    pp, ldp = (None, 0)
+    if out_planes is not None:
+        pp, _, _, ldp = out_planes.mat("y planes")
+    lib.call("mmsa_dwpair_gate", px, ldx, _chk(w_tap), po, ldo, pp, ldp, b, h, wd, c, _stream())
+    return out if out is not None else out_planes
+
+
 def im2col_nchw(x, c0, cin, p, out):
     b, ctot, h, w = x.shape
     if not x.is_contiguous():
