@@ -64,7 +64,7 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
 
 /* --- GEMM (replaces F.linear / 1x1 conv / patchify conv / ConvTranspose2d 2x2 s2) ---------------------------
  * C = beta*resid + colscale[n] * alpha * act(A[M,K] W[N,K]^T + bias[n]); batch > 1 = strided batched (strides in
- * elements; strideW / strideBias may be 0 to share).  K % 32 == 0.  resid_mod > 0: residual row = row % resid_mod
+ * elements; strideW / strideBias may be 0 to share; colscale, when given, uses strideBias too).  K % 32 == 0.  resid_mod > 0: residual row = row % resid_mod
  * (broadcast over the batch, e.g. pos_embed).  out_mode 1 = 2x2 pixel-shuffle store for ConvTranspose2d(k=2,s=2)
  * (BK:55,324): row (b,h,w), column (i,j,co) -> row (b,2h+i,2w+j), column co; resid uses the destination index.
  * Call sites replaced: IE:488,499,162-167; TC:107-111,297-304,328-335; AM:947-950,447-451,87-89,121-126,286-290;
@@ -104,10 +104,14 @@ int mmsa_relpos_bias_planes(const uint16_t* qkv_planes, long ldq, const float* R
  * Row LayerNorm (biased variance): y = (x-mean)/sqrt(var+eps)*w + b; optional y2 = x + y.  map_mode 1 scatters
  * token (b,h,w) of an [B,map_H,map_W] grid to row (b,h/2,w/2), column block (h&1)*2+(w&1) (the im2col layout of
  * the ConvNeXt 2x2 s2 downsample conv, TC:328-335).  Replaces nn.LayerNorm / LN2d / WithBias_LayerNorm:
- * IE:367,377; AM:479-487,519-520,51-74; mmpretrain_custom/models/utils/norm.py:51-90. */
+ * IE:367,377; AM:479-487,519-520,51-74; mmpretrain_custom/models/utils/norm.py:51-90.
+ * Row groups (group_rows > 0; the two TwinConvNeXt streams stacked along the rows, TC:445-476): group g = row / group_rows
+ * uses w + g*w_gstride, b + g*w_gstride and writes at column offset g*y_gcol; y_wrap != 0: output row = row % group_rows
+ * (channel-concatenation of the two streams' stage outputs, TC:466-472).  group_rows = 0: one group. */
 int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps, float* y, long ldy,
                         float* y2, long ldy2, uint16_t* y_planes, long ldp /* optional interleaved planes of y */,
-                        int rows, int C, int map_mode, int map_H, int map_W, mmsa_stream_t stream);
+                        int rows, int C, int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol,
+                        int y_wrap, mmsa_stream_t stream);
 
 /* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
 int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C, double* out,
@@ -126,7 +130,8 @@ int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rs
  * im2col_nchw: out[(b,ph,pw)][(c,kh,kw)] from NCHW input channels [c0, c0+Cin) (IE:658-663, TC:297-304). */
 int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y, long ldy,
                      long ystrideB, uint16_t* y_planes, long ldp, long pstrideB /* optional interleaved planes */,
-                     int B, int H, int W, int C, int k, int act, mmsa_stream_t stream);
+                     int B, int H, int W, int C, int k, int act,
+                     int imgs_per_group /* > 0: image group g = b / imgs_per_group uses w + g*k*k*C, bias + g*C */, mmsa_stream_t stream);
 int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
                     int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);
 /* gated pair stage of the neck Mlp (AM:127-132): y = gelu(dw3x3(x)[:, :C]) * dw3x3(x)[:, C:], x token-major [B*H*W, 2C], the
@@ -146,8 +151,8 @@ int mmsa_gffm_build(const float* E, uint16_t* x_planes, uint16_t* y_planes /* [B
                     int cpad, mmsa_stream_t stream);
 int mmsa_gelu_gate(const float* x, long ldx, float* y, long ldy, long rows, int C, mmsa_stream_t stream);
 int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int B, int H, int W, int C, mmsa_stream_t stream);
-int mmsa_ca_apply(const float* z, long ldz, const float* att, long lda, float* out, long ldo, int B, int H, int W,
-                  int C, mmsa_stream_t stream);
+int mmsa_ca_apply(const float* z, long ldz, const float* att, long lda, float* out, long ldo,
+                  uint16_t* out_planes, long ldp /* optional interleaved planes */, int B, int H, int W, int C, mmsa_stream_t stream);
 
 /* --- tail (BK:316-337): out NCHW [B,C,Hc,Wc] = (cmap + bilinear(xtok)) * bn_scale + bn_shift; cmap image b starts at b*cstrideB --- */
 int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok, long ldx, const float* bn_scale,

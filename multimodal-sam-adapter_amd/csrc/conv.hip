@@ -56,8 +56,13 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
 __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restrict__ x, long ldx, long xstrideB,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ y, long ldy, long ystrideB,
-                                                            int H, int W, int C, int tilesX) {
+                                                            int H, int W, int C, int tilesX, int imgs_per_group, long w_gstride) {
   constexpr int TW = 14, CB = 64;
+  if (imgs_per_group > 0) {   // image groups (the two ConvNeXt streams stacked along the batch) with their own weights
+    const int grp = blockIdx.z / imgs_per_group;
+    w += (long)grp * w_gstride;
+    if (bias) bias += (long)grp * C;
+  }
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [14][14][64]
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * CB;
@@ -120,18 +125,20 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
 
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
                                 float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB,
-                                int B, int H, int W, int C, int k, int act, hipStream_t stream) {
+                                int B, int H, int W, int C, int k, int act, int imgs_per_group, hipStream_t stream) {
   MMSA_CHECK_ARG(x && w && (y || yp) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
+  MMSA_CHECK_ARG(imgs_per_group >= 0 && (imgs_per_group == 0 || B % imgs_per_group == 0), "dwconv_nhwc: bad image grouping");
   MMSA_CHECK_ARG(!yp || ((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0 && (pstrideB & 63) == 0), "dwconv_nhwc: bad output planes");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "dwconv_nhwc: odd kernel <= 7 expected, got %d", k);
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (xstrideB & 3) == 0 && (ystrideB & 3) == 0, "dwconv_nhwc: C/ld must be multiples of 4");
   if (k == 7 && y && !yp && act == ACT_NONE && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)bias)) & 15) == 0) {
     const int tx = cdiv(W, 8), ty = cdiv(H, 8);
     dim3 grid(tx * ty, cdiv(C, 64), B);
-    hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, H, W, C, tx);
+    hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, H, W, C, tx, imgs_per_group, (long)k * k * C);
     MMSA_CHECK_LAUNCH("dwconv_nhwc(7x7 tiled)");
     return MMSA_OK;
   }
+  MMSA_CHECK_ARG(imgs_per_group == 0 || imgs_per_group == B, "dwconv_nhwc: image groups are implemented by the tiled 7x7 kernel only");
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
   hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, B, H, W, C, k, act);
   MMSA_CHECK_LAUNCH("dwconv_nhwc");
@@ -194,13 +201,25 @@ __global__ __launch_bounds__(256) void gconv_tiled_kernel(const float* __restric
   for (int ci0 = 0; ci0 < cin_g; ci0 += CCH) {
     const int nch = min(CCH, cin_g - ci0);
     __syncthreads();
-    for (int i = threadIdx.x; i < TW * TW * nch; i += 256) {
-      const int ci = i % nch, pos = i / nch;
-      const int ly = pos / TW, lx = pos - ly * TW;
-      const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
-      float v = 0.f;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xb[((long)iy * W + ix) * ldx + ci0 + ci];
-      tile[ci][pos] = v;
+    {   // all loads of a lane in flight before the first LDS write (a rolled load -> store loop serialised ~11 global
+        // round trips per chunk and was most of the kernel's time)
+      constexpr int NIT = (TW * TW * CCH + 255) / 256;
+      float v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int ci = i & (CCH - 1), pos = i >> 3;
+        const int ly = pos / TW, lx = pos - ly * TW;
+        const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+        v[it] = 0.f;
+        if (pos < TW * TW && ci < nch && iy >= 0 && iy < H && ix >= 0 && ix < W) v[it] = xb[((long)iy * W + ix) * ldx + ci0 + ci];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int ci = i & (CCH - 1), pos = i >> 3;
+        if (pos < TW * TW) tile[ci][pos] = v[it];
+      }
     }
     __syncthreads();
     for (int ci = 0; ci < nch; ++ci) {

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
 
   // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. +3]
   const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
+  const float* colscale = a.colscale ? a.colscale + (long)bz * a.strideBias : nullptr;   // per-column vectors share the batch stride
   const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
   float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
   unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
       int ci = nn;
       if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
       bv[ni][r] = bias ? bias[nn] : 0.f;
-      cv[ni][r] = a.colscale ? a.colscale[ci] * a.alpha : a.alpha;
+      cv[ni][r] = colscale ? colscale[ci] * a.alpha : a.alpha;
     }
   // ROLLED over the four 16-row sub-tiles (the code always takes accumulator column 0, the columns are then rotated down
   // by register moves), one activation branch per 4 values: fully unrolled with the activation switch expanded per

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       const int rt = tile - bz * per_b;
       const int m0 = (rt / a.nbn) * V2_BM, n0 = (rt % a.nbn) * V2_BN;
       const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
+      const float* colscale = a.colscale ? a.colscale + (long)bz * a.strideBias : nullptr;   // per-column vectors share the batch stride
       const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
       float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
       unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
         int ci = min(n + r, a.N - 1);
         bv[r] = bias ? bias[ci] : 0.f;
         if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-        cv[r] = a.colscale ? a.colscale[ci] * a.alpha : a.alpha;
+        cv[r] = colscale ? colscale[ci] * a.alpha : a.alpha;
       }
       // row mapping (destination row / column, residual row); identity unless GEN
       auto map_row = [&](int m, int nn, long& drow_, int& dcol, long& rrow) {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
               int ci = n + r;
               const float b_ = bias ? bias[ci] : 0.f;
               if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-              x = apply_act(x + b_, act) * (a.colscale ? a.colscale[ci] * a.alpha : a.alpha);
+              x = apply_act(x + b_, act) * (colscale ? colscale[ci] * a.alpha : a.alpha);
             }
             long drow_, rrow; int dcol;
             map_row(m, n + r, drow_, dcol, rrow);
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
               int ci = n + r;
               const float b_ = bias ? bias[ci] : 0.f;
               if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-              x = apply_act(x + b_, act) * (a.colscale ? a.colscale[ci] * a.alpha : a.alpha);
+              x = apply_act(x + b_, act) * (colscale ? colscale[ci] * a.alpha : a.alpha);
             }
             long drow_, rrow; int dcol;
             map_row(m, n + r, drow_, dcol, rrow);
@@ -477,6 +478,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
       return MMSA_ERR_LAUNCH;
     }
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (getenv("MMSA_GEMM_MAX_GRID")) g_num_cus = atoi(getenv("MMSA_GEMM_MAX_GRID"));   // experiment: leave CUs to concurrent streams
     (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);

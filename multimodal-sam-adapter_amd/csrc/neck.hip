@@ -240,7 +240,8 @@ extern "C" int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int 
 
 // out = z + z * a_w[b,w,c] * a_h[b,h,c];  att: [B, H+W, C] rows 0..H-1 = a_h, H.. = a_w
 __global__ __launch_bounds__(256) void ca_apply_kernel(const float* __restrict__ z, long ldz, const float* __restrict__ att, long lda,
-                                                       float* __restrict__ out, long ldo, int H, int W, int C, long total4) {
+                                                       float* __restrict__ out, long ldo, unsigned short* __restrict__ outp, long ldp,
+                                                       int H, int W, int C, long total4) {
   const unsigned c4n = C >> 2;   // 32-bit index arithmetic (total4 < 2^32, checked by the launcher)
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total4; i += gridDim.x * blockDim.x) {
     const unsigned rowu = i / c4n;
@@ -258,18 +259,26 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(const float* __restrict__
     o.y = v.y + v.y * aw.y * ah.y;
     o.z = v.z + v.z * aw.z * ah.z;
     o.w = v.w + v.w * aw.w * ah.w;
-    *reinterpret_cast<float4*>(out + row * ldo + c) = o;
+    if (out) *reinterpret_cast<float4*>(out + row * ldo + c) = o;
+    if (outp) {
+      uint2 h2, l2;
+      split4(o, h2, l2);
+      unsigned short* q_ = outp + row * ldp + ilv(c);
+      *reinterpret_cast<uint2*>(q_) = h2;
+      *reinterpret_cast<uint2*>(q_ + 32) = l2;
+    }
   }
 }
 
 extern "C" int mmsa_ca_apply(const float* z, long ldz, const float* att, long lda, float* out, long ldo,
-                             int B, int H, int W, int C, hipStream_t stream) {
-  MMSA_CHECK_ARG(z && att && out && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && (ldo & 3) == 0, "ca_apply: bad args");
+                             unsigned short* out_planes, long ldp, int B, int H, int W, int C, hipStream_t stream) {
+  MMSA_CHECK_ARG(z && att && (out || out_planes) && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && (ldo & 3) == 0, "ca_apply: bad args");
+  MMSA_CHECK_ARG(!out_planes || ((((uintptr_t)out_planes) & 127) == 0 && (ldp & 63) == 0 && ldp >= 2L * ((C + 31) / 32 * 32)), "ca_apply: bad output planes");
   const long total4 = (long)B * H * W * (C >> 2);
   MMSA_CHECK_ARG(total4 < (1L << 31), "ca_apply: too many elements for the 32-bit index arithmetic");
   int blocks = cdiv(total4, 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(ca_apply_kernel, dim3(blocks), dim3(256), 0, stream, z, ldz, att, lda, out, ldo, H, W, C, total4);
+  hipLaunchKernelGGL(ca_apply_kernel, dim3(blocks), dim3(256), 0, stream, z, ldz, att, lda, out, ldo, out_planes, ldp, H, W, C, total4);
   MMSA_CHECK_LAUNCH("ca_apply");
   return MMSA_OK;
 }

@@ -14,10 +14,15 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b, float eps,
     float* __restrict__ y, long ldy, float* __restrict__ y2, long ldy2,
     unsigned short* __restrict__ yp, long ldp, int rows, int C,
-    int map_mode, int map_H, int map_W) {
+    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  // row groups (the two ConvNeXt streams stacked along the rows): group g = row / group_rows has its own weight /
+  // bias vectors (w + g * w_gstride) and writes at column offset g * y_gcol; y_wrap: output row = row % group_rows
+  const int grp = group_rows > 0 ? row / group_rows : 0;
+  w += (long)grp * w_gstride;
+  b += (long)grp * w_gstride;
   const float* xr = x + (long)row * ldx;
   float4 v[NV];
   float s = 0.f;
@@ -42,15 +47,15 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-  long orow = row;
-  long ocol = 0;
+  long orow = (group_rows > 0 && y_wrap) ? row - grp * group_rows : row;
+  long ocol = (long)grp * y_gcol;
   if (map_mode == 1) {  // 2x2 patchify: token (b,h,w) -> row (b,h/2,w/2), column block (h&1)*2+(w&1)
     const int ww = row % map_W;
     const int t = row / map_W;
     const int hh = t % map_H;
     const int bb = t / map_H;
     orow = ((long)bb * (map_H / 2) + (hh >> 1)) * (map_W / 2) + (ww >> 1);
-    ocol = (long)(((hh & 1) << 1) | (ww & 1)) * C;
+    ocol += (long)(((hh & 1) << 1) | (ww & 1)) * C;
   }
   float* yr = y ? y + orow * ldy + ocol : nullptr;
   float* y2r = y2 ? y2 + (long)row * ldy2 : nullptr;
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps,
                                    float* y, long ldy, float* y2, long ldy2,
                                    unsigned short* yp, long ldp, int rows, int C,
-                                   int map_mode, int map_H, int map_W, hipStream_t stream) {
+                                   int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap,
+                                   hipStream_t stream) {
   MMSA_CHECK_ARG(x && w && b && (y || yp) && rows > 0 && C > 0, "layernorm_rows: bad args");
   MMSA_CHECK_ARG(!yp || map_mode == 0 || C % 32 == 0, "layernorm_rows: patchified planes need C %% 32 == 0");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy2 & 3) == 0 && (ldp & 3) == 0, "layernorm_rows: C/ld must be multiples of 4");
@@ -94,8 +100,11 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
   MMSA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)b) | ((uintptr_t)y2)) & 15) == 0, "layernorm_rows: pointers must be 16-byte aligned");
   if (map_mode == 1) MMSA_CHECK_ARG(map_H > 0 && map_W > 0 && (map_H & 1) == 0 && (map_W & 1) == 0 && rows % (map_H * map_W) == 0 && y2 == nullptr,
                                     "layernorm_rows: patchify map needs even H,W");
+  MMSA_CHECK_ARG(group_rows >= 0 && (group_rows == 0 || (rows % group_rows == 0 && (w_gstride & 3) == 0 && (y_gcol & 3) == 0 && (!yp || (y_gcol & 31) == 0))),
+                 "layernorm_rows: bad row grouping");
+  MMSA_CHECK_ARG(group_rows == 0 || map_mode == 0 || (group_rows % (map_H * map_W) == 0 && y_wrap == 0 && y_gcol == 0), "layernorm_rows: grouping with patchify needs whole images per group");
   dim3 grid(cdiv(rows, 4)), block(256);
-#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W)
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap)
   if (C <= 256) LN_LAUNCH(1);
   else if (C <= 512) LN_LAUNCH(2);
   else if (C <= 1024) LN_LAUNCH(4);

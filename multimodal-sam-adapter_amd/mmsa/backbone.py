@@ -191,6 +191,23 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 st["stages"].append(blks)
                 st["out_norm"].append((sd[t + f"norm_{s}{i}.weight"], sd[t + f"norm_{s}{i}.bias"]))
             pk["twin"][s] = st
+        # both streams stacked along a leading batch dimension: the two ConvNeXt chains run as ONE chain of batched kernels
+        # (per-batch weights), see _twin_batched
+        def stack2(fx, fy):
+            if isinstance(fx, ops.Planes):
+                buf = torch.cat([fx.p, fy.p], 0).contiguous()
+                pl = ops.Planes(buf[:fx.n], fx.n, fx.k, fx.kpad)
+                pl.full = buf           # keeps the second batch alive; batch stride = n * 2 * kpad elements
+                return pl
+            return torch.stack([fx, fy], 0).contiguous()
+
+        def merge(ax, ay):
+            if isinstance(ax, dict):
+                return {k: merge(ax[k], ay[k]) for k in ax}
+            if isinstance(ax, (list, tuple)):
+                return [merge(u, v) for u, v in zip(ax, ay)]
+            return stack2(ax, ay)
+        pk["twin2"] = merge(pk["twin"]["x"], pk["twin"]["y"])
         # --- fusion neck
         f = "spm.smart_fusion."
         pk["neck"] = []
@@ -457,84 +474,107 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         chans = self.channels
         sizes = [(H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
         tcat = [ws.get(f"tcat{i}", B * sizes[i][0] * sizes[i][1], 2 * chans[i]) for i in range(4)]
-        # The two ConvNeXt streams and the four neck levels are independent chains of mostly small launches
-        # (M = 8192 rows at 1/16 resolution fills only ~1/3 of the CUs per GEMM), so they run on separate HIP
-        # streams (fork/join with events; captured as parallel branches of the HIP graph) with private workspaces.
+        # the same maps as interleaved planes (A operand of the neck's 1x1 convs) when the per-modality width is a k-block multiple
+        tcat_p = [ws.planes(f"tcat{i}", B * sizes[i][0] * sizes[i][1], 2 * chans[i]) if chans[i] % 32 == 0 else None for i in range(4)]
+        # The ConvNeXt chain and the four neck levels are chains of mostly small launches (M = 8192 rows at 1/16 resolution
+        # fills a fraction of the CUs per GEMM), so the neck levels run on separate HIP streams (fork/join with events;
+        # captured as parallel branches of the HIP graph) with private workspaces.  Neck level i needs only the stage-i
+        # outputs, so it starts as soon as they are written: the heavy 1/4-resolution level runs underneath ConvNeXt
+        # stages 1..3 instead of after them.
         main = torch.cuda.current_stream()
-        if not getattr(self, "multistream", True):   # profiling aid: everything on the current stream
-            side = [main, main, main]
-        else:
-            if getattr(self, "_side", None) is None or self._side[0].device != x.device:
-                self._side = [torch.cuda.Stream(device=x.device) for _ in range(3)]
-            side = self._side
-        fork = torch.cuda.Event()
-        fork.record(main)
-        # --- TwinConvNeXt (TC:445-476): rgb stream on the current stream, auxiliary stream on a side stream
-        side[0].wait_event(fork)
-        with torch.cuda.stream(side[0]):
-            self._twin_stream(1, x, B, sizes, tcat)
-            ev_y = torch.cuda.Event()
-            ev_y.record(side[0])
-        self._twin_stream(0, x, B, sizes, tcat)
-        main.wait_event(ev_y)
-        # --- RoadFormer2Neck (AM:364-394) + fc1..4 (AM:947-956): level 0 here, levels 1..3 on side streams
-        ready = torch.cuda.Event()
-        ready.record(main)
+        multi = getattr(self, "multistream", True)
+        if multi:
+            if getattr(self, "_side", None) is None or len(self._side) < 4 or self._side[0].device != x.device:
+                self._side = [torch.cuda.Stream(device=x.device) for _ in range(4)]
+            s_neck = self._side[0:4]
+        else:   # profiling aid: everything on the current stream
+            s_neck = [main] * 4
+        # --- TwinConvNeXt (TC:445-476): the rgb and the auxiliary stream are ONE chain of batched kernels (batch index =
+        #     stream, per-batch weights): every launch carries twice the work of a per-stream launch.  As two concurrent
+        #     HIP streams the chains took 8.5 ms against 5.5 ms for one alone -- the persistent GEMM grids of one stream
+        #     hold the LDS of every CU, so the other stream's kernels queue behind them.
+        ev_x = []
+        self._twin_batched(x, B, sizes, tcat, ev_x, tcat_p)
+        # --- RoadFormer2Neck (AM:364-394) + fc1..4 (AM:947-956): one stream per level, gated on that level's two inputs
         offs = [0, 0, sizes[1][0] * sizes[1][1], sizes[1][0] * sizes[1][1] + sizes[2][0] * sizes[2][1]]
         joins = []
-        for i in (1, 2, 3):
-            s = side[i - 1]
-            s.wait_event(ready)
-            with torch.cuda.stream(s):
-                self._neck_level(i, pk["neck"][i], tcat[i], B, sizes[i][0], sizes[i][1], chans[i], cbuf[offs[i]:], Nc * D)
+        for i in range(4):
+            sn = s_neck[i]
+            sn.wait_event(ev_x[i])
+            with torch.cuda.stream(sn):
+                if i == 0:
+                    self._neck_level(0, pk["neck"][0], tcat[0], B, sizes[0][0], sizes[0][1], chans[0], c1_out, 0, tcat_p[0])
+                else:
+                    self._neck_level(i, pk["neck"][i], tcat[i], B, sizes[i][0], sizes[i][1], chans[i], cbuf[offs[i]:], Nc * D, tcat_p[i])
                 e = torch.cuda.Event()
-                e.record(s)
+                e.record(sn)
                 joins.append(e)
-        self._neck_level(0, pk["neck"][0], tcat[0], B, sizes[0][0], sizes[0][1], chans[0], c1_out, 0)
         for e in joins:
             main.wait_event(e)
 
-    def _twin_stream(self, si, x, B, sizes, tcat):
-        """One ConvNeXt stream (TC:451-472); writes its half of the channel-concatenated stage outputs."""
+    def _twin_batched(self, x, B, sizes, tcat, stage_events, tcat_p=None):
+        """Both ConvNeXt streams (TC:451-472) as one chain: activations stacked [2 (stream), B*h*w, c], weights [2, ...];
+        stage outputs are channel-concatenated into tcat[i] (TC:466-472) by the grouped out-norm LayerNorm."""
         pk, ws = self._packed, self._ws
         chans = self.channels
-        st = pk["twin"]["xy"[si]]
-        t = f"cn{si}_"
+        st = pk["twin2"]
+        t = "cnb_"
         h0, w0 = sizes[0]
-        a = ws.get(t + "stem_a", B * h0 * w0, st["stem"].kpad)
-        ops.im2col_nchw(x, 3 * si, 3, 4, a)
-        t0 = ws.get(t + "tmp", B * h0 * w0, chans[0])
-        ops.gemm(a, st["stem"], t0, bias=st["stem_b"])
-        cur = ws.get(t + "cur0", B * h0 * w0, chans[0])
-        ops.layernorm(t0, st["stem_nw"], st["stem_nb"], 1e-6, cur)
+        P0 = B * h0 * w0
+        kp = st["stem"].kpad
+        a = ws.get(t + "stem_a", 2 * P0, kp)
+        for si in range(2):
+            ops.im2col_nchw(x, 3 * si, 3, 4, a[si * P0:(si + 1) * P0])
+        t0 = ws.get(t + "tmp", 2 * P0, chans[0])
+        ops.gemm(a, st["stem"], t0, bias=st["stem_b"], batch=2, m=P0, stride_a=P0 * kp, stride_w=st["stem"].n * 2 * kp,
+                 stride_bias=chans[0], stride_c=P0 * chans[0])
+        cur = ws.get(t + "cur0", 2 * P0, chans[0])
+        ops.layernorm(t0, st["stem_nw"], st["stem_nb"], 1e-6, cur, group_rows=P0, w_gstride=chans[0])
         for i in range(4):
             hh, wwd = sizes[i]
             P = B * hh * wwd
             c = chans[i]
             if i >= 1:
                 ds = st["ds"][i - 1]
-                pa = ws.planes(t + "patch", P, 4 * chans[i - 1])
-                ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, out_planes=pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]))
-                cur = ws.get(t + f"cur{i}", P, c)
-                ops.gemm(pa, ds["w"], cur, bias=ds["b"])
-            d = ws.get(t + "tmp", P, c)
-            n = ws.planes(t + "n", P, c)
-            hbuf = ws.planes(t + "h", P, 4 * c)
+                cp = chans[i - 1]
+                Pp = B * sizes[i - 1][0] * sizes[i - 1][1]
+                pa = ws.planes(t + "patch", 2 * P, 4 * cp)
+                ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, out_planes=pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]),
+                              group_rows=Pp, w_gstride=cp)
+                cur = ws.get(t + f"cur{i}", 2 * P, c)
+                ops.gemm(pa, ds["w"], cur, bias=ds["b"], batch=2, m=P, stride_a=P * 2 * pa.kpad, stride_w=ds["w"].n * 2 * ds["w"].kpad,
+                         stride_bias=c, stride_c=P * c)
+            d = ws.get(t + "tmp", 2 * P, c)
+            n = ws.planes(t + "n", 2 * P, c)
+            hbuf = ws.planes(t + "h", 2 * P, 4 * c)
             for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
-                ops.dwconv(cur, blk["dw"], blk["dw_b"], d, B, hh, wwd, 7)
-                ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n)
-                ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf)
-                ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur)
+                ops.dwconv(cur, blk["dw"], blk["dw_b"], d, 2 * B, hh, wwd, 7, imgs_per_group=B)
+                ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n, group_rows=P, w_gstride=c)
+                ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf, batch=2, m=P, stride_a=P * 2 * n.kpad,
+                         stride_w=blk["pw1"].n * 2 * blk["pw1"].kpad, stride_bias=4 * c, stride_cp=P * 2 * hbuf.kpad)
+                ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur, batch=2, m=P,
+                         stride_a=P * 2 * hbuf.kpad, stride_w=blk["pw2"].n * 2 * blk["pw2"].kpad, stride_bias=c,
+                         stride_r=P * c, stride_c=P * c)
             nw, nb = st["out_norm"][i]
-            ops.layernorm(cur, nw, nb, 1e-6, tcat[i][:, si * c:(si + 1) * c])
+            ops.layernorm(cur, nw, nb, 1e-6, tcat[i], group_rows=P, w_gstride=c, y_gcol=c, y_wrap=True,
+                          out_planes=tcat_p[i] if tcat_p is not None else None)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            stage_events.append(ev)
 
-    def _neck_level(self, level, lv, t, B, h, w, c, out, out_stride_b):
+    def _neck_level(self, level, lv, t, B, h, w, c, out, out_stride_b, tp=None):
         ws = _Tagged(self._ws, f"nk{level}_")
         C = 2 * c
         HW = h * w
         P = B * HW
         gcat = ws.get("nk_g", P, C)
         lcat = ws.get("nk_l", P, C)
+        # When the per-modality width is a k-block multiple (every shipped config), the 1x1-conv operands travel as
+        # interleaved planes written by their producers (LayerNorm, GEMM epilogue, depthwise conv, ca_apply), so all of the
+        # neck's GEMMs run on the LDS-DMA kernel instead of the fp32-A one.
+        pl_ok = tp is not None and c % 32 == 0
+        gcat_p = ws.planes("nk_gp", P, C) if pl_ok else None
+        lcat_p = ws.planes("nk_lp", P, C) if pl_ok else None
         for m in range(2):
             X = t[:, m * c:(m + 1) * c]
             # GFE (AM:133-145, 75-109): x + LN(x) + proj(softmax(norm(q) norm(k)^T * temp) v) * scale2
@@ -555,14 +595,21 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             base = st.data_ptr()
             ops.chanattn_build(g, base + 8 * (3 * c), 9 * c, base + 8 * (3 * c + c), 9 * c, gp["temp"], gp["proj"], pl, B, c, 8)
             ops.gemm(q2[:, 2 * c:], pl, gcat[:, m * c:(m + 1) * c], alpha=gp["scale2"], resid=s, batch=B, m=HW,
-                     stride_a=HW * 3 * c, stride_w=c * 2 * cp, stride_r=HW * c, stride_c=HW * C)
+                     stride_a=HW * 3 * c, stride_w=c * 2 * cp, stride_r=HW * c, stride_c=HW * C,
+                     out_planes=gcat_p.cols(m * c, (m + 1) * c) if pl_ok else None, stride_cp=HW * 2 * C)
             # MobileNetV2 (AM:281-295)
             lp = lv["loc"][m]
             h1 = ws.get("nk_q1", P, 2 * c)
             h2 = ws.get("nk_q2", P, 2 * c)
-            ops.gemm(X, lp["w1"], h1, act="relu6")
-            ops.dwconv(h1, lp["dw"], None, h2, B, h, w, 3, act="relu6")
-            ops.gemm(h2, lp["w3"], lcat[:, m * c:(m + 1) * c], alpha=lp["scale"], resid=X)
+            if pl_ok:
+                ops.gemm(tp.cols(m * c, (m + 1) * c), lp["w1"], h1, act="relu6")
+                h2p = ws.planes("nk_h2p", P, 2 * c)
+                ops.dwconv(h1, lp["dw"], None, None, B, h, w, 3, act="relu6", out_planes=h2p)
+                ops.gemm(h2p, lp["w3"], alpha=lp["scale"], resid=X, out_planes=lcat_p.cols(m * c, (m + 1) * c))
+            else:
+                ops.gemm(X, lp["w1"], h1, act="relu6")
+                ops.dwconv(h1, lp["dw"], None, h2, B, h, w, 3, act="relu6")
+                ops.gemm(h2, lp["w3"], lcat[:, m * c:(m + 1) * c], alpha=lp["scale"], resid=X)
         # GFFM (AM:242-267)
         e = ws.get("nk_gram", B * c, c)
         ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1)
@@ -571,10 +618,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         py = ops.Planes(ws.get(f"nk_pp2{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
         ops.gffm_build(e, px, py, B, c)
         fbuf = ws.get("nk_f", P, C)
-        ops.gemm(gcat[:, c:], px, fbuf[:, :c], alpha=lv["gx"], resid=gcat[:, :c], batch=B, m=HW,
-                 stride_a=HW * C, stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
-        ops.gemm(gcat[:, :c], py, fbuf[:, c:], alpha=lv["gy"], resid=gcat[:, c:], batch=B, m=HW,
-                 stride_a=HW * C, stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
+        ops.gemm(gcat_p.cols(c, C) if pl_ok else gcat[:, c:], px, fbuf[:, :c], alpha=lv["gx"], resid=gcat[:, :c], batch=B, m=HW,
+                 stride_a=HW * C * (2 if pl_ok else 1), stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
+        ops.gemm(gcat_p.cols(0, c) if pl_ok else gcat[:, :c], py, fbuf[:, c:], alpha=lv["gy"], resid=gcat[:, c:], batch=B, m=HW,
+                 stride_a=HW * C * (2 if pl_ok else 1), stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
         # LayerNorm over H*W (AM:265) + FFRM (AM:158-162), one apply pass
         st = ws.get("nk_st", B * 3, C, dtype=torch.float64)
         ops.colstats(fbuf, HW * C, B, HW, st, wrow=lv["lnw"])
@@ -587,7 +634,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.lnhw_apply(fbuf, mean, rstd, mult, lv["lnw"], lv["lnb"], fn, B, HW)
         # gated MLP on the local branch (AM:127-132) and Scale2 (AM:279-280)
         hm = ws.get("nk_hm", P, 2 * C)
-        ops.gemm(lcat, lv["mlp_in"], hm)
+        ops.gemm(lcat_p if pl_ok else lcat, lv["mlp_in"], hm)
         hg = ws.planes("nk_hg", P, C)   # dw 3x3 pair conv + chunk + gelu gate fused, emitted as planes for the GEMM
         ops.dwpair_gate(hm, lv["mlp_dw"], None, B, h, w, C, out_planes=hg)
         z = ws.get("nk_f", P, C)  # fbuf is dead now
@@ -602,13 +649,19 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                  stride_a=(h + w) * lv["mip_pad"], stride_c=(h + w) * C)
         ops.gemm(y1[h:], lv["caw"], att[h:], bias=lv["caw_b"], act="sigmoid", batch=B, m=w,
                  stride_a=(h + w) * lv["mip_pad"], stride_c=(h + w) * C)
-        zo = ws.get("nk_g", P, C)  # fn is dead now
-        ops.ca_apply(z, att, zo, B, h, w)
+        if pl_ok:
+            zo = ws.planes("nk_zop", P, C)
+            ops.ca_apply(z, att, None, B, h, w, out_planes=zo)
+            sa = HW * 2 * C
+        else:
+            zo = ws.get("nk_g", P, C)  # fn is dead now
+            ops.ca_apply(z, att, zo, B, h, w)
+            sa = HW * C
         # fc_i (AM:947-956) straight into c1 / the c2|c3|c4 token buffer (level embed folded into the bias)
         if out_stride_b == 0:
             ops.gemm(zo, lv["fc"], out, bias=lv["fc_b"])
         else:
-            ops.gemm(zo, lv["fc"], out, bias=lv["fc_b"], batch=B, m=HW, stride_a=HW * C, stride_c=out_stride_b)
+            ops.gemm(zo, lv["fc"], out, bias=lv["fc_b"], batch=B, m=HW, stride_a=sa, stride_c=out_stride_b)
 
 
 class SAMAdapterbimodalMixModNewInTwinConvNEWwithcp(SAMAdapterbimodalMixModNewInTwinConvNEW):

@@ -43,11 +43,11 @@ SIGNATURES = {
     "mmsa_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, I, F, P],
     "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_relpos_bias_planes": [P, L, P, P, P, I, I, I, I, I, I, P],
-    "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, P],
+    "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, I, L, L, I, P],
     "mmsa_colstats": [P, L, L, P, I, I, I, P, P],
     "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P, P],
     "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
-    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, P],
+    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, P],
     "mmsa_dwpair_gate": [P, L, P, P, L, P, L, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],
     "mmsa_im2col_nchw": [P, I, I, I, I, I, I, I, P, I, P],
@@ -56,7 +56,7 @@ SIGNATURES = {
     "mmsa_gffm_build": [P, P, P, I, I, I, P],
     "mmsa_gelu_gate": [P, L, P, L, L, I, P],
     "mmsa_pool_hw": [P, L, P, L, I, I, I, I, P],
-    "mmsa_ca_apply": [P, L, P, L, P, L, I, I, I, I, P],
+    "mmsa_ca_apply": [P, L, P, L, P, L, P, L, I, I, I, I, P],
     "mmsa_tail_fuse": [P, L, L, P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_window_attention_planes": [P, L, P, P, P, P, L, I, I, I, I, I, I, F, P],
     "mmsa_nchw_to_planes": [P, L, P, L, I, I, L, P],

@@ -70,6 +70,12 @@ class Planes:
         """Row slice (same columns)."""
         return Planes(self.p[lo:hi], None, self.k, self.kpad)
 
+    def cols(self, lo, hi):
+        """Column slice [lo, hi) of the matrix (both multiples of 32): the k-blocks are self-contained in the layout."""
+        if lo % 32 or hi % 32:
+            raise RuntimeError("mmsa.Planes.cols: column bounds must be multiples of 32")
+        return Planes(self.p[:, 2 * lo:2 * hi], self.n, hi - lo, hi - lo)
+
     def mat(self, name):
         ptr, rows, cols, ld = _mat(self.p, name, torch.int16)
         if ptr % 128 or ld % 64:
@@ -146,7 +152,9 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     return out if out is not None else out_planes
 
 
-def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None):
+def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None, group_rows=0, w_gstride=0, y_gcol=0, y_wrap=False):
+    """Row LayerNorm.  group_rows > 0: stacked row groups with their own weights (w, b of shape [groups, C]); group g writes
+    at column offset g * y_gcol, and at row (row % group_rows) when y_wrap."""
     px, rows, c, ldx = _mat(x, "x")
     py, ldy = None, 0
     if out is not None:
@@ -159,7 +167,7 @@ def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None)
         pp, _, _, ldp = out_planes.mat("y planes")
     mh, mw = patchify or (0, 0)
     lib.call("mmsa_layernorm_rows", px, ldx, _chk(w), _chk(b), eps, py, ldy, p2, ld2, pp, ldp, rows, c,
-             1 if patchify else 0, mh, mw, _stream())
+             1 if patchify else 0, mh, mw, group_rows, w_gstride, y_gcol, 1 if y_wrap else 0, _stream())
     return out if out is not None else out_planes
 
 
@@ -272,7 +280,8 @@ def lnhw_apply(x, mean, rstd, mult, w, bias, out, b, hw):
     return out
 
 
-def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=None, out_planes=None, pstride_b=None):
+def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=None, out_planes=None, pstride_b=None,
+           imgs_per_group=0):
     """Depthwise conv; result to fp32 `out` and/or interleaved `out_planes`."""
     px, _, c, ldx = _mat(x, "x")
     po, ldo = None, 0
@@ -284,7 +293,7 @@ def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=N
     xs = h * wd * ldx if xstride_b is None else xstride_b
     ys = h * wd * ldo if ystride_b is None else ystride_b
     ps = h * wd * ldp if pstride_b is None else pstride_b
-    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, b, h, wd, c, k, ACT[act], _stream())
+    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, b, h, wd, c, k, ACT[act], imgs_per_group, _stream())
     return out if out is not None else out_planes
 
 
@@ -349,12 +358,17 @@ def pool_hw(z, out, b, h, w):
     return out
 
 
-def ca_apply(z, att, out, b, h, w):
+def ca_apply(z, att, out, b, h, w, out_planes=None):
     pz, _, c, ldz = _mat(z, "z")
     pa, _, _, lda = _mat(att, "att")
-    po, _, _, ldo = _mat(out, "out")
-    lib.call("mmsa_ca_apply", pz, ldz, pa, lda, po, ldo, b, h, w, c, _stream())
-    return out
+    po, ldo = (None, 0)
+    if out is not None:
+        po, _, _, ldo = _mat(out, "out")
+    pp, ldp = (None, 0)
+    if out_planes is not None:
+        pp, _, _, ldp = out_planes.mat("out planes")
+    lib.call("mmsa_ca_apply", pz, ldz, pa, lda, po, ldo, pp, ldp, b, h, w, c, _stream())
+    return out if out is not None else out_planes
 
 
 def tail_fuse(cmap, cstride_b, xtok, bn_scale, bn_shift, out, b, hc, wc, hx, wx):
