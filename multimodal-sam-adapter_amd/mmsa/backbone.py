@@ -364,7 +364,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # ---- spatial prior module -> c1 [B*HW/16, D], c (c2|c3|c4 + level embed) [B, Nc, D]
         c1 = ws.get("c1", B * (H // 4) * (W // 4), D)
         cbuf = ws.get("c", B * Nc, D)
-        self._spm(x, B, H, W, c1, cbuf, Nc)
+        c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
 
         # ---- patch embedding + absolute position embedding (IE:662-671, BK:268-278)
         a = ws.get("pe_a", B * T, pk["pe_w"].kpad)
@@ -382,6 +382,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
 
         # ---- tail (BK:316-337)
+        torch.cuda.current_stream().wait_event(c1_ready)
         outs = []
         c2p = ws.planes("up_a", B * n2, D)
         for bi in range(B):
@@ -509,8 +510,11 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 e = torch.cuda.Event()
                 e.record(sn)
                 joins.append(e)
-        for e in joins:
+        # c1 (level 0, the heaviest) is consumed only by the tail (BK:316-337): its stream is joined there, so it runs
+        # underneath the ViT blocks; the injectors need levels 1..3
+        for e in joins[1:]:
             main.wait_event(e)
+        return joins[0]
 
     def _twin_batched(self, x, B, sizes, tcat, stage_events, tcat_p=None):
         """Both ConvNeXt streams (TC:451-472) as one chain: activations stacked [2 (stream), B*h*w, c], weights [2, ...];

@@ -31,10 +31,13 @@ def graph_time(fn, n=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
-t_spm = graph_time(lambda: m._spm(x.contiguous().float(), B, H, W, c1, cbuf, Nc))
+def _spm_joined():
+    e = m._spm(x.contiguous().float(), B, H, W, c1, cbuf, Nc)
+    torch.cuda.current_stream().wait_event(e)
+t_spm = graph_time(_spm_joined)
 t_all = graph_time(lambda: m(x))
 m.multistream = False
-t_spm1 = graph_time(lambda: m._spm(x.contiguous().float(), B, H, W, c1, cbuf, Nc))
+t_spm1 = graph_time(_spm_joined)
 t_all1 = graph_time(lambda: m(x))
 print(f"SPM {t_spm:.2f} ms of {t_all:.2f} ms (side streams on);  SPM {t_spm1:.2f} ms of {t_all1:.2f} ms (single stream)")
 
@@ -74,7 +77,7 @@ def eager_time(fn, n=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 m.multistream = True
-print(f"eager: SPM {eager_time(lambda: m._spm(xf, B, H, W, c1, cbuf, Nc)):.2f} ms, conv {eager_time(conv_only):.2f} ms, neck {eager_time(neck_only):.2f} ms")
+print(f"eager: SPM {eager_time(_spm_joined):.2f} ms, conv {eager_time(conv_only):.2f} ms, neck {eager_time(neck_only):.2f} ms")
 
 def both_independent():
     main = torch.cuda.current_stream()
