@@ -106,6 +106,35 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 
+// GELU on 4 values with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per instruction); the two
+// transcendentals per value (v_rcp_f32, v_exp_f32) stay scalar.  Same formula as fast_erf.
+typedef __attribute__((ext_vector_type(2))) float mmsa_f2;
+__device__ __forceinline__ mmsa_f2 gelu2(mmsa_f2 x) {
+  const mmsa_f2 z = x * 0.70710678118654752440f;
+  const mmsa_f2 az = __builtin_elementwise_abs(z);
+  const mmsa_f2 d = az * 0.3275911f + 1.0f;
+  mmsa_f2 t;
+  t.x = __builtin_amdgcn_rcpf(d.x);
+  t.y = __builtin_amdgcn_rcpf(d.y);
+  mmsa_f2 p = t * 1.061405429f + (-1.453152027f);
+  p = p * t + 1.421413741f;
+  p = p * t + (-0.284496736f);
+  p = p * t + 0.254829592f;
+  p = p * t;
+  const mmsa_f2 a2 = az * az * (-1.4426950408889634f);
+  mmsa_f2 e;
+  e.x = __builtin_amdgcn_exp2f(a2.x);
+  e.y = __builtin_amdgcn_exp2f(a2.y);
+  mmsa_f2 r = 1.0f - p * e;            // erf(|z|)
+  r.x = copysignf(r.x, z.x);
+  r.y = copysignf(r.y, z.y);
+  return x * 0.5f * (r + 1.0f);
+}
+__device__ __forceinline__ float4 gelu4(float4 v) {
+  const mmsa_f2 a = gelu2((mmsa_f2){v.x, v.y}), b = gelu2((mmsa_f2){v.z, v.w});
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
     case ACT_GELU: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));  // erf-form GELU (nn.GELU default)

@@ -299,7 +299,8 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
             o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
             if (act != ACT_NONE) {   // ONE wave-uniform branch per 4 values (none when ACT is a template constant)
-              o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
+              if (act == ACT_GELU) o = gelu4(o);
+              else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
             }
             o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
             if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
             o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
             if (act != ACT_NONE) {   // ONE wave-uniform branch per 4 values (none when ACT is a template constant)
-              o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
+              if (act == ACT_GELU) o = gelu4(o);
+              else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
             }
             o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
             if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
