@@ -9,6 +9,7 @@ import torch
 
 from oracle import ref_encoder as R
 from tests.configs import CONFIGS, make_input, probe_index
+from tests.weights import seeded_state_dict
 from tests.util import assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +21,7 @@ def _build(name):
     cfg = CONFIGS[name]
     torch.manual_seed(0)
     orc = R.OracleEncoder(**cfg["kwargs"])
-    sd = R.seeded_state_dict(orc, seed=cfg["seed"])
+    sd = seeded_state_dict(orc, seed=cfg["seed"])
     orc.load_state_dict(sd)
     m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
     missing = m.load_state_dict(sd, strict=True)

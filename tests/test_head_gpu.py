@@ -9,6 +9,7 @@ import torch
 from oracle import ref_encoder as R
 from oracle import ref_head as RH
 from tests.configs import HEAD_CONFIGS, make_head_inputs, probe_index
+from tests.weights import seeded_state_dict
 from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +21,7 @@ def build(name):
     import mmsa
     cfg = HEAD_CONFIGS[name]
     orc = RH.OracleSegformerHead(**cfg["kwargs"])
-    sd = R.seeded_state_dict(orc, seed=cfg["seed"])
+    sd = seeded_state_dict(orc, seed=cfg["seed"])
     orc.load_state_dict(sd)
     head = mmsa.build_head(dict(type="SegformerHead", **cfg["kwargs"]))
     head.load_state_dict(sd)

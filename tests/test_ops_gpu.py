@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_encoder as R
+from tests.weights import seeded_state_dict
 from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -133,7 +134,7 @@ def test_colstats_ffrm_lnhw(ops):
     ln.weight.data = torch.randn(HW, generator=g(31)) * 0.2 + 1
     ln.bias.data = torch.randn(HW, generator=g(32)) * 0.1
     ffrm = R.FFRM(C)
-    sd = R.seeded_state_dict(ffrm, 3)
+    sd = seeded_state_dict(ffrm, 3)
     ffrm.load_state_dict(sd)
     with torch.no_grad():
         ref = ffrm(ln(f.view(B, C, HW)).view(B, C, H, W))
@@ -181,7 +182,7 @@ def test_msda_fused_module(ops):
     S = sum(h * w for h, w in shapes)
     Lq = 8 * 6
     mod = R.MSDeformAttn(D, L, M, Pn, 0.5)
-    sd = R.seeded_state_dict(mod, 5)
+    sd = seeded_state_dict(mod, 5)
     sd["sampling_offsets.weight"] *= 4  # push samples across the borders
     mod.load_state_dict(sd)
     q = torch.randn(B, Lq, D, generator=g(40))
@@ -220,7 +221,7 @@ def test_attention(ops, H, W, heads, hd, ws, table):
     import mmsa.backbone as bb
     B, D = 2, heads * hd
     att = R.Attention(D, heads, (table // 2 + 1, table // 2 + 1))
-    sd = R.seeded_state_dict(att, 7)
+    sd = seeded_state_dict(att, 7)
     sd["rel_pos_h"] = torch.randn(table, hd, generator=g(50)) * 0.3
     sd["rel_pos_w"] = torch.randn(table, hd, generator=g(51)) * 0.3
     sd["qkv.bias"] = torch.randn(3 * D, generator=g(52)) * 0.5  # pad tokens attend with k = v = bias
@@ -327,7 +328,7 @@ def test_gfe_module(ops, c, H, W):
     """GFE (AM:133-145): LN -> grouped qkv convs -> L2-normalised channel attention -> proj, as the backbone runs it."""
     B, HW = 2, H * W
     mod = R.GFE(c)
-    sd = R.seeded_state_dict(mod, 11)
+    sd = seeded_state_dict(mod, 11)
     mod.load_state_dict(sd)
     x = torch.randn(B, c, H, W, generator=g(91))
     with torch.no_grad():
@@ -381,7 +382,7 @@ def test_gffm_gemms(ops):
 def test_coordinate_attention_and_gate(ops):
     B, C, H, W = 2, 64, 9, 11
     ca = R.CA(C)
-    sd = R.seeded_state_dict(ca, 13)
+    sd = seeded_state_dict(ca, 13)
     ca.load_state_dict(sd)
     ca.eval()
     x = torch.randn(B, C, H, W, generator=g(93))

@@ -9,6 +9,7 @@ import torch
 
 from oracle import ref_encoder as R
 from tests.configs import CONFIGS, make_input, probe_index, weights_checksum
+from tests.weights import seeded_state_dict
 from tests.util import assert_close
 
 
@@ -62,7 +63,7 @@ def _check_model(golden_dir, name, full):
     g = _load(golden_dir, f"model_{name}.npz")
     torch.manual_seed(0)
     m = R.OracleEncoder(**cfg["kwargs"])
-    sd = R.seeded_state_dict(m, seed=cfg["seed"])
+    sd = seeded_state_dict(m, seed=cfg["seed"])
     assert abs(weights_checksum(sd) - float(g["weights_checksum"])) <= 1e-6 * float(g["weights_checksum"])
     m.load_state_dict(sd)
     x = make_input(cfg)
@@ -113,7 +114,7 @@ def test_oracle_head_matches_reference_golden(name, golden_dir):
     from tests.configs import HEAD_CONFIGS, make_head_inputs
     cfg = HEAD_CONFIGS[name]
     orc = RH.OracleSegformerHead(**cfg["kwargs"])
-    sd = R.seeded_state_dict(orc, seed=cfg["seed"])
+    sd = seeded_state_dict(orc, seed=cfg["seed"])
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     assert abs(weights_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point}) - float(gold["weights_checksum"])) < 1e-6 * float(gold["weights_checksum"])
     orc.load_state_dict(sd)

@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_encoder as R
+from tests.weights import seeded_state_dict
 from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +83,7 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table):
     import mmsa.backbone as bb
     B, D = 2, heads * hd
     att = R.Attention(D, heads, (table // 2 + 1, table // 2 + 1))
-    sd = R.seeded_state_dict(att, 7)
+    sd = seeded_state_dict(att, 7)
     sd["rel_pos_h"] = torch.randn(table, hd, generator=g(50)) * 0.3
     sd["rel_pos_w"] = torch.randn(table, hd, generator=g(51)) * 0.3
     sd["qkv.bias"] = torch.randn(3 * D, generator=g(52)) * 0.5
@@ -143,7 +144,7 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws):
     D = heads * hd
     L = 2 * ws - 1
     att = R.Attention(D, heads, (ws, ws))
-    sd = R.seeded_state_dict(att, 17)
+    sd = seeded_state_dict(att, 17)
     sd["rel_pos_h"] = torch.randn(L, hd, generator=g(70)) * 0.3
     sd["rel_pos_w"] = torch.randn(L, hd, generator=g(71)) * 0.3
     sd["qkv.bias"] = torch.randn(3 * D, generator=g(72)) * 0.5

@@ -1,0 +1,59 @@
+"""The build's deterministic "live weights" generator (SURVEY 8c fixture hygiene).  Test infrastructure shared by the golden
+generator (tools/oracle/make_golden.py, which applies it to the imported reference), the tests and smoke(): data only, no
+reference code."""
+import math
+
+import torch
+
+
+def seeded_state_dict(model, seed=0):
+    """The build's deterministic 'live weights' generator (SURVEY 8c fixture hygiene): every
+    parameter and buffer is overwritten with seeded non-trivial values so no branch is dead
+    (injector gamma, GFFM gammas, MobileNetV2 scale, rel_pos, BN running stats, MSDA
+    offset/attention weights).  Keys are visited in sorted order so the same recipe can be
+    applied to the reference model via load_state_dict."""
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    out = {}
+    for k in sorted(sd.keys()):
+        v = sd[k]
+        shp = tuple(v.shape)
+
+        def rn(std=1.0):
+            return torch.randn(shp, generator=g) * std
+        leaf = k.split(".")[-1]
+        if leaf == "num_batches_tracked":
+            out[k] = torch.zeros((), dtype=torch.long)
+        elif leaf == "running_var":
+            out[k] = 0.5 + torch.rand(shp, generator=g)
+        elif leaf == "running_mean":
+            out[k] = rn(0.1)
+        elif "sampling_offsets" in k and leaf == "bias":
+            out[k] = v.clone()  # keep ring init (+-1..+-4 px)
+        elif "sampling_offsets" in k and leaf == "weight":
+            out[k] = rn(0.05)
+        elif "attention_weights" in k:
+            out[k] = rn(0.05) if leaf == "weight" else rn(0.5)
+        elif leaf in ("rel_pos_h", "rel_pos_w"):
+            out[k] = rn(0.05)
+        elif k in ("pos_embed", "level_embed"):
+            out[k] = rn(0.3)
+        elif leaf == "gamma" and "injector" in k:
+            out[k] = 0.5 + 0.2 * torch.rand(shp, generator=g)
+        elif leaf == "gamma":  # ConvNeXt layer scale
+            out[k] = 0.2 + 0.2 * torch.rand(shp, generator=g)
+        elif leaf in ("scale", "scale1", "scale2") and v.ndim == 0:
+            out[k] = torch.tensor(0.6) + 0.3 * torch.rand((), generator=g)
+        elif leaf == "scale":  # AttentionBase per-head temperature [8,1,1]
+            out[k] = 0.8 + 0.4 * torch.rand(shp, generator=g)
+        elif leaf == "weight" and v.ndim == 1:  # norm weights
+            out[k] = 1.0 + rn(0.1)
+        elif leaf == "bias":
+            out[k] = rn(0.05)
+        elif leaf == "weight":
+            fan_in = v[0].numel()
+            out[k] = rn(0.7 / math.sqrt(max(fan_in, 1)))
+        else:
+            out[k] = rn(0.1)
+        out[k] = out[k].to(v.dtype)
+    return out

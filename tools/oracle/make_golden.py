@@ -3,7 +3,7 @@ tools/oracle/ref_import.py) in the build container.  Output: tests/golden/*.npz 
 inputs, seeds, expected outputs).  Re-run:  python tools/oracle/make_golden.py [--big]
 
 Weights are not stored: they come from the build's deterministic generator
-`oracle.ref_encoder.seeded_state_dict(model, seed)` applied to the reference model with
+`tests.weights.seeded_state_dict(model, seed)` applied to the reference model with
 load_state_dict; a checksum of the generated weights is stored so drift is detected.
 """
 import argparse
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
 
 import ref_import  # noqa: E402
-from oracle import ref_encoder as R  # noqa: E402
+from tests.weights import seeded_state_dict  # noqa: E402
 from tests.configs import CONFIGS, HEAD_CONFIGS, make_head_inputs, make_input, weights_checksum, probe_index  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -82,7 +82,7 @@ def gen_model(name, full):
     ref = ref_import.build_reference(**cfg["kwargs"])
     keys = list(ref.state_dict().keys())
     shapes = [list(v.shape) for v in ref.state_dict().values()]
-    sd = R.seeded_state_dict(ref, seed=cfg["seed"])
+    sd = seeded_state_dict(ref, seed=cfg["seed"])
     ref.load_state_dict(sd)
     x = make_input(cfg)
     with torch.no_grad():
@@ -114,7 +114,7 @@ def gen_head(name, full):
     """Reference SegformerHead (imported unmodified; see ref_import.build_reference_head) on seeded weights + inputs."""
     cfg = HEAD_CONFIGS[name]
     ref = ref_import.build_reference_head(**cfg["kwargs"])
-    sd = R.seeded_state_dict(ref, seed=cfg["seed"])
+    sd = seeded_state_dict(ref, seed=cfg["seed"])
     ref.load_state_dict(sd)
     xs = make_head_inputs(cfg)
     with torch.no_grad():
