@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
     for (int v = 0; v < 2; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int pbeg = blockIdx.y * GR_ROWS + wave * (GR_ROWS / 4);
   const int pend = min(P, pbeg + GR_ROWS / 4);
+  // unrolled x8 so that 32 independent loads are in flight per lane (rolled, every iteration waited for its own 4 loads)
+#pragma unroll 8
   for (int pb = pbeg; pb < pend; pb += 4) {   // wave-uniform trip count (MFMA needs full EXEC)
     const int p = pb + kk;
     const bool vp = p < pend;  // pend - pbeg may not be a multiple of 4

@@ -9,14 +9,17 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
-template <int NV>
+// RPW = rows per wave: 1 (64 lanes x NV float4 per row) or 2 (C <= 128: two rows per wave, 32 lanes each -- with one row per
+// wave a 96-channel row kept 24 of 64 lanes busy)
+template <int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b, float eps,
     float* __restrict__ y, long ldy, float* __restrict__ y2, long ldy2,
     unsigned short* __restrict__ yp, long ldp, int rows, int C,
     int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int LPR = 64 / RPW;                       // lanes per row
+  const int lane = threadIdx.x & (LPR - 1);
+  const int row = blockIdx.x * (4 * RPW) + (threadIdx.x / LPR);
   if (row >= rows) return;
   // row groups (the two ConvNeXt streams stacked along the rows): group g = row / group_rows has its own weight /
   // bias vectors (w + g * w_gstride) and writes at column offset g * y_gcol; y_wrap: output row = row % group_rows
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
+    const int c = (lane + LPR * i) * 4;
     if (c < C) {
       v[i] = *reinterpret_cast<const float4*>(xr + c);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -36,17 +39,17 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+  const float mean = (RPW == 1 ? wave_sum(s) : half_wave_sum(s)) / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
+    const int c = (lane + LPR * i) * 4;
     if (c < C) {
       const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
       q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  const float rstd = 1.0f / sqrtf((RPW == 1 ? wave_sum(q) : half_wave_sum(q)) / (float)C + eps);
   long orow = (group_rows > 0 && y_wrap) ? row - grp * group_rows : row;
   long ocol = (long)grp * y_gcol;
   if (map_mode == 1) {  // 2x2 patchify: token (b,h,w) -> row (b,h/2,w/2), column block (h&1)*2+(w&1)
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   unsigned short* pr = yp ? yp + orow * ldp : nullptr;   // ilv planes row (ocol is a multiple of 32 when patchifying)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
+    const int c = (lane + LPR * i) * 4;
     if (c < C) {
       const float4 ww = *reinterpret_cast<const float4*>(w + c);
       const float4 bb = *reinterpret_cast<const float4*>(b + c);
@@ -103,9 +106,11 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
   MMSA_CHECK_ARG(group_rows >= 0 && (group_rows == 0 || (rows % group_rows == 0 && (w_gstride & 3) == 0 && (y_gcol & 3) == 0 && (!yp || (y_gcol & 31) == 0))),
                  "layernorm_rows: bad row grouping");
   MMSA_CHECK_ARG(group_rows == 0 || map_mode == 0 || (group_rows % (map_H * map_W) == 0 && y_wrap == 0 && y_gcol == 0), "layernorm_rows: grouping with patchify needs whole images per group");
-  dim3 grid(cdiv(rows, 4)), block(256);
-#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap)
-  if (C <= 256) LN_LAUNCH(1);
+  const int rpw = C <= 128 ? 2 : 1;
+  dim3 grid(cdiv(rows, 4 * rpw)), block(256);
+#define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap)
+  if (C <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<1, 2>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap);
+  else if (C <= 256) LN_LAUNCH(1);
   else if (C <= 512) LN_LAUNCH(2);
   else if (C <= 1024) LN_LAUNCH(4);
   else if (C <= 2048) LN_LAUNCH(8);
@@ -119,45 +124,56 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
 // colstats: out[b][0][c] = sum_p x, out[b][1][c] = sum_p x^2, out[b][2][c] = sum_p wrow[p]*x   (double)
 // grid (ceil(C/64), ceil(HW/ROWS_PER_BLOCK), B), block 256 = 64 channels x 4 row lanes.
 #define CS_ROWS 512
+// block 256 = 16 float4 columns (64 channels) x 16 row lanes: a wave reads 4 rows x 256 contiguous bytes per instruction
+// (the first version read one float per lane: 256 B per wave instruction)
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, long ldx, long strideB,
                                                        const float* __restrict__ wrow, int HW, int C,
                                                        double* __restrict__ out) {
-  __shared__ double red[3][4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ double red[3][16][64];
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
   const int p0 = blockIdx.y * CS_ROWS;
   const int p1 = min(p0 + CS_ROWS, HW);
   const float* xb = x + (long)blockIdx.z * strideB;
-  double d1 = 0.0, d2 = 0.0, d3 = 0.0;
-  if (c < C) {
-    for (int pb = p0 + rg; pb < p1; pb += 4 * 32) {
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) {
-        const int p = pb + 4 * k;
+  double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0}, d3[4] = {0, 0, 0, 0};
+  if (c < C) {   // C % 4 == 0
+    for (int pb = p0 + rg; pb < p1; pb += 16 * 8) {
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int p = pb + 16 * k;
         if (p < p1) {
-          const float v = xb[(long)p * ldx + c];
-          s1 += v;
-          s2 += v * v;
-          if (wrow) s3 += wrow[p] * v;
+          const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ldx + c);
+          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+          s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+          if (wrow) { const float wp = wrow[p]; s3.x += wp * v.x; s3.y += wp * v.y; s3.z += wp * v.z; s3.w += wp * v.w; }
         }
       }
-      d1 += (double)s1; d2 += (double)s2; d3 += (double)s3;
+      d1[0] += (double)s1.x; d1[1] += (double)s1.y; d1[2] += (double)s1.z; d1[3] += (double)s1.w;
+      d2[0] += (double)s2.x; d2[1] += (double)s2.y; d2[2] += (double)s2.z; d2[3] += (double)s2.w;
+      d3[0] += (double)s3.x; d3[1] += (double)s3.y; d3[2] += (double)s3.z; d3[3] += (double)s3.w;
     }
   }
-  red[0][rg][cl] = d1; red[1][rg][cl] = d2; red[2][rg][cl] = d3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][rg][c4 * 4 + j] = d1[j]; red[1][rg][c4 * 4 + j] = d2[j]; red[2][rg][c4 * 4 + j] = d3[j]; }
   __syncthreads();
-  if (rg == 0 && c < C) {
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+    const int cl = threadIdx.x;
+    double a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a1 += red[0][r][cl]; a2 += red[1][r][cl]; a3 += red[2][r][cl]; }
     double* o = out + (long)blockIdx.z * 3 * C;
-    atomicAdd(o + c, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
-    atomicAdd(o + C + c, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
-    if (wrow) atomicAdd(o + 2 * C + c, red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl]);
+    const int cc = blockIdx.x * 64 + cl;
+    atomicAdd(o + cc, a1);
+    atomicAdd(o + C + cc, a2);
+    if (wrow) atomicAdd(o + 2 * C + cc, a3);
   }
 }
 
 extern "C" int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C,
                              double* out, hipStream_t stream) {
   MMSA_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "colstats: bad args");
+  MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (strideB & 3) == 0 && (((uintptr_t)x) & 15) == 0, "colstats: C / ld must be multiples of 4, x 16-byte aligned");
   if (hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)B * C, stream) != hipSuccess) {
     mmsa_set_error("colstats: memset failed");
     return MMSA_ERR_LAUNCH;
