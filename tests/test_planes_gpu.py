@@ -165,3 +165,72 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws):
     assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws}")
     with pytest.raises(RuntimeError):
         ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, 15, hd ** -0.5)
+
+
+def test_layernorm_row_groups_and_wrap(ops):
+    """Grouped LayerNorm of the batched TwinConvNeXt chain: per-group weights, column offset + row wrap (channel concat)."""
+    P, C = 300, 96
+    x = torch.randn(2 * P, C, generator=g(80)) * 2 + 0.5
+    w, b = torch.randn(2, C, generator=g(81)), torch.randn(2, C, generator=g(82))
+    ref = torch.cat([F.layer_norm(x[:P], (C,), w[0], b[0], 1e-6), F.layer_norm(x[P:], (C,), w[1], b[1], 1e-6)], 1)   # [P, 2C]
+    out = torch.zeros(P, 2 * C, device=DEV)
+    outp = ops.alloc_planes(P, 2 * C, DEV, zero=True)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out, out_planes=outp, group_rows=P, w_gstride=C, y_gcol=C, y_wrap=True)
+    assert_close(out, ref, tol=5e-5, what="grouped LN fp32 (wrap)")
+    assert_close(planes_to_float(outp), ref, tol=5e-5, what="grouped LN planes (wrap)")
+    stacked = torch.cat([F.layer_norm(x[:P], (C,), w[0], b[0], 1e-6), F.layer_norm(x[P:], (C,), w[1], b[1], 1e-6)], 0)
+    out2 = torch.empty(2 * P, C, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out2, group_rows=P, w_gstride=C)
+    assert_close(out2, stacked, tol=5e-5, what="grouped LN stacked")
+
+
+def test_dwconv7_image_groups(ops):
+    B, H, W, C = 2, 12, 20, 64
+    convs = [torch.nn.Conv2d(C, C, 7, padding=3, groups=C) for _ in range(2)]
+    x = torch.randn(2 * B, C, H, W, generator=g(83))
+    ref = torch.cat([convs[0](x[:B]), convs[1](x[B:])], 0).detach().permute(0, 2, 3, 1).reshape(-1, C)
+    wt = torch.stack([c.weight.detach().reshape(C, 49).t().contiguous() for c in convs], 0).contiguous()   # [2, 49, C]
+    bs = torch.stack([c.bias.detach() for c in convs], 0).contiguous()
+    out = torch.empty(2 * B * H * W, C, device=DEV)
+    ops.dwconv(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), wt.to(DEV), bs.to(DEV), out, 2 * B, H, W, 7, imgs_per_group=B)
+    assert_close(out, ref, tol=5e-5, what="dwconv7 with per-group weights")
+
+
+def test_gemm_batched_per_batch_bias_and_colscale(ops):
+    M, N, K = 384, 160, 96
+    a = torch.randn(2 * M, K, generator=g(84))
+    w = torch.randn(2, N, K, generator=g(85)) / K ** 0.5
+    bias, gam, res = torch.randn(2, N, generator=g(86)), torch.randn(2, N, generator=g(87)), torch.randn(2 * M, N, generator=g(88))
+    ref = torch.cat([res[i * M:(i + 1) * M] + gam[i] * F.linear(a[i * M:(i + 1) * M].double(), w[i].double(), bias[i].double()).float()
+                     for i in range(2)], 0)
+    ap = ops.split_planes(a.to(DEV), kpad=K)
+    wp = ops.split_planes(w.reshape(2 * N, K).to(DEV))
+    wp0 = ops.Planes(wp.p[:N], N, K, wp.kpad)
+    out = torch.empty(2 * M, N, device=DEV)
+    ops.gemm(ap, wp0, out, bias=bias.to(DEV), colscale=gam.to(DEV), resid=res.to(DEV), batch=2, m=M, stride_a=M * 2 * ap.kpad,
+             stride_w=N * 2 * wp.kpad, stride_bias=N, stride_r=M * N, stride_c=M * N)
+    assert_close(out, ref, what="batched gemm, per-batch weights / bias / colscale")
+
+
+def test_dwpair_gate_and_ca_apply_planes(ops):
+    B, H, W, C = 2, 10, 14, 64
+    conv = torch.nn.Conv2d(2 * C, 2 * C, 3, padding=1, groups=C, bias=False)
+    x = torch.randn(B, 2 * C, H, W, generator=g(89))
+    y = conv(x).detach()
+    ref = (F.gelu(y[:, :C]) * y[:, C:]).permute(0, 2, 3, 1).reshape(-1, C)
+    wt = conv.weight.detach().reshape(C, 2, 2, 9).permute(3, 0, 2, 1).contiguous()   # [tap][group][ci][co]
+    out = torch.empty(B * H * W, C, device=DEV)
+    outp = ops.alloc_planes(B * H * W, C, DEV)
+    xin = x.permute(0, 2, 3, 1).reshape(-1, 2 * C).contiguous().to(DEV)
+    ops.dwpair_gate(xin, wt.to(DEV), out, B, H, W, C, out_planes=outp)
+    assert_close(out, ref, tol=5e-5, what="dwpair_gate fp32")
+    assert_close(planes_to_float(outp), ref, tol=5e-5, what="dwpair_gate planes")
+    z = torch.randn(B * H * W, C, generator=g(90))
+    att = torch.rand(B * (H + W), C, generator=g(91))
+    ah = att.view(B, H + W, C)[:, :H].reshape(B, H, 1, C)
+    aw = att.view(B, H + W, C)[:, H:].reshape(B, 1, W, C)
+    zr = z.view(B, H, W, C)
+    refz = (zr + zr * aw * ah).reshape(-1, C)
+    zp = ops.alloc_planes(B * H * W, C, DEV)
+    ops.ca_apply(z.to(DEV), att.to(DEV), None, B, H, W, out_planes=zp)
+    assert_close(planes_to_float(zp), refz, tol=5e-5, what="ca_apply planes")
