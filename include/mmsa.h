@@ -159,6 +159,14 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
                    const float* bn_shift, float* out, int B, int Hc, int Wc, int Hx, int Wx, int C,
                    mmsa_stream_t stream);
 
+/* --- global attention with the rel-pos terms computed in the kernel (Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 on a
+ *     window_size = 0 block): planes in / out as mmsa_attention_planes; relpos_planes = interleaved planes of a [256, 64] matrix, rows
+ *     0..2H-2 = rel_pos_h and rows 128..128+2W-2 = rel_pos_w (tables already resized to 2H-1 / 2W-1 rows, IE:568-575).  W = 64,
+ *     H <= 64 and a multiple of 4, head_dim 64.  No mmsa_relpos_bias pass. --- */
+int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const uint16_t* relpos_planes,
+                                 uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim, float scale,
+                                 mmsa_stream_t stream);
+
 /* --- windowed attention with the rel-pos bias fused (Block.forward IE:382-423 on a window_size > 0 block: window_partition ->
  *     Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 -> window_unpartition).  qkv / bias / out as in
  *     mmsa_attention_planes; relpos_planes = interleaved planes of a [64, 64] matrix whose rows 0..2ws-2 are the block's

@@ -29,6 +29,7 @@ struct AttnArgs {
   const unsigned short* bp;      // ilv planes form of qkv_bias [2*3D]
   unsigned short* op;            // ilv planes output (PL kernels), row stride ldo (>= 2*D)
   const float* rp;               // [B, heads, T, KH+KW] rel-pos bias terms (relpos kernel below)
+  const unsigned short* relg;    // REL kernels: planes of a [256, 64] matrix, rows 0..2KH-2 = rel_pos_h, rows 128..128+2KW-2 = rel_pos_w
   float* out; long ldo;          // [B*T, D], channel = head*HD + c (IE:498)
   int B, H, W, heads, D;
   int ws;                        // 0: global attention; >0: window size
@@ -40,7 +41,9 @@ struct AttnArgs {
   float scale;
 };
 
-template <int HD, bool PL, bool FB>
+// REL (with PL, FB, HD = 64): the rel-pos terms are computed in the kernel's prologue (MFMA, like wattn.hip) instead of being
+// read from the prepass output
+template <int HD, bool PL, bool FB, bool REL = false>
 __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
@@ -81,7 +84,9 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
   const int colq = head * HD, colk = a.D + head * HD, colv = 2 * a.D + head * HD;
 
   // ---- bias tables for the block's 128 queries -> LDS
-  if constexpr (FB) {
+  if constexpr (REL) {
+    // filled below from the Q fragments
+  } else if constexpr (FB) {
     // H-term only (KH % 4 == 0, checked by the launcher): float4 loads, four per lane IN FLIGHT before the first LDS
     // write -- the rolled load -> store loop below serialises one global round trip per element
     const int ncol = a.KH + a.KW, nf4 = a.KH >> 2, total4 = 128 * nf4;
@@ -150,7 +155,58 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
 
   // FB: W-term of the bias for this lane's fixed key columns (kw = 16t + 4G + r), pre-multiplied by log2(e)
   float bwr[2][4][4];
-  if constexpr (FB) {
+  if constexpr (REL) {
+    // T[i][q] = rel_pos[i] . q (unscaled q) for the 2K-1 relative offsets of each axis: 8 MFMA tiles per axis and sub-tile,
+    // table fragments straight from the packed planes (64 KiB, L2-resident).  Re-indexed by key coordinate
+    // (get_rel_pos IE:579-584: i = (q - k) + (K - 1)): H-term -> bh[q][kh] (LDS, read once per key block), W-term -> a
+    // temporary table in the K/V staging region, from which each lane takes the 16 values of its fixed key columns.
+    float* bwt = reinterpret_cast<float*>(smem);
+    int qc[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int tok = min(q0 + wave * 32 + sub * 16 + l15, a.Nk - 1);
+      qc[sub][0] = tok / a.W;
+      qc[sub][1] = tok - qc[sub][0] * a.W;
+    }
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+      const int Kx = ax ? a.KW : a.KH;
+      float* tab = ax ? bwt : bh;
+      const int tstr = ax ? a.KWs : a.KHs;
+#pragma unroll 2
+      for (int t = 0; t < 8; ++t) {
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const unsigned short* rr = a.relg + (long)(ax * 128 + 16 * t + l15) * 128 + 64 * ks + 8 * G;
+          const bf16x8 rh_ = *reinterpret_cast<const bf16x8*>(rr);
+          const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rr + 32);
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[sub][ks], acc[sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql_[sub][ks], acc[sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[sub][ks], acc[sub], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kc = qc[sub][ax] + (Kx - 1) - (16 * t + 4 * G + r);   // key coordinate served by table row i
+            if (kc >= 0 && kc < Kx) tab[(wave * 32 + sub * 16 + l15) * tstr + kc] = acc[sub][r];
+          }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bwr[sub][t][r] = bwt[(wave * 32 + sub * 16 + l15) * a.KWs + 16 * t + 4 * G + r] * 1.4426950408889634f;
+    __syncthreads();   // the K/V staging below overwrites the temporary table
+  } else if constexpr (FB) {
     // straight from the rel-pos prepass output (no LDS copy: the table is read exactly once per lane), which leaves
     // 36 KiB K/V + 33 KiB H-term table per workgroup = two workgroups per CU
     const float* rpb = a.rp + ((long)b * a.heads + head) * T * (a.KH + a.KW) + a.KH;
@@ -445,7 +501,10 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
     hipLaunchKernelGGL((attn_kernel<HD_, PL_, FB_>), grid, dim3(256), smem, stream, a);                                    \
   } while (0)
   if (head_dim == 64) {
-    if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
+    if (planes && a.relg) {
+      MMSA_CHECK_ARG(fb && H <= 64 && 128 * a.KWs * (int)sizeof(float) <= 2 * 8 * 64 * 16 + 2 * 64 * VSTR, "attention: the fused rel-pos path needs a W = 64, H <= 64 global grid");
+      hipLaunchKernelGGL((attn_kernel<64, true, true, true>), grid, dim3(256), smem, stream, a);
+    } else if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
     else { if (fb) ATTN_LAUNCH(64, false, true); else ATTN_LAUNCH(64, false, false); }
   } else {
     if (planes) { if (fb) ATTN_LAUNCH(32, true, true); else ATTN_LAUNCH(32, true, false); }
@@ -477,6 +536,20 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, cons
   AttnArgs a = {};
   a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo;
   return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, true, stream);
+}
+
+// global attention with the rel-pos terms computed in the kernel (no mmsa_relpos_bias pass): W = 64, H <= 64 and a multiple
+// of 4, head_dim 64.  relpos_planes: interleaved planes of a [256, 64] matrix, rows 0..2H-2 = rel_pos_h, 128..128+2W-2 = rel_pos_w
+extern "C" int mmsa_global_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p,
+                                            const unsigned short* relpos_planes, unsigned short* out_p, long ldo, int B, int H, int W,
+                                            int heads, int head_dim, float scale, hipStream_t stream) {
+  MMSA_CHECK_ARG(qkv_p && bias_p && relpos_planes && out_p, "global_attention_planes: null pointer");
+  MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)relpos_planes) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
+                 "global_attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
+  MMSA_CHECK_ARG(head_dim == 64 && W == 64 && H <= 64 && (H % 4) == 0, "global_attention_planes: needs head_dim 64 and a W = 64, H <= 64 (multiple of 4) grid");
+  AttnArgs a = {};
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo;
+  return attention_launch(a, B, H, W, heads, head_dim, 0, scale, true, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

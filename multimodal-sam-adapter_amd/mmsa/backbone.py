@@ -325,11 +325,21 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # rel-pos gather tables (IE:554-584)
         g["rel"] = []
         ws = cfg["window_size"]
+        hd_ = cfg["embed_dim"] // cfg["num_heads"]
+        g["relg"] = []
         for blk in pk["blocks"]:
+            relg = None
             if blk["ws"]:
-                g["rel"].append((_rel_table(ws, blk["rph"]), _rel_table(ws, blk["rpw"])))
+                g["rel"].append((_rel_table(ws, blk["rph"]), _rel_table(ws, blk["rpw"])) if blk.get("relp") is None else None)
+            elif hd_ == 64 and Wp == 64 and Hp <= 64 and Hp % 4 == 0:
+                # global block on a 64-wide grid: rel-pos terms computed inside the attention kernel from the packed tables
+                th = blk["rph"] if blk["rph"].shape[0] == 2 * Hp - 1 else _linear_resize_rows(blk["rph"], 2 * Hp - 1)
+                tw = blk["rpw"] if blk["rpw"].shape[0] == 2 * Wp - 1 else _linear_resize_rows(blk["rpw"], 2 * Wp - 1)
+                relg = ops.global_relpos_planes(th, tw)
+                g["rel"].append(None)
             else:
                 g["rel"].append((_rel_table(Hp, blk["rph"]), _rel_table(Wp, blk["rpw"])))
+            g["relg"].append(relg)
         pk["geom"][key] = g
         return g
 
@@ -377,7 +387,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             it = pk["inter"][i]
             self._injector(it["inj"], xs[i], xs[i + 1], cbuf, geo, B, T, Nc)
             for bi in range(idx[0], idx[-1] + 1):
-                self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp)
+                self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp, geo["relg"][bi])
             for ex in it["ext"]:
                 self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
 
@@ -401,7 +411,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         return outs, None
 
     # ------------------------------------------------------------------ SAM ViT block (IE:382-423)
-    def _block(self, bp, rel, x, B, Hp, Wp):
+    def _block(self, bp, rel, x, B, Hp, Wp, relg=None):
         ws, cfg = self._ws, self.cfg
         D, heads = cfg["embed_dim"], cfg["num_heads"]
         hd = D // heads
@@ -416,6 +426,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ao = ws.planes("blk_ao", B * T, D)
         if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
             ops.window_attention(qkv, bp["qkv_bp"], bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+        elif relg is not None:           # global block on a 64-wide grid: flash kernel with the rel-pos terms fused
+            ops.global_attention(qkv, bp["qkv_bp"], relg, ao, B, Hp, Wp, heads, hd, hd ** -0.5)
         else:
             kk = 2 * wsz if wsz else Hp + Wp
             rp = ws.get("blk_rp", B * heads * T, kk)

@@ -236,6 +236,25 @@ def window_relpos_planes(rel_pos_h, rel_pos_w, ws):
     return split_planes(m)
 
 
+def global_relpos_planes(rel_pos_h, rel_pos_w):
+    """Pack a global block's rel-pos tables (already 2H-1 / 2W-1 rows) for global_attention: [256, hd] -> Planes."""
+    if rel_pos_h.shape[0] > 127 or rel_pos_w.shape[0] > 127:
+        raise RuntimeError("mmsa.global_relpos_planes: tables must have at most 127 rows")
+    m = torch.zeros(256, rel_pos_h.shape[1], dtype=torch.float32, device=rel_pos_h.device)
+    m[:rel_pos_h.shape[0]] = rel_pos_h
+    m[128:128 + rel_pos_w.shape[0]] = rel_pos_w
+    return split_planes(m)
+
+
+def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale):
+    """Global attention with the rel-pos terms fused (planes in, planes out); W = 64, H <= 64, head_dim 64."""
+    pq, _, _, ldq = qkv.mat("qkv")
+    po, _, _, ldo = out.mat("out")
+    lib.call("mmsa_global_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relg.p, torch.int16), po, ldo,
+             b, h, w, heads, hd, scale, _stream())
+    return out
+
+
 _SELECTORS = {}
 
 

@@ -234,3 +234,30 @@ def test_dwpair_gate_and_ca_apply_planes(ops):
     zp = ops.alloc_planes(B * H * W, C, DEV)
     ops.ca_apply(z.to(DEV), att.to(DEV), None, B, H, W, out_planes=zp)
     assert_close(planes_to_float(zp), refz, tol=5e-5, what="ca_apply planes")
+
+
+@pytest.mark.parametrize("H", [64, 32])
+def test_global_attention_fused_relpos(ops, H):
+    """Global flash kernel with the rel-pos terms computed in its prologue (no prepass) vs the oracle's Attention."""
+    import mmsa.backbone as bb
+    W, heads, hd, B = 64, 2, 64, 2
+    D = heads * hd
+    att = R.Attention(D, heads, (H, W))
+    sd = seeded_state_dict(att, 27)
+    sd["rel_pos_h"] = torch.randn(2 * H - 1, hd, generator=g(92)) * 0.3
+    sd["rel_pos_w"] = torch.randn(2 * W - 1, hd, generator=g(93)) * 0.3
+    sd["qkv.bias"] = torch.randn(3 * D, generator=g(94)) * 0.5
+    att.load_state_dict(sd)
+    x = torch.randn(B, H, W, D, generator=g(95))
+    with torch.no_grad():
+        ref = att(x)
+    T = H * W
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV)
+    ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
+    relg = ops.global_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV))
+    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV), kpad=3 * D)
+    ao = ops.alloc_planes(B * T, D, DEV)
+    ops.global_attention(qkv, biasp, relg, ao, B, H, W, heads, hd, hd ** -0.5)
+    out = torch.empty(B * T, D, device=DEV)
+    ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
+    assert_close(out.view(B, H, W, D), ref, what=f"global attention fused rel-pos {H}x{W}")
