@@ -45,6 +45,9 @@ struct GemmV2Args {
 #define V2_W_BYTES (V2_BN * 128)                        // 16 KiB
 #define V2_STAGE (V2_A_BYTES + V2_W_BYTES)              // 48 KiB
 #define V2_NST 3
+#ifndef V2_SETPRIO
+#define V2_SETPRIO 0   // s_setprio(1) around the MFMA chunks: measured no effect on this kernel (same-box A/B)
+#endif
 
 #define GLDS16(gptr, lptr)                                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
@@ -156,11 +159,13 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   // barrier) are issued BETWEEN the MFMA chunks, two per chunk: an LDS-DMA costs ~100 issue cycles (M0 write, address
   // arithmetic, the instruction) which disappear under the 16-cycle passes of the MFMAs already queued.
 #define MFMA_CHUNK(ni)                                                                                      \
+  if (V2_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                            \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                        \
     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);            \
     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
-  }
+  }                                                                                                         \
+  if (V2_SETPRIO) __builtin_amdgcn_s_setprio(0);
 #define K_STEP()                                                                                            \
   {                                                                                                         \
     if (nowait > 0) --nowait;                                                                               \
