@@ -188,6 +188,15 @@ int mmsa_head_fuse(const float* z0, const float* z1, int H1, int W1, const float
                    float* out32, long ldo, int B, int H, int W, int C, int act, mmsa_stream_t stream);
 int mmsa_tokens_to_nchw(const float* src, long ld, float* dst, int B, long HW, int C, mmsa_stream_t stream);
 
+/* --- segmentor glue (segmentation/mmseg_custom/models/segmentors/encoder_decoder.py): bilinear_accum writes (accumulate = 0) or adds
+ *     (accumulate != 0) resize(src -> hc x wc, bilinear, align_corners=False) into window (y0, x0) of the NCHW canvas dst and, when count
+ *     is given, adds 1 to count[b, y, x] over the window (ED:90-94, 213-219); div_count: preds / count_mat (ED:225); argmax over C
+ *     (ED:477) -> uint8 map, first maximum wins. --- */
+int mmsa_bilinear_accum_nchw(const float* src, long src_strideB, int B, int C, int hs, int ws, float* dst, int Hd, int Wd, int y0, int x0,
+                             int hc, int wc, float* count, int accumulate, mmsa_stream_t stream);
+int mmsa_div_count_nchw(float* x, const float* count, int B, int C, long HW, mmsa_stream_t stream);
+int mmsa_argmax_nchw(const float* x, unsigned char* out, int B, int C, long HW, mmsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""Inference glue of the reference's EncoderDecoder on device (segmentation/mmseg_custom/models/segmentors/encoder_decoder.py):
+`encode_decode` (ED:85-95), `slide_inference` (ED:191-234), `whole_inference`, and the class map of `simple_test` (ED:449,477).
+
+The crops of a sliding-window frame are batched through ONE backbone + head call (the reference runs them one by one,
+ED:205-214), and the resize / pad / accumulate / count of every crop is one kernel launch on the logits canvas."""
+import torch
+
+from . import lib
+from . import ops
+
+
+def _resize_into(logits, canvas, y0, x0, hc, wc, count=None, accumulate=False):
+    b, c, hs, ws = logits.shape
+    lib.call("mmsa_bilinear_accum_nchw", logits.data_ptr(), c * hs * ws, b, c, hs, ws, canvas.data_ptr(), canvas.shape[2], canvas.shape[3],
+             y0, x0, hc, wc, count.data_ptr() if count is not None else None, 1 if accumulate else 0, ops._stream())
+
+
+def _check(img):
+    if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4:
+        raise RuntimeError("mmsa.inference: img must be a float32 [B, C, H, W] GPU tensor (there is no CPU path)")
+
+
+@torch.no_grad()
+def encode_decode(backbone, head, img):
+    """ED:85-95: logits of the head resized (bilinear, align_corners=False) to the input size -> [B, classes, H, W]."""
+    _check(img)
+    feats, _ = backbone(img)
+    lg = head(feats)
+    out = torch.empty(img.shape[0], lg.shape[1], img.shape[2], img.shape[3], device=img.device)
+    _resize_into(lg, out, 0, 0, img.shape[2], img.shape[3])
+    return out
+
+
+def crop_boxes(h_img, w_img, crop_size, stride):
+    """The window grid of ED:198-212 (windows at the right / bottom border are shifted inwards)."""
+    h_crop, w_crop = crop_size
+    h_stride, w_stride = stride
+    h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
+    w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
+    boxes = []
+    for h_idx in range(h_grids):
+        for w_idx in range(w_grids):
+            y1, x1 = h_idx * h_stride, w_idx * w_stride
+            y2, x2 = min(y1 + h_crop, h_img), min(x1 + w_crop, w_img)
+            y1, x1 = max(y2 - h_crop, 0), max(x2 - w_crop, 0)
+            boxes.append((y1, x1, y2, x2))
+    return boxes
+
+
+@torch.no_grad()
+def slide_inference(backbone, head, img, crop_size, stride, max_batch=8):
+    """ED:191-234 without the optional rescale: averaged logits [B, classes, H, W] of overlapping windows.  All windows have
+    the crop size here (the backbone needs H = W = img_size), i.e. the image must be at least as large as the crop."""
+    _check(img)
+    B, _, H, W = img.shape
+    if H < crop_size[0] or W < crop_size[1]:
+        raise RuntimeError("mmsa.slide_inference: the image must be at least as large as the crop")
+    boxes = crop_boxes(H, W, crop_size, stride)
+    preds = count = None
+    jobs = [(b, box) for box in boxes for b in range(B)]
+    for s in range(0, len(jobs), max_batch):
+        chunk = jobs[s:s + max_batch]
+        crops = torch.stack([img[b, :, y1:y2, x1:x2] for b, (y1, x1, y2, x2) in chunk], 0).contiguous()
+        feats, _ = backbone(crops)
+        lg = head(feats)                                   # [n, classes, hc/4, wc/4]
+        if preds is None:
+            preds = torch.zeros(B, lg.shape[1], H, W, device=img.device)
+            count = torch.zeros(B, H, W, device=img.device)
+        for k, (b, (y1, x1, y2, x2)) in enumerate(chunk):   # preds[b] += pad(resize(logits_k)); count[b, window] += 1
+            _resize_into(lg[k:k + 1], preds[b:b + 1], y1, x1, y2 - y1, x2 - x1, count=count[b:b + 1], accumulate=True)
+    if bool((count == 0).any()):
+        raise RuntimeError("mmsa.slide_inference: windows do not cover the image")   # ED:220
+    lib.call("mmsa_div_count_nchw", preds.data_ptr(), count.data_ptr(), B, preds.shape[1], H * W, ops._stream())
+    return preds
+
+
+@torch.no_grad()
+def whole_inference(backbone, head, img):
+    """ED: whole-image mode = encode_decode on the full input."""
+    return encode_decode(backbone, head, img)
+
+
+@torch.no_grad()
+def argmax_map(seg_logit):
+    """ED:449,477: softmax is monotonic, the prediction is the per-pixel argmax over the class axis -> uint8 [B, H, W]."""
+    _check(seg_logit)
+    seg_logit = seg_logit.contiguous()
+    B, C, H, W = seg_logit.shape
+    out = torch.empty(B, H, W, dtype=torch.uint8, device=seg_logit.device)
+    lib.call("mmsa_argmax_nchw", seg_logit.data_ptr(), out.data_ptr(), B, C, H * W, ops._stream())
+    return out

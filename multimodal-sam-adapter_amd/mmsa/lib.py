@@ -63,6 +63,9 @@ SIGNATURES = {
     "mmsa_nchw_to_planes": [P, L, P, L, I, I, L, P],
     "mmsa_head_fuse": [P, P, I, I, P, I, I, P, I, I, L, P, P, P, L, P, L, I, I, I, I, I, P],
     "mmsa_tokens_to_nchw": [P, L, P, I, L, I, P],
+    "mmsa_bilinear_accum_nchw": [P, L, I, I, I, I, P, I, I, I, I, I, I, P, I, P],
+    "mmsa_div_count_nchw": [P, P, I, I, L, P],
+    "mmsa_argmax_nchw": [P, P, I, I, L, P],
 }
 _RESTYPES = {"mmsa_last_error": c_char_p}
 

@@ -67,3 +67,16 @@ def make_head_inputs(cfg, batch=None, seed=None):
     b = batch or cfg["batch"]
     g = torch.Generator().manual_seed(cfg["in_seed"] if seed is None else seed)
     return [torch.randn(b, c, cfg["size"] >> i, cfg["size"] >> i, generator=g) for i, c in enumerate(cfg["kwargs"]["in_channels"])]
+
+
+def toy_encode_decode(num_classes, seed):
+    """Fixed seeded stand-in for encode_decode used to pin slide_inference (reference method vs oracle): a 1x1 conv on the
+    4x-downsampled crop, resized back to the crop size (the shape flow of encode_decode, ED:88-94)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(num_classes, 6, 1, 1, generator=g)
+
+    def fn(crop):
+        low = F.avg_pool2d(crop, 4)
+        return F.interpolate(F.conv2d(low, w), size=crop.shape[2:], mode="bilinear", align_corners=False)
+    return fn

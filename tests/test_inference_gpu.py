@@ -1,0 +1,74 @@
+"""GPU parity of the segmentor glue (mmsa.inference: encode_decode, slide_inference, argmax map) against the CPU oracle
+(oracle/ref_segmentor.py, pinned to the reference's own EncoderDecoder.slide_inference)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_encoder as R
+from oracle import ref_head as RH
+from oracle import ref_segmentor as RS
+from tests.configs import CONFIGS, HEAD_CONFIGS, make_input
+from tests.util import assert_close
+from tests.weights import seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def models():
+    import mmsa
+    cfg, hcfg = CONFIGS["tiny256"], HEAD_CONFIGS["head_tiny"]
+    orc = R.OracleEncoder(**cfg["kwargs"])
+    sd = seeded_state_dict(orc, seed=cfg["seed"])
+    orc.load_state_dict(sd)
+    horc = RH.OracleSegformerHead(**hcfg["kwargs"])
+    hsd = seeded_state_dict(horc, seed=hcfg["seed"])
+    horc.load_state_dict(hsd)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m.load_state_dict(sd)
+    h = mmsa.build_head(dict(type="SegformerHead", **hcfg["kwargs"]))
+    h.load_state_dict(hsd)
+    return cfg, orc, horc, m, h
+
+
+def test_bilinear_accum_div_argmax_ops():
+    import mmsa.inference as inf
+    from mmsa import lib, ops
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(2, 7, 13, 9, generator=g)
+    ref = F.interpolate(lg, size=(40, 33), mode="bilinear", align_corners=False)
+    canvas = torch.zeros(2, 7, 50, 60, device=DEV)
+    count = torch.zeros(2, 50, 60, device=DEV)
+    for _ in range(2):
+        inf._resize_into(lg.to(DEV), canvas, 6, 11, 40, 33, count=count, accumulate=True)
+    want = torch.zeros(2, 7, 50, 60)
+    want[:, :, 6:46, 11:44] = 2 * ref
+    assert_close(canvas, want, tol=1e-6, what="bilinear accumulate")
+    assert torch.equal(count.cpu()[:, 6:46, 11:44], torch.full((2, 40, 33), 2.0)) and float(count.sum()) == 2 * 2 * 40 * 33
+    inf._resize_into(lg.to(DEV), canvas, 6, 11, 40, 33)          # overwrite mode
+    assert_close(canvas[:, :, 6:46, 11:44], ref, tol=1e-6, what="bilinear write")
+    x = torch.randn(2, 7, 50, 60, generator=g)
+    x[0, 3, 0, 0] = x[0, 5, 0, 0] = 9.0                          # a tie: first maximum wins
+    am = inf.argmax_map(x.to(DEV))
+    assert am.dtype == torch.uint8 and torch.equal(am.cpu().long(), x.argmax(1))
+
+
+def test_encode_decode_and_slide_inference(models):
+    import mmsa.inference as inf
+    cfg, orc, horc, m, h = models
+    x = make_input(cfg, batch=1)
+    out = inf.encode_decode(m, h, x.to(DEV))
+    ref = RS.encode_decode(orc, horc, x)
+    assert_close(out, ref, what="encode_decode")
+    # a 320 x 400 frame, 256 x 256 windows, stride 170: 2 x 2 windows with overlaps and a shifted last column / row
+    g = torch.Generator().manual_seed(3)
+    frame = torch.randn(1, 6, 320, 400, generator=g)
+    frame[:, 3:] = (torch.rand(1, 3, 320, 400, generator=g) < 0.05).float() * torch.rand(1, 3, 320, 400, generator=g)
+    got = inf.slide_inference(m, h, frame.to(DEV), (256, 256), (170, 170), max_batch=3)
+    want = RS.slide_inference(lambda c: RS.encode_decode(orc, horc, c), frame, (256, 256), (170, 170), 7)
+    assert_close(got, want, what="slide_inference logits")
+    agree = (inf.argmax_map(got).cpu().long() == want.argmax(1)).float().mean().item()
+    assert agree > 0.999, f"class maps agree on {agree:.5f} of the pixels"
+    with pytest.raises(RuntimeError):
+        inf.slide_inference(m, h, frame[:, :, :200].to(DEV), (256, 256), (170, 170))

@@ -127,3 +127,15 @@ def test_oracle_head_matches_reference_golden(name, golden_dir):
     keys = [ln.split(" ")[0] for ln in open(os.path.join(golden_dir, "state_dict_keys_head.txt"))]
     if name == "head_tiny":
         assert list(orc.state_dict().keys()) == keys
+
+
+def test_oracle_slide_inference_matches_reference_method(golden_dir):
+    """oracle/ref_segmentor.slide_inference vs the reference's own EncoderDecoder.slide_inference (golden slide.npz)."""
+    from oracle import ref_segmentor as RS
+    from tests.configs import toy_encode_decode
+    gold = np.load(os.path.join(golden_dir, "slide.npz"))
+    for tag in "abc":
+        h, w, ch, cw, sh, sw = (int(v) for v in gold[f"{tag}_cfg"])
+        img = torch.randn(2, 6, h, w, generator=torch.Generator().manual_seed(31))
+        y = RS.slide_inference(toy_encode_decode(5, seed=77), img, (ch, cw), (sh, sw), 5)
+        assert torch.equal(y, torch.from_numpy(gold[f"{tag}_out"])) or (y - torch.from_numpy(gold[f"{tag}_out"])).abs().max() < 1e-6

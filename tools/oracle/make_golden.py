@@ -132,6 +132,21 @@ def gen_head(name, full):
     print(name, tuple(y.shape), flush=True)
 
 
+def gen_slide():
+    """The reference's own EncoderDecoder.slide_inference on a seeded frame with a fixed toy encode_decode (tests/golden/slide.npz)."""
+    from tests.configs import toy_encode_decode
+    out = {}
+    for tag, (hw, crop, stride) in dict(a=((90, 150), (64, 64), (40, 40)), b=((64, 100), (64, 64), (48, 48)), c=((70, 70), (64, 64), (64, 64))).items():
+        g = torch.Generator().manual_seed(31)
+        img = torch.randn(2, 6, hw[0], hw[1], generator=g)
+        fn = toy_encode_decode(5, seed=77)
+        y = ref_import.reference_slide_inference(fn, img, crop, stride, 5)
+        out[f"{tag}_cfg"] = np.array(list(hw) + list(crop) + list(stride))
+        out[f"{tag}_out"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, "slide.npz"), **out)
+    print("slide", {k: v.shape for k, v in out.items() if k.endswith("_out")}, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also ViT-B@512 and ViT-L@1024 (minutes, GBs of RAM)")
@@ -142,6 +157,7 @@ def main():
     gen_bookkeeping()
     for n in ("tiny224", "tiny256", "tiny320"):
         gen_model(n, full=True)
+    gen_slide()
     gen_head("head_vitl", full=False)
     gen_head("head_odd", full=True)
     gen_head("head_tiny", full=True)

@@ -276,3 +276,24 @@ def build_reference_head(**cfg):
         head = mod.SegformerHead(**cfg)
     head.eval()
     return head
+
+
+def reference_slide_inference(encode_decode_fn, img, crop_size, stride, num_classes):
+    """Run the reference's own `EncoderDecoder.slide_inference` (segmentors/encoder_decoder.py:191-234, UNMODIFIED) with a stand-in
+    `self` carrying test_cfg / num_classes / align_corners and the given encode_decode callable; rescale=False."""
+    import torch.nn as nn
+    install()
+    if "mmseg_custom.models.segmentors" not in sys.modules:
+        m = types.ModuleType("mmseg_custom.models.segmentors")
+        m.__path__ = [os.path.join(SEG, "mmseg_custom/models/segmentors")]
+        sys.modules["mmseg_custom.models.segmentors"] = m
+    import mmseg.models.segmentors.base as sb
+
+    class BaseSegmentor(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+    sb.BaseSegmentor = BaseSegmentor
+    mod = importlib.import_module("mmseg_custom.models.segmentors.encoder_decoder")
+    fake = types.SimpleNamespace(test_cfg=types.SimpleNamespace(stride=stride, crop_size=crop_size), num_classes=num_classes,
+                                 align_corners=False, encode_decode=lambda im, meta: encode_decode_fn(im))
+    return mod.EncoderDecoder.slide_inference(fake, img, [dict(ori_shape=tuple(img.shape[2:]) + (3,))], False)
