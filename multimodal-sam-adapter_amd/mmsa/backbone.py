@@ -10,6 +10,8 @@ and provides the stream.  Activations are fp32, token-major (NHWC) end to end; o
 NCHW by the fused tail kernel.  There is no CPU / PyTorch fallback."""
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -110,16 +112,50 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         self._ws = None
         self.register_load_state_dict_post_hook(lambda m, _: m.invalidate())
         self.init_weights(pretrained)
+        if isinstance(checkpoint, str) and os.path.isfile(checkpoint):   # URLs (the shipped configs) cannot be fetched here: skipped
+            self.load_convnext_checkpoint(checkpoint)
         self.eval()
 
     # ------------------------------------------------------------------ plugin surface
     def init_weights(self, pretrained=None):
-        """IE:305-315: load a (SAM) checkpoint non-strictly when a path is given."""
+        """IE:305-315: load a (SAM) checkpoint non-strictly when a path is given (the container conventions of
+        mmcv_custom/checkpoint.py:343-360: 'state_dict' / 'model' / 'module' wrappers, 'module.' and 'encoder.' prefixes)."""
         if isinstance(pretrained, str):
             ck = torch.load(pretrained, map_location="cpu")
-            sd = ck.get("state_dict", ck.get("model", ck)) if isinstance(ck, dict) else ck
-            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+            sd = ck
+            if isinstance(ck, dict):
+                for key in ("state_dict", "model", "module"):
+                    if key in ck and isinstance(ck[key], dict):
+                        sd = ck[key]
+                        break
+            if list(sd.keys())[0].startswith("module."):
+                sd = {k[7:]: v for k, v in sd.items()}
+            if sorted(sd.keys())[0].startswith("encoder"):
+                sd = {k.replace("encoder.", ""): v for k, v in sd.items() if k.startswith("encoder.")}
             self.load_state_dict(sd, strict=False)
+
+    def load_convnext_checkpoint(self, path):
+        """TwinConvNeXt.init_weights (TC:403-443): a single-stream ConvNeXt checkpoint is loaded into BOTH streams -- every key
+        gets '_x' / '_y' inserted before its first '.' ('stages.0.0.gamma' -> 'stages_x.0.0.gamma' and 'stages_y...') and is
+        loaded non-strictly, so keys that do not exist under the new name (the reference's 'norm0.weight' -> 'norm0_x.weight',
+        while its modules are called norm_x0) are skipped exactly like there.  Returns the list of twin_conv keys loaded."""
+        ck = torch.load(path, map_location="cpu")
+        sd = ck.get("state_dict", ck.get("model", ck)) if isinstance(ck, dict) else ck
+        sd = {(k[9:] if k.startswith("backbone.") else k): v for k, v in sd.items()}
+        if list(sd.keys())[0].startswith("module."):
+            sd = {k[7:]: v for k, v in sd.items()}
+        own = self.state_dict()
+        loaded, new = [], {}
+        for k, v in sd.items():
+            dot = k.find(".")
+            for sfx in ("_x", "_y"):
+                nk = (k[:dot] + sfx + k[dot:]) if dot != -1 else k + sfx
+                full = "spm.twin_conv." + nk
+                if full in own:   # a shape mismatch raises in load_state_dict, like in the reference
+                    new[full] = v
+                    loaded.append(full)
+        self.load_state_dict(new, strict=False)
+        return loaded
 
     def invalidate(self):
         """Drop packed weights (call after mutating parameters in place)."""

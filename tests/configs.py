@@ -80,3 +80,20 @@ def toy_encode_decode(num_classes, seed):
         low = F.avg_pool2d(crop, 4)
         return F.interpolate(F.conv2d(low, w), size=crop.shape[2:], mode="bilinear", align_corners=False)
     return fn
+
+
+def fake_convnext_checkpoint(twin_keys_shapes, seed=41):
+    """A single-stream ConvNeXt state dict (mmpretrain key names: downsample_layers.*, stages.*, norm{i}.*) with seeded values,
+    derived from the x-stream keys/shapes of a TwinConvNeXt: what TwinConvNeXt.init_weights (TC:403-443) duplicates into both streams."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in sorted(twin_keys_shapes):
+        first, rest = k.split(".", 1)
+        if first.endswith("_x"):
+            base = first[:-2]
+        elif first.startswith("norm_x"):
+            base = "norm" + first[len("norm_x"):]
+        else:
+            continue
+        sd[base + "." + rest] = torch.randn(shp, generator=g) * 0.1
+    return sd

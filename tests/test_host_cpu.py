@@ -161,3 +161,33 @@ def test_head_registry_and_state_dict_contract(golden_dir):
         head(make_head_inputs(cfg))
     with pytest.raises(NotImplementedError):
         mmsa.build_head(dict(type="SegformerHead", **dict(cfg["kwargs"], interpolate_mode="nearest")))
+
+
+def test_convnext_checkpoint_duplication_matches_reference(golden_dir, tmp_path):
+    """TwinConvNeXt.init_weights (TC:403-443): a single-stream ConvNeXt checkpoint lands in both streams; the set of loaded
+    keys (the reference leaves the per-stage out norms untouched) and their values equal what the reference ends up with."""
+    import mmsa
+    from tests.configs import CONFIGS, fake_convnext_checkpoint
+    cfg = CONFIGS["tiny256"]
+    m0 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    twin = [(k[len("spm.twin_conv."):], tuple(v.shape)) for k, v in m0.state_dict().items() if k.startswith("spm.twin_conv.")]
+    ck = fake_convnext_checkpoint(twin)
+    path = os.path.join(tmp_path, "convnext.pth")
+    torch.save({"state_dict": ck}, path)
+    before = {k: v.clone() for k, v in m0.state_dict().items()}
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **dict(cfg["kwargs"], checkpoint=path)))
+    gold = np.load(os.path.join(golden_dir, "convnext_ckpt.npz"))
+    want = set(str(k) for k in gold["loaded"])
+    sd = m.state_dict()
+    got = set()
+    for k in sd:
+        if not k.startswith("spm.twin_conv."):
+            continue
+        first, rest = k[len("spm.twin_conv."):].split(".", 1)
+        src = (first[:-2] if first.endswith(("_x", "_y")) else first) + "." + rest
+        if src in ck and torch.equal(ck[src], sd[k]):
+            got.add(k)
+    assert got == want and len(got) == 104
+    cs = sum(sd[k].double().abs().sum().item() for k in gold["loaded"])
+    assert abs(cs - float(gold["checksum"])) < 1e-9 * float(gold["checksum"])
+    assert int(gold["n_twin"]) == len(twin)

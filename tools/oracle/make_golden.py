@@ -147,6 +147,34 @@ def gen_slide():
     print("slide", {k: v.shape for k, v in out.items() if k.endswith("_out")}, flush=True)
 
 
+def gen_ckpt():
+    """TwinConvNeXt.init_weights (TC:403-443) of the reference on a seeded single-stream ConvNeXt checkpoint: which twin keys
+    end up loaded, and their checksums (tests/golden/convnext_ckpt.npz)."""
+    import tempfile
+    from tests.configs import fake_convnext_checkpoint
+    cfg = CONFIGS["tiny256"]
+    ref0 = ref_import.build_reference(**cfg["kwargs"])
+    twin = [(k[len("spm.twin_conv."):], tuple(v.shape)) for k, v in ref0.state_dict().items() if k.startswith("spm.twin_conv.")]
+    ck = fake_convnext_checkpoint(twin)
+    path = os.path.join(tempfile.gettempdir(), "mmsa_fake_convnext.pth")
+    torch.save({"state_dict": ck}, path)
+    torch.manual_seed(0)
+    ref = ref_import.build_reference(**dict(cfg["kwargs"], checkpoint=path))
+    sd = ref.state_dict()
+    keys = [k for k in sd if k.startswith("spm.twin_conv.")]
+    # a key counts as loaded when its tensor equals the checkpoint tensor it would be fed from
+    loaded = []
+    for k in keys:
+        sub = k[len("spm.twin_conv."):]
+        first, rest = sub.split(".", 1)
+        src = (first[:-2] if first.endswith(("_x", "_y")) else first) + "." + rest
+        if src in ck and ck[src].shape == sd[k].shape and torch.equal(ck[src], sd[k]):
+            loaded.append(k)
+    np.savez_compressed(os.path.join(OUT, "convnext_ckpt.npz"), loaded=np.array(loaded), n_twin=np.int64(len(keys)),
+                        checksum=np.float64(sum(sd[k].double().abs().sum().item() for k in loaded)))
+    print("convnext ckpt: loaded", len(loaded), "of", len(keys), "twin keys", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also ViT-B@512 and ViT-L@1024 (minutes, GBs of RAM)")
@@ -158,6 +186,7 @@ def main():
     for n in ("tiny224", "tiny256", "tiny320"):
         gen_model(n, full=True)
     gen_slide()
+    gen_ckpt()
     gen_head("head_vitl", full=False)
     gen_head("head_odd", full=True)
     gen_head("head_tiny", full=True)
