@@ -349,18 +349,21 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
       const float* bhq = bh + qloc * a.KHs;
       const float* bwq = bw + qloc * a.KWs;
       float mx = -INFINITY;
+      float bhv_blk = 0.f;   // FB: H-term of this key block (scores below exclude it)
       if constexpr (FB) {
         // global attention on a 64-wide grid: the 64 keys of a block are one image row (kh = kb) and
         // kw = 16t + 4G + r is the same in every block -> the W-term lives in registers, the H-term is one read
-        const float bhv = bhq[kb] * LOG2E;
+        // the H-term is the same for all 64 keys of the block: it is added to the row maximum, not to every score
+        bhv_blk = bhq[kb] * LOG2E;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = s[sub][t][r] * sc2 + (bhv + bwr[sub][t][r]);
+            const float v = s[sub][t][r] * sc2 + bwr[sub][t][r];
             s[sub][t][r] = v;
             mx = fmaxf(mx, v);
           }
+        mx += bhv_blk;
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -383,7 +386,10 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[sub], mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
+      // wave-uniform: no row of this sub-tile has a new maximum -> nothing to rescale (common after the first key blocks)
+      const bool rescale = __builtin_amdgcn_readfirstlane(__any(m_new != m_run[sub]) ? 1 : 0) != 0;
       m_run[sub] = m_new;
+      const float m_sub = m_new - bhv_blk;   // scores exclude the block's H-term
       float psum = 0.f;
       // MFMA k-slot (G, j): j < 4 -> key 16*(2*s2) + 4G + j ; j >= 4 -> key 16*(2*s2+1) + 4G + (j-4)
 #pragma unroll
@@ -394,8 +400,8 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // dword u = elements (2u, 2u+1): tile 2*s2 + (u>>1), regs 2*(u&1), 2*(u&1)+1
           const int t = 2 * s2 + (u >> 1), r = 2 * (u & 1);
-          const float p0 = __builtin_amdgcn_exp2f(s[sub][t][r] - m_new);
-          const float p1 = __builtin_amdgcn_exp2f(s[sub][t][r + 1] - m_new);
+          const float p0 = __builtin_amdgcn_exp2f(s[sub][t][r] - m_sub);
+          const float p1 = __builtin_amdgcn_exp2f(s[sub][t][r + 1] - m_sub);
           psum += p0 + p1;
           split2(p0, p1, hp[u], lp[u]);
         }
@@ -403,9 +409,11 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
         pl[sub][s2] = __builtin_bit_cast(bf16x8, ll);
       }
       l_run[sub] = l_run[sub] * alpha + psum;
+      if (rescale) {
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        o[sub][d][0] *= alpha; o[sub][d][1] *= alpha; o[sub][d][2] *= alpha; o[sub][d][3] *= alpha;
+        for (int d = 0; d < DT; ++d) {
+          o[sub][d][0] *= alpha; o[sub][d][1] *= alpha; o[sub][d][2] *= alpha; o[sub][d][3] *= alpha;
+        }
       }
     }
 
