@@ -12,6 +12,7 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __restrict__ src, long strideB, int C, long HW,
                                                              uint16_t* __restrict__ planes, long ldp) {
   // tile: one 32-channel k-block x 256 pixels.  row stride 257 floats: transposed reads hit distinct banks.
@@ -21,14 +22,29 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __rest
   const int c0 = blockIdx.y * 32;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* sb = src + (long)b * strideB;
+  if (VEC) {   // HW % 4 == 0 and 16-byte aligned rows: one 16-byte load per lane = 1 KiB per wave instruction
+    float4 v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int cl = wv * 8 + j;
-    const int c = c0 + cl;
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + wv * 8 + j;
+      const long pix = pix0 + 4 * lane;
+      v[j] = (c < C && pix < HW) ? *reinterpret_cast<const float4*>(sb + (long)c * HW + pix) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long pix = pix0 + lane + 64 * k;
-      tile[cl][lane + 64 * k] = (c < C && pix < HW) ? sb[(long)c * HW + pix] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      float* t = &tile[wv * 8 + j][4 * lane];
+      t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cl = wv * 8 + j;
+      const int c = c0 + cl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long pix = pix0 + lane + 64 * k;
+        tile[cl][lane + 64 * k] = (c < C && pix < HW) ? sb[(long)c * HW + pix] : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -62,7 +78,10 @@ extern "C" int mmsa_nchw_to_planes(const float* src, long strideB, uint16_t* pla
   MMSA_CHECK_ARG((reinterpret_cast<uintptr_t>(planes) & 127) == 0, "nchw_to_planes: planes must be 128-byte aligned");
   MMSA_CHECK_ARG(strideB >= (long)C * HW, "nchw_to_planes: image stride %ld < C*HW", strideB);
   dim3 grid(cdiv(HW, 256), cpad / 32, B);
-  hipLaunchKernelGGL(nchw_to_planes_kernel, grid, dim3(256), 0, stream, src, strideB, C, HW, planes, ldp);
+  if ((HW & 3) == 0 && (strideB & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+    hipLaunchKernelGGL(nchw_to_planes_kernel<true>, grid, dim3(256), 0, stream, src, strideB, C, HW, planes, ldp);
+  else
+    hipLaunchKernelGGL(nchw_to_planes_kernel<false>, grid, dim3(256), 0, stream, src, strideB, C, HW, planes, ldp);
   MMSA_CHECK_LAUNCH("nchw_to_planes");
   return MMSA_OK;
 }
@@ -82,9 +101,10 @@ __global__ __launch_bounds__(256) void head_fuse_kernel(const float* __restrict_
   const long pixg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // b*H*W + h*W + w
   if (pixg >= npix_total) return;
   const int lane = threadIdx.x & 63;
-  const long hw = (long)H * W;
-  const int b = (int)(pixg / hw);
-  const int rem = (int)(pixg - (long)b * hw);
+  const unsigned hw = (unsigned)H * (unsigned)W;   // 32-bit index arithmetic (npix_total < 2^31, checked by the launcher)
+  const unsigned pg = (unsigned)pixg;
+  const int b = (int)(pg / hw);
+  const int rem = (int)(pg - (unsigned)b * hw);
   const int h = rem / W, w = rem - h * W;
   // per-level taps (wave-uniform)
   long o00[3], o01[3], o10[3], o11[3];
@@ -177,6 +197,7 @@ extern "C" int mmsa_head_fuse(const float* z0, const float* z1, int H1, int W1, 
     ++n;
   }
   const long npix = (long)B * H * W;
+  MMSA_CHECK_ARG(npix < (1L << 31), "head_fuse: too many pixels for the 32-bit index arithmetic");
   hipLaunchKernelGGL(head_fuse_kernel, dim3(cdiv(npix, 4)), dim3(256), 0, stream, z0, ld, lv, n, bn_scale, bn_shift, planes, ldp,
                      out32, ldo, H, W, C, npix, act);
   MMSA_CHECK_LAUNCH("head_fuse");
