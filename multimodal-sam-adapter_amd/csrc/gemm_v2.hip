@@ -57,7 +57,20 @@ struct GemmV2Args {
 // divisions per output row); the common epilogue (GEN = false) has none.
 // ACT >= 0: the activation is a compile-time constant (the epilogue then has no activation switch and is small enough to be
 // unrolled over the four sub-tiles inside the instruction cache); ACT = -1: runtime a.act, rolled epilogue.
-template <bool GEN, int ACT>
+// PP = true: "ping-pong" main loop.  The two waves of every SIMD belong to different groups (waves 0-3 / 4-7) that run
+// half a k-tile apart: while one group reads its fragments from LDS and issues its share of the LDS-DMA, the other owns
+// the MFMA pipe.  With every wave in phase (PP = false) the whole CU first reads LDS (~1000 cycles, MFMA idle) and then
+// computes (1536 cycles, LDS idle): MfmaUtil 36-42 %.
+#ifdef V2_STAMP   // timing experiment build only (tools/build_variant.sh -DV2_STAMP): cycle stamps of workgroup 0, k-tiles 8..11
+__device__ unsigned long long g_v2_stamps[8 * 4 * 10];
+extern "C" int mmsa_debug_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v2_stamps), sizeof(unsigned long long) * 8 * 4 * 10);
+}
+#define STAMP(i_) if (stamp_on) tt[i_] = __builtin_readcyclecounter();
+#else
+#define STAMP(i_)
+#endif
+template <bool GEN, int ACT, bool PP>
 __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   constexpr bool EPI_UNROLL = ACT >= 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,6 +78,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;   // PP: wave w runs on SIMD w % 4, so every SIMD hosts one wave of each group
   const int l15 = lane & 15, g = lane >> 4;
   const int K = a.K;
   const int nk = K / V2_BK;
@@ -151,6 +165,11 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   if (total > 1) PREFETCH_NEXT();
 
   int st = 0, tile = rb, nowait = 0, j = 0;
+  if constexpr (PP) {   // k-tile 0 must be visible before the first read phase
+    if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   // One k-tile.  The DMAs of iteration j must have landed; those of j+1 (6 instructions, issued later) may stay in
   // flight.  vmcnt retires in order and counts stores too, so a wait issued after an epilogue would also wait for that
@@ -213,9 +232,105 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     ++j;                                                                                                    \
   }
 
+  // Ping-pong k-tile (PP).  Barriers are numbered b1, b2, ... per output tile; group 1 passes one extra barrier before its
+  // first k-tile and group 0 one after its last, so between b(2j) and b(2j+1) group 0 READS k-tile j while group 1 runs the
+  // MFMAs of j-1, and between b(2j+1) and b(2j+2) group 0 runs the MFMAs of j while group 1 reads j.
+  //   * a read phase = 16 ds_read_b128 + this wave's 6 DMA instructions of k-tile j+2 (ring slot (j+2)%3 = (j-1)%3: both
+  //     groups retired their reads of it with lgkmcnt(0) before b(2j)) + lgkmcnt(0);
+  //   * k-tile j+1 must have landed for ALL waves before b(2j+2) (group 0 reads it right after): group 0 waits at the end of
+  //     its MFMA phase, group 1 at the end of its read phase, both with the 6 DMAs of j+2 left in flight;
+  //   * last k-tile of an output tile: everybody drains (vmcnt 0) before b(2nk+1); after it the epilogue owns slot st_cur.
+#ifdef V2_STAMP
+#define STAMP_DECL() unsigned long long tt[9]; const bool stamp_on = blockIdx.x == 0 && tdone == 0 && kt >= 8 && kt < 12;
+#define STAMP_STORE() if (stamp_on && lane == 0) { _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) g_v2_stamps[(wave * 4 + (kt - 8)) * 10 + q_] = tt[q_]; }
+#else
+#define STAMP_DECL()
+#define STAMP_STORE()
+#endif
+#define V2_PP_NR 6   // all 6 DMA pieces of a wave and k-tile are issued in the READ phase: moving 2..6 of them between the MFMA
+                     // chunks (where a piece costs fewer issue cycles) measured 5-10 % slower (same-box A/B) -- the MFMA phase must stay pure
+#define V2_STR_(x) #x
+#define V2_STR(x) V2_STR_(x)
+#define PP_WAIT(cnt_)                                                                                       \
+  {                                                                                                         \
+    if (nowait > 0) --nowait;                                                                               \
+    else if (j + 2 < total) asm volatile("s_waitcnt vmcnt(" V2_STR(cnt_) ")" ::: "memory");                  \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+  }
+#define PP_PIECE(i_)                                                                                        \
+  if (do_pf) {                                                                                              \
+    if ((i_) == 0) GLDS16(sa0 + pko, pfb + lds_a);                                                          \
+    if ((i_) == 1) GLDS16(sa1 + pko, pfb + lds_a + 1024);                                                   \
+    if ((i_) == 2) GLDS16(sa2 + pko, pfb + lds_a + 2048);                                                   \
+    if ((i_) == 3) GLDS16(sa3 + pko, pfb + lds_a + 3072);                                                   \
+    if ((i_) == 4) GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w);                                             \
+    if ((i_) == 5) GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024);                                      \
+  }
+#define K_STEP_PP()                                                                                         \
+  {                                                                                                         \
+    const bool do_pf = pf_j < total;                                                                        \
+    const bool last_k = kt == nk - 1;                                                                       \
+    STAMP_DECL()                                                                                            \
+    STAMP(0)                                                                                                \
+    unsigned char* pfb = smem + pf_st * V2_STAGE;                                                           \
+    const int pko = pf_kt * 64;                                                                             \
+    const unsigned char* base = smem + st * V2_STAGE;                                                       \
+    bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);                             \
+      al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
+    }                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                             \
+      wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                             \
+    }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    STAMP(1)                                                                                                \
+    _Pragma("unroll") for (int pi_ = 0; pi_ < V2_PP_NR; ++pi_) PP_PIECE(pi_)                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    STAMP(2)                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    STAMP(3)                                                                                                \
+    if (grp && !last_k) PP_WAIT(V2_PP_NR)                                                                   \
+    STAMP(4)                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    STAMP(5)                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    MFMA_CHUNK(0)                                                                                           \
+    MFMA_CHUNK(1)                                                                                           \
+    MFMA_CHUNK(2)                                                                                           \
+    MFMA_CHUNK(3)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (do_pf) {                                                                                            \
+      pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                   \
+      ++pf_j;                                                                                               \
+      if (++pf_kt == nk) {                                                                                  \
+        pf_kt = 0;                                                                                          \
+        pf_tile += G;                                                                                       \
+        if (pf_j < total) SET_TILE_SRC(pf_tile);                                                            \
+      }                                                                                                     \
+    }                                                                                                       \
+    STAMP(6)                                                                                                \
+    if (last_k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+    else if (!grp) PP_WAIT(6)                                                                               \
+    STAMP(7)                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    STAMP(8)                                                                                                \
+    STAMP_STORE()                                                                                           \
+    st = st == 2 ? 0 : st + 1;                                                                              \
+    ++j;                                                                                                    \
+  }
+
   for (int tdone = 0; tdone < my_tiles; ++tdone) {
+    if constexpr (PP) {
+      if (grp) __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) K_STEP()
+      for (int kt = 0; kt < nk; ++kt) K_STEP_PP()
+      if (!grp) __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) K_STEP()
+    }
     const int st_cur = st == 0 ? 2 : st - 1;   // ring slot of the k-tile just consumed: free until the DMA of iteration j+2
 
     if (a.debug == 2) { tile += G; continue; }
@@ -234,10 +349,14 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
       unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
       const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of j, j+1 (already issued) and every store issued so far
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; the next two k-tiles landed for all
-      nowait = 2;
+      if constexpr (PP) {
+        nowait = 1;   // both groups drained before the last barrier of the k loop: k-tile j (and j+1) are visible
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of j, j+1 (already issued) and every store issued so far
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; the next two k-tiles landed for all
+        nowait = 2;
+      }
       float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
       const int nb_ = n0 + wn * 64;
       const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
@@ -446,9 +565,16 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
         }
       }
     }
+    if constexpr (PP) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // slot st_cur (epilogue staging of every wave) is free again: group 0 DMAs into it next
+    }
     tile += G;
   }
 #undef K_STEP
+#undef K_STEP_PP
+#undef PP_WAIT
+#undef PP_PIECE
 #undef MFMA_CHUNK
 }
 
@@ -486,15 +612,20 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     }
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (getenv("MMSA_GEMM_MAX_GRID")) g_num_cus = atoi(getenv("MMSA_GEMM_MAX_GRID"));   // experiment: leave CUs to concurrent streams
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+#define V2_ATTR(GEN_, ACT_)                                                                                                   \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE); \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+    V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1)
+#undef V2_ATTR
   }
   const int grid = a.ntiles < g_num_cus ? a.ntiles : g_num_cus;   // one resident workgroup per CU (144 KiB LDS each)
   const bool gen = out_mode != 0 || resid_mod > 0;
-#define V2_LAUNCH(GEN_, ACT_) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_>), dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a)
+  static const bool pp = getenv("MMSA_GEMM_PP") ? atoi(getenv("MMSA_GEMM_PP")) != 0 : true;   // 0: every wave in phase (A/B timing)
+#define V2_LAUNCH(GEN_, ACT_)                                                                                              \
+  do {                                                                                                                     \
+    if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true>), dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a);   \
+    else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false>), dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a);    \
+  } while (0)
   if (gen) {
     V2_LAUNCH(true, -1);
   } else {

@@ -12,6 +12,7 @@ ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
 # When set to a list, every gemm() launch is bracketed by HIP events recorded on the launch stream and
 # (flops, start, stop) is appended; bench.py uses this for the roofline of the dominant kernel.
 GEMM_PROFILE = None
+GEMM_SHAPES = None   # optional parallel list of (m, n, k, batch, act, has_resid, outputs) per profiled launch (tools/gemm_shapes.py)
 
 
 def _event():
@@ -149,6 +150,9 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
         nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)
         prof.append((2.0 * m * w.n * w.k * batch, e0, e1,
                      4.0 * batch * (m * w.kpad + w.n * w.kpad + m * w.n * (nout + (1 if resid is not None else 0)))))
+        if GEMM_SHAPES is not None:
+            GEMM_SHAPES.append((m, w.n, w.k, batch, act, resid is not None, ("C" if out is not None else "") + ("P" if out_planes is not None else ""),
+                                "planes" if pap is not None else "fp32"))
     return out if out is not None else out_planes
 
 

@@ -72,3 +72,30 @@ def test_encode_decode_and_slide_inference(models):
     assert agree > 0.999, f"class maps agree on {agree:.5f} of the pixels"
     with pytest.raises(RuntimeError):
         inf.slide_inference(m, h, frame[:, :, :200].to(DEV), (256, 256), (170, 170))
+
+
+def test_muses_frame_full_size_batching_invariance():
+    """BASELINE.json configs[3] at full size: one [1, 6, 1080, 1920] frame -> six 1024 x 1024 windows
+    (y in {0, 56}, x in {0, 640, 896}; ED:198-214 with crop 1024, stride 640) through the ViT-L encoder + head.  The oracle
+    needs minutes per window, so the full-size check is a property: the window grid is the reference's, and the six windows
+    batched through one encoder call give the logits of six single-window calls (images are independent in eval)."""
+    import mmsa
+    import mmsa.inference as inf
+    assert inf.crop_boxes(1080, 1920, (1024, 1024), (640, 640)) == [(y, x, y + 1024, x + 1024) for y in (0, 56) for x in (0, 640, 896)]
+    cfg, hcfg = CONFIGS["vitl1024"], HEAD_CONFIGS["head_vitl"]
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m.load_state_dict(seeded_state_dict(m, seed=cfg["seed"]))
+    h = mmsa.build_head(dict(type="SegformerHead", **hcfg["kwargs"]))
+    h.load_state_dict(seeded_state_dict(h, seed=hcfg["seed"]))
+    h = h.to(DEV)
+    g = torch.Generator().manual_seed(21)
+    frame = torch.randn(1, 6, 1080, 1920, generator=g)
+    frame[:, 3:] = (torch.rand(1, 3, 1080, 1920, generator=g) < 0.05).float() * torch.rand(1, 3, 1080, 1920, generator=g)
+    frame = frame.to(DEV)
+    batched = inf.slide_inference(m, h, frame, (1024, 1024), (640, 640), max_batch=6)
+    single = inf.slide_inference(m, h, frame, (1024, 1024), (640, 640), max_batch=1)
+    assert batched.shape == (1, 25, 1080, 1920) and bool(torch.isfinite(batched).all())
+    assert_close(batched, single, tol=1e-5, what="six windows batched vs one by one")
+    # the top-left window alone covers rows < 56 and columns < 640: no averaging there
+    alone = inf.encode_decode(m, h, frame[:, :, :1024, :1024].contiguous())
+    assert_close(batched[:, :, :56, :640], alone[:, :, :56, :640], tol=1e-5, what="singly covered region equals that window's logits")

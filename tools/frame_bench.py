@@ -1,0 +1,45 @@
+"""Frames/s of BASELINE.json configs[3]: one MUSES frame [1, 6, 1080, 1920] -> six 1024 x 1024 windows
+(crop 1024, stride 640) batched through the ViT-L encoder + Segformer head, logits averaged on the 1080 x 1920 canvas, class map
+by argmax.  Everything between the resident frame and the uint8 map is timed.  Usage: python tools/frame_bench.py [iters]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "multimodal-sam-adapter_amd"))
+import torch  # noqa: E402
+
+import mmsa  # noqa: E402
+import mmsa.inference as inf  # noqa: E402
+from tests.configs import CONFIGS, HEAD_CONFIGS  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **CONFIGS["vitl1024"]["kwargs"]))
+    h = mmsa.build_head(dict(type="SegformerHead", **HEAD_CONFIGS["head_vitl"]["kwargs"])).to(dev)
+    g = torch.Generator().manual_seed(7)
+    frame = torch.randn(1, 6, 1080, 1920, generator=g)
+    frame[:, 3:] = (torch.rand(1, 3, 1080, 1920, generator=g) < 0.05).float() * torch.rand(1, 3, 1080, 1920, generator=g)
+    frame = frame.to(dev)
+    out = {}
+    for mb in (6, 3, 1):
+        for _ in range(2):
+            cls = inf.argmax_map(inf.slide_inference(m, h, frame, (1024, 1024), (640, 640), max_batch=mb))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            cls = inf.argmax_map(inf.slide_inference(m, h, frame, (1024, 1024), (640, 640), max_batch=mb))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[f"max_batch_{mb}"] = {"ms_per_frame": dt * 1e3, "frames_per_s": 1 / dt, "crops_per_s": 6 / dt}
+    print(json.dumps({"workload": "MUSES frame 1080x1920 -> 6 crops 1024^2, ViT-L RGB+LiDAR, encoder+head+slide+argmax (eager, no graph)",
+                      "class_map": [int(cls.shape[1]), int(cls.shape[2])], **out}))
+
+
+if __name__ == "__main__":
+    main()
