@@ -171,11 +171,18 @@ def main():
             traffic = round(tj["traffic_bytes_per_launch"])
             tnote = ("HBM-side bytes per launch (average over the step's GEMM launches) from profiles/r01_gemm_traffic.json: rocprofv3 "
                      "--pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes of this workload")
+        mfile = os.path.join(ROOT, "profiles", "r01_mfma_util.json")   # written by tools/pmc_mfma.sh (rocprofv3 --pmc MfmaUtil / MOPS passes)
+        mfma = None
+        if os.path.exists(mfile) and a.config == "vitl1024":
+            mj = json.load(open(mfile))
+            mfma = {"gemm_family_mfma_util_pct": round(mj["gemm_family"]["mfma_util_pct"], 1), "gemm_family_mfma_tflops_counted": round(mj["gemm_family"]["mfma_tflops"], 1),
+                    "whole_step_mfma_util_pct": round(mj["whole_step"]["mfma_util_pct"], 1), "whole_step_mfma_tflops_counted": round(mj["whole_step"]["mfma_tflops"], 1),
+                    "source": "profiles/r01_mfma_util.json: rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{BF16,F32} passes of this workload"}
         roofline = {"bound": "mfma", "kernel": "split3 GEMM (gemm_v2_kernel + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                     "compulsory_bytes_per_launch": round(mmsa.ops.collect_gemm_profile.bytes / max(len(prof), 1)),
                     "launches_per_step": len(prof), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
-                    "kernel_ms_per_step": round(ms, 3),
+                    "kernel_ms_per_step": round(ms, 3), "mfma_counters": mfma,
                     "note": "algorithmic 2*M*N*K FLOPs; the kernel issues 3x that on MFMA (bf16 hi/lo split for fp32-level parity)"}
 
     cpu = None

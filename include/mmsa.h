@@ -142,12 +142,12 @@ int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, in
                      mmsa_stream_t stream);
 
 /* --- modality-fusion neck pieces (AM:75-109, 234-267, 110-132, 176-221) ------------------------------------- */
-int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, float* G, int B, int P, int c,
+int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G /* [B,c,c] double: order-independent sum */, int B, int P, int c,
                  int nblk, mmsa_stream_t stream);
-int mmsa_chanattn_build(const float* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
+int mmsa_chanattn_build(const double* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
                         const float* temp, const float* Wp, uint16_t* planes /* [B,c,2*cpad] */, int B, int c, int cpad,
                         int heads, mmsa_stream_t stream);
-int mmsa_gffm_build(const float* E, uint16_t* x_planes, uint16_t* y_planes /* [B,c,2*cpad] each */, int B, int c,
+int mmsa_gffm_build(const double* E, uint16_t* x_planes, uint16_t* y_planes /* [B,c,2*cpad] each */, int B, int c,
                     int cpad, mmsa_stream_t stream);
 int mmsa_gelu_gate(const float* x, long ldx, float* y, long ldy, long rows, int C, mmsa_stream_t stream);
 int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int B, int H, int W, int C, mmsa_stream_t stream);

@@ -333,7 +333,10 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
   // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 forces this one
   static const bool force_v1 = getenv("MMSA_GEMM_V1") != nullptr;
-  if (ap && M >= 128 && !force_v1)
+  // one 128-column strip with many rows and a deep K (ConvNeXt stage-0 pw2: N = 96, K = 384): the 128-row tiles of this kernel
+  // balance better over the CUs than 256-row tiles (61 vs 75 us at M = 131072; at K <= 192 the 256-row kernel is faster)
+  const bool narrow = N <= 128 && M >= 65536 && K >= 384;
+  if (ap && M >= 128 && !force_v1 && !narrow)
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
                                out_mode, ps_H, ps_W, ps_C, stream);

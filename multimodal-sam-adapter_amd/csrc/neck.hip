@@ -1,6 +1,8 @@
 // Kernels specific to the RoadFormer2Neck modality fusion (AM:297-394) on NHWC fp32 maps.
-//   gram_tn        : G[b] = X[b]^T Y[b] over the H*W rows, exact fp32 on v_mfma_f32_16x16x4_f32
-//                    (GFE channel attention q k^T AM:102; GFFM energies AM:252-253).
+//   gram_tn        : G[b] = X[b]^T Y[b] over the H*W rows, exact fp32 on v_mfma_f32_16x16x4_f32 per 256-row slice; the slices
+//                    are combined in DOUBLE (atomics): their order is arbitrary, and with fp32 atomics the 1e-7 noise of the
+//                    sum was amplified by GFFM's softmax over energies of magnitude ~1e4 to run-to-run differences of up to
+//                    2e-3 in c1 / c2 (GFE channel attention q k^T AM:102; GFFM energies AM:252-253).
 //   chanattn_build : GFE: L2-normalised, temperature-scaled channel softmax per head (AM:100-103) folded with
 //                    the 1x1 `proj` (AM:107) into one per-image [c,c] weight, emitted as bf16 hi/lo planes so
 //                    that  proj(attn @ v)  becomes a single split3 GEMM over the tokens.
@@ -12,7 +14,7 @@
 // ---------------------------------------------------------------------------------------------
 #define GR_ROWS 1024   // rows of X/Y per workgroup (4 waves x 256)
 __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
-                                                      long strideB, float* __restrict__ G, int P, int c, int nblk) {
+                                                      long strideB, double* __restrict__ G, int P, int c, int nblk) {
   const int nt = (c + 31) / 32;
   const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
   if (nblk > 1) {  // only tiles that intersect a diagonal head block are needed
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
     acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
   }
-  float* Gb = G + (long)b * c * c;
+  double* Gb = G + (long)b * c * c;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -61,14 +63,14 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
       for (int r = 0; r < 4; ++r) {
         const int i = 32 * ti + 16 * u + 4 * kk + r;   // D row = 4*(lane>>4) + r
         const int j = 32 * tj + 16 * v + l15;          // D col = lane & 15
-        if (i < c && j < c) atomicAdd(Gb + (long)i * c + j, acc[u][v][r]);
+        if (i < c && j < c) atomicAdd(Gb + (long)i * c + j, (double)acc[u][v][r]);
       }
 }
 
-extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, float* G,
+extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G,
                             int B, int P, int c, int nblk, hipStream_t stream) {
   MMSA_CHECK_ARG(X && Y && G && B > 0 && P > 0 && c > 0 && nblk > 0 && c % nblk == 0, "gram_tn: bad args");
-  if (hipMemsetAsync(G, 0, sizeof(float) * (size_t)B * c * c, stream) != hipSuccess) {
+  if (hipMemsetAsync(G, 0, sizeof(double) * (size_t)B * c * c, stream) != hipSuccess) {
     mmsa_set_error("gram_tn: memset failed");
     return MMSA_ERR_LAUNCH;
   }
@@ -82,7 +84,7 @@ extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, 
 // ---------------------------------------------------------------------------------------------
 // grid (heads, B).  G: [B,c,c] = q^T k; sq/sk: column sums of squares of q and k (double, from colstats slot 1).
 // planes: [B, c, cpad] bf16 hi/lo of  Wcomb[o][j] = sum_i Wp[o][i] * attn[i][j]   (attn block diagonal per head).
-__global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __restrict__ G, const double* __restrict__ sq,
+__global__ __launch_bounds__(256) void chanattn_build_kernel(const double* __restrict__ G, const double* __restrict__ sq,
                                                              long sq_strideB, const double* __restrict__ sk, long sk_strideB,
                                                              const float* __restrict__ temp, const float* __restrict__ Wp,
                                                              unsigned short* __restrict__ planes,
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __rest
   const int h = blockIdx.x, b = blockIdx.y;
   const int ch = c / heads;
   const int st = ch + 1;
-  const float* Gb = G + (long)b * c * c;
+  const double* Gb = G + (long)b * c * c;
   const float t = temp[h];
   for (int i = threadIdx.x; i < ch; i += 256) {
     const int gi = h * ch + i;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __rest
     for (int j = 0; j < ch; ++j) {
       const int gj = h * ch + j;
       const float nk = fmaxf((float)sqrt(sk[(long)b * sk_strideB + gj]), 1e-12f);
-      const float v = Gb[(long)gi * c + gj] / (nq * nk) * t;
+      const float v = (float)Gb[(long)gi * c + gj] / (nq * nk) * t;
       attn[i * st + j] = v;
       mx = fmaxf(mx, v);
     }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void chanattn_build_kernel(const float* __rest
   }
 }
 
-extern "C" int mmsa_chanattn_build(const float* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
+extern "C" int mmsa_chanattn_build(const double* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
                                    const float* temp, const float* Wp, unsigned short* planes,
                                    int B, int c, int cpad, int heads, hipStream_t stream) {
   MMSA_CHECK_ARG(G && sq && sk && temp && Wp && planes, "chanattn_build: null pointer");
@@ -145,28 +147,29 @@ extern "C" int mmsa_chanattn_build(const float* G, const double* sq, long sq_str
 
 // ---------------------------------------------------------------------------------------------
 // grid (c, B, 2): z = 0 -> Ax[i][:] = softmax_j E[i][j];  z = 1 -> Ay[i][:] = softmax_j E[j][i]
-__global__ __launch_bounds__(256) void gffm_build_kernel(const float* __restrict__ E, unsigned short* __restrict__ xp,
+__global__ __launch_bounds__(256) void gffm_build_kernel(const double* __restrict__ E, unsigned short* __restrict__ xp,
                                                          unsigned short* __restrict__ yp, int c, int cpad) {
   __shared__ float red[4];
   const int i = blockIdx.x, b = blockIdx.y, tr = blockIdx.z;
-  const float* Eb = E + (long)b * c * c;
+  const double* Eb = E + (long)b * c * c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the row maximum as fp32 (exact comparison: fp32 values are a subset), the shifted logits from the double energies
   float mx = -INFINITY;
-  for (int j = threadIdx.x; j < c; j += 256) mx = fmaxf(mx, tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]);
+  for (int j = threadIdx.x; j < c; j += 256) mx = fmaxf(mx, (float)(tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]));
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float s = 0.f;
-  for (int j = threadIdx.x; j < c; j += 256) s += expf((tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]) - mx);
+  for (int j = threadIdx.x; j < c; j += 256) s += expf((float)((tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]) - (double)mx));
   s = wave_sum(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
   const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
   unsigned short* pl = tr ? yp : xp;   // ilv planes [B, c, 2*cpad]
   for (int j = threadIdx.x; j < c; j += 256) {
-    const float p = expf((tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]) - mx) * inv;
+    const float p = expf((float)((tr ? Eb[(long)j * c + i] : Eb[(long)i * c + j]) - (double)mx)) * inv;
     unsigned short hh, ll;
     split_bf16(p, hh, ll);
     unsigned short* q_ = pl + ((long)b * c + i) * 2 * cpad + ilv(j);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void gffm_build_kernel(const float* __restrict
   }
 }
 
-extern "C" int mmsa_gffm_build(const float* E, unsigned short* xp, unsigned short* yp, int B, int c, int cpad,
+extern "C" int mmsa_gffm_build(const double* E, unsigned short* xp, unsigned short* yp, int B, int c, int cpad,
                                hipStream_t stream) {
   MMSA_CHECK_ARG(E && xp && yp && cpad >= c, "gffm_build: bad args");
   hipLaunchKernelGGL(gffm_build_kernel, dim3(c, B, 2), dim3(256), 0, stream, E, xp, yp, c, cpad);

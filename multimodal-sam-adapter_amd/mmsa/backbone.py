@@ -640,7 +640,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.gconv(q1, gp["q2"], None, q2, B, h, w, 32, 3 * c // 32, 3 * c // 32, 3)
             st = ws.get("nk_st", B * 3, 3 * c, dtype=torch.float64)
             ops.colstats(q2, HW * 3 * c, B, HW, st)
-            g = ws.get("nk_gram", B * c, c)
+            g = ws.get("nk_gram", B * c, c, dtype=torch.float64)
             ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8)
             cp = ops.pad32(c)
             pl = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
@@ -663,7 +663,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 ops.dwconv(h1, lp["dw"], None, h2, B, h, w, 3, act="relu6")
                 ops.gemm(h2, lp["w3"], lcat[:, m * c:(m + 1) * c], alpha=lp["scale"], resid=X)
         # GFFM (AM:242-267)
-        e = ws.get("nk_gram", B * c, c)
+        e = ws.get("nk_gram", B * c, c, dtype=torch.float64)
         ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1)
         cp = ops.pad32(c)
         px = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)

@@ -352,19 +352,20 @@ def im2col_nchw(x, c0, cin, p, out):
 
 
 def gram_tn(x, y, stride_b, g, b, p, nblk=1):
+    """G[b] = X[b]^T Y[b] -> float64 [B*c, c] (the row slices are combined in double: run-to-run identical)."""
     px, _, c, ldx = _mat(x, "X")
     py, _, _, ldy = _mat(y, "Y")
-    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g), b, p, c, nblk, _stream())
+    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g, torch.float64, "G"), b, p, c, nblk, _stream())
     return g
 
 
 def chanattn_build(g, sq, sq_stride, sk, sk_stride, temp, wp, planes, b, c, heads):
-    lib.call("mmsa_chanattn_build", _chk(g), sq, sq_stride, sk, sk_stride, _chk(temp), _chk(wp),
+    lib.call("mmsa_chanattn_build", _chk(g, torch.float64, "G"), sq, sq_stride, sk, sk_stride, _chk(temp), _chk(wp),
              planes.p.data_ptr(), b, c, planes.kpad, heads, _stream())
 
 
 def gffm_build(e, px_, py_, b, c):
-    lib.call("mmsa_gffm_build", _chk(e), px_.p.data_ptr(), py_.p.data_ptr(), b, c, px_.kpad, _stream())
+    lib.call("mmsa_gffm_build", _chk(e, torch.float64, "E"), px_.p.data_ptr(), py_.p.data_ptr(), b, c, px_.kpad, _stream())
 
 
 def gelu_gate(x, out, c):

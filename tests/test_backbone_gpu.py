@@ -53,8 +53,9 @@ def test_batch_and_determinism():
     ref, _ = orc(x)
     for a, b, r in zip(f_a, f_b, ref):
         assert_close(a, r, what="batch 3")
-        assert rel_l2(a, b) < 1e-5  # only the fp32 atomics of the Gram kernels are order dependent
-    # images are independent: batch element 1 alone gives the same result
+        assert torch.equal(a, b), "two runs on the same input must agree bit for bit (no order-dependent reduction on the path)"
+    # images are independent: batch element 1 alone gives the same result (at this toy size the row count decides which
+    # GEMM kernel runs, so not the same bits; at ViT-L sizes it is bit-exact: test_inference_gpu.py)
     f_1, _ = m(x[1:2].to(DEV))
     for a, s in zip(f_a, f_1):
         assert rel_l2(a[1:2], s) < 1e-5

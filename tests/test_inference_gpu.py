@@ -95,7 +95,7 @@ def test_muses_frame_full_size_batching_invariance():
     batched = inf.slide_inference(m, h, frame, (1024, 1024), (640, 640), max_batch=6)
     single = inf.slide_inference(m, h, frame, (1024, 1024), (640, 640), max_batch=1)
     assert batched.shape == (1, 25, 1080, 1920) and bool(torch.isfinite(batched).all())
-    assert_close(batched, single, tol=1e-5, what="six windows batched vs one by one")
+    assert torch.equal(batched, single), "six windows batched vs one by one: the path is batch invariant bit for bit"
     # the top-left window alone covers rows < 56 and columns < 640: no averaging there
     alone = inf.encode_decode(m, h, frame[:, :, :1024, :1024].contiguous())
-    assert_close(batched[:, :, :56, :640], alone[:, :, :56, :640], tol=1e-5, what="singly covered region equals that window's logits")
+    assert_close(batched[:, :, :56, :640], alone[:, :, :56, :640], tol=1e-6, what="singly covered region equals that window's logits")

@@ -313,14 +313,14 @@ def test_gram_tn(ops):
     x = torch.randn(B, P, 2 * c, generator=g(90))
     ref = torch.einsum("bpi,bpj->bij", x[..., :c].double(), x[..., c:].double()).float()
     xd = x.view(B * P, 2 * c).to(DEV)
-    out = torch.empty(B * c, c, device=DEV)
+    out = torch.empty(B * c, c, device=DEV, dtype=torch.float64)
     ops.gram_tn(xd[:, :c], xd[:, c:], P * 2 * c, out, B, P, nblk=1)
-    assert_close(out.view(B, c, c), ref, tol=1e-5, what="gram full")
+    assert_close(out.view(B, c, c).float(), ref, tol=1e-5, what="gram full")
     ops.gram_tn(xd[:, :c], xd[:, c:], P * 2 * c, out, B, P, nblk=8)  # only diagonal head blocks are defined
     ch = c // 8
     for h in range(8):
         sl = slice(h * ch, (h + 1) * ch)
-        assert_close(out.view(B, c, c)[:, sl, sl], ref[:, sl, sl], tol=1e-5, what="gram diag block")
+        assert_close(out.view(B, c, c)[:, sl, sl].float(), ref[:, sl, sl], tol=1e-5, what="gram diag block")
 
 
 @pytest.mark.parametrize("c,H,W", [(32, 12, 10), (96, 16, 16)])
@@ -345,7 +345,7 @@ def test_gfe_module(ops, c, H, W):
     ops.gconv(q1, q2w, None, q2, B, H, W, G, 3 * c // G, 3 * c // G, 3)
     st = torch.empty(B * 3, 3 * c, dtype=torch.float64, device=DEV)
     ops.colstats(q2, HW * 3 * c, B, HW, st)
-    gm = torch.empty(B * c, c, device=DEV)
+    gm = torch.empty(B * c, c, device=DEV, dtype=torch.float64)
     ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, gm, B, HW, nblk=8)
     pl = ops.Planes(torch.zeros(B * c, 2 * c, dtype=torch.int16, device=DEV), c, c, c)
     base = st.data_ptr()
@@ -367,7 +367,7 @@ def test_gffm_gemms(ops):
     ay = F.softmax(torch.bmm(y, x.transpose(1, 2)), -1)
     ref = torch.cat((gx * torch.bmm(ax, y) + x, gy * torch.bmm(ay, x) + y), 1)  # before the LayerNorm
     gc = gin.permute(0, 2, 3, 1).reshape(B * HW, 2 * c).contiguous().to(DEV)
-    e = torch.empty(B * c, c, device=DEV)
+    e = torch.empty(B * c, c, device=DEV, dtype=torch.float64)
     ops.gram_tn(gc[:, :c], gc[:, c:], HW * 2 * c, e, B, HW)
     mk = lambda: ops.Planes(torch.zeros(B * c, 2 * c, dtype=torch.int16, device=DEV), c, c, c)
     px, py = mk(), mk()

@@ -10,7 +10,7 @@ for e in ev[1:]:
     else:
         cur.append(e)
 segs.append(cur)
-want = int(sys.argv[2]) if len(sys.argv) > 2 else 786
+want = int(sys.argv[2]) if len(sys.argv) > 2 else collections.Counter(len(s) for s in segs if len(s) > 100).most_common(1)[0][0]
 seg = [s for s in segs if len(s) == want][-1]
 t0, t1 = seg[0][0], max(x[1] for x in seg)
 pts = []
