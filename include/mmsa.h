@@ -35,6 +35,8 @@ int mmsa_version(void);
 const char* mmsa_last_error(void);
 
 /* HIP events on the launch stream (for bench.py; torch.cuda.Event only sees torch's current stream). */
+/* testing aid: fill the LDS of every CU with `pattern` (finds kernels that read LDS they did not write) */
+int mmsa_debug_poison_lds(unsigned pattern, mmsa_stream_t stream);
 int mmsa_event_create(void** ev);
 int mmsa_event_record(void* ev, mmsa_stream_t stream);
 int mmsa_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */

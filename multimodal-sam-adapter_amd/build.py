@@ -9,6 +9,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "mmsa", "libmmsa_hip.so")
 
 
+# sources compiled without the SLP vectoriser: see the header of csrc/conv_pair.hip
+NO_SLP = {"conv_pair.hip"}
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -29,6 +33,8 @@ def build(force=False, verbose=True):
         o = os.path.join(HERE, "build", os.path.basename(s).replace(".hip", ".o"))
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-c", s, "-o", o]
+        if os.path.basename(s) in NO_SLP:
+            cmd.insert(3, "-fno-slp-vectorize")
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         out, _ = p.communicate()

@@ -31,3 +31,23 @@ extern "C" int mmsa_event_elapsed_ms(void* a, void* b, float* ms) {
   return MMSA_OK;
 }
 extern "C" int mmsa_event_destroy(void* ev) { hipEventDestroy((hipEvent_t)ev); return MMSA_OK; }
+
+// Testing aid (tests/test_backbone_gpu.py, MMSA_DEBUG_POISON_LDS=1 in mmsa/lib.py): overwrite the LDS of every CU with `pattern`
+// so that a kernel which reads LDS it has not written itself (the leftovers of whatever ran on that CU before) shows up as NaNs
+// or as a changed result.  One 160-KiB workgroup fills a CU's LDS; 4 x #CUs workgroups reach every CU.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern) {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  if (lds_words[(threadIdx.x * 97) % (160 * 1024 / 4)] != pattern) asm volatile("s_nop 0");   // keep the stores
+}
+extern "C" int mmsa_debug_poison_lds(unsigned pattern, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 160 * 1024, stream, pattern);
+  MMSA_CHECK_LAUNCH("debug_poison_lds");
+  return MMSA_OK;
+}

@@ -29,6 +29,7 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.bufs = {}
+        self.zeroed = set()   # buffers whose never-written parts must stay zero (K padding of planes)
 
     def get(self, name, rows, cols, dtype=torch.float32, zero=False):
         n = rows * cols
@@ -36,7 +37,20 @@ class Workspace:
         if b is None or b.numel() < n or b.dtype != dtype:
             b = torch.zeros(n, dtype=dtype, device=self.device) if zero else torch.empty(n, dtype=dtype, device=self.device)
             self.bufs[name] = b
+        if zero:
+            self.zeroed.add(name)
         return b[:n].view(rows, cols)
+
+    def poison(self):
+        """Testing aid: fill every scratch buffer that is not of the keep-zero kind with NaN (fp) / 0x7fc0 bf16 NaN patterns,
+        so that a read of a never-written element shows up in the outputs (tests/test_backbone_gpu.py)."""
+        for name, b in self.bufs.items():
+            if name in self.zeroed:
+                continue
+            if b.dtype in (torch.float32, torch.float64):
+                b.fill_(float("nan"))
+            elif b.dtype == torch.int16:
+                b.fill_(0x7fc0)
 
     def planes(self, name, rows, cols, zero=False):
         """Interleaved bf16 hi/lo activation planes of a [rows, cols] matrix (cols padded to 32)."""
@@ -381,7 +395,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, x):
+    def _prepare(self, x):
         if not x.is_cuda:
             raise RuntimeError("mmsa: input must be a GPU tensor; the MI355X backbone has no CPU path")
         if x.dim() != 4 or x.shape[1] != 6:
@@ -398,7 +412,58 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             self._packed["dev"] = dev
         if self._ws is None or self._ws.device != dev:
             self._ws = Workspace(dev)
+        return x, B, H, W
+
+    def _cbufs(self, B, H, W, tag=""):
+        """c1 [B*HW/16, D] and c = (c2|c3|c4 + level embed) [B, Nc, D]; `tag` selects one of the two sets of the pipelined mode."""
+        D = self.cfg["embed_dim"]
+        Nc = (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32)
+        return self._ws.get("c1" + tag, B * (H // 4) * (W // 4), D), self._ws.get("c" + tag, B * Nc, D), Nc
+
+    def forward(self, x):
+        x, B, H, W = self._prepare(x)
+        # ---- spatial prior module -> c1, c
+        c1, cbuf, Nc = self._cbufs(B, H, W)
+        c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
+        return self._vit(x, B, H, W, c1, cbuf, c1_ready), None
+
+    def forward_pipelined(self, x_next):
+        """Throughput mode (two-stage software pipeline over consecutive batches).  The spatial prior module depends only on
+        the image, and every ViT block depends on it (the first injector reads c2..c4), so inside one batch the two cannot
+        overlap -- but the SPM of the NEXT batch can run underneath the ViT blocks of the current one: its many small launches
+        fill the CUs that the ViT's kernels leave idle.  Each call starts the SPM of `x_next` on a side stream (into the other
+        of two c1 / c buffer sets) and runs the ViT + interactions + tail of the batch given to the PREVIOUS call, whose
+        outputs it returns (None on the first call; pass None to drain).  Per batch the arithmetic and the results are those of
+        forward(), bit for bit."""
+        cur = getattr(self, "_pl_cur", None)
+        main = torch.cuda.current_stream()
+        nxt = None
+        if x_next is not None:
+            x_next, B, H, W = self._prepare(x_next)
+            q = 1 - cur["set"] if cur is not None else 0
+            c1, cbuf, Nc = self._cbufs(B, H, W, f"_p{q}")
+            if getattr(self, "_pipe_stream", None) is None or self._pipe_stream.device != x_next.device:
+                self._pipe_stream = torch.cuda.Stream(device=x_next.device)
+            sa = self._pipe_stream
+            sa.wait_stream(main)
+            with torch.cuda.stream(sa):
+                ev = self._spm(x_next, B, H, W, c1, cbuf, Nc)
+                sa.wait_event(ev)   # neck level 0 (c1) is joined inside this stage: the tail of the next call needs it
+            nxt = dict(x=x_next, set=q, dims=(B, H, W), c1=c1, c=cbuf)
+            if os.environ.get("MMSA_PIPE_SERIAL") == "1":   # debugging aid: no overlap between the two stages
+                main.wait_stream(sa)
+        outs = None
+        if cur is not None:
+            B, H, W = cur["dims"]
+            outs = self._vit(cur["x"], B, H, W, cur["c1"], cur["c"], None)
+        if nxt is not None:
+            main.wait_stream(self._pipe_stream)   # join: the next call (or graph replay) starts after both stages
+        self._pl_cur = nxt
+        return (outs, None) if outs is not None else None
+
+    def _vit(self, x, B, H, W, c1, cbuf, c1_ready):
         pk, ws, cfg = self._packed, self._ws, self.cfg
+        dev = x.device
         geo = self._geometry(H, W, dev)
         D = cfg["embed_dim"]
         p = cfg["patch_size"]
@@ -406,11 +471,6 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         T = Hp * Wp
         n2, n3, n4 = (H // 8) * (W // 8), T, (H // 32) * (W // 32)
         Nc = n2 + n3 + n4
-
-        # ---- spatial prior module -> c1 [B*HW/16, D], c (c2|c3|c4 + level embed) [B, Nc, D]
-        c1 = ws.get("c1", B * (H // 4) * (W // 4), D)
-        cbuf = ws.get("c", B * Nc, D)
-        c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
 
         # ---- patch embedding + absolute position embedding (IE:662-671, BK:268-278)
         a = ws.get("pe_a", B * T, pk["pe_w"].kpad)
@@ -428,7 +488,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
 
         # ---- tail (BK:316-337)
-        torch.cuda.current_stream().wait_event(c1_ready)
+        if c1_ready is not None:
+            torch.cuda.current_stream().wait_event(c1_ready)
         outs = []
         c2p = ws.planes("up_a", B * n2, D)
         for bi in range(B):
@@ -443,8 +504,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.tail_fuse(cbuf[n2:], Nc * D, xs[3], *pk["bn"][2], f3, B, Hp, Wp, Hp, Wp)
         f4 = torch.empty(B, D, H // 32, W // 32, device=dev)
         ops.tail_fuse(cbuf[n2 + n3:], Nc * D, xs[4], *pk["bn"][3], f4, B, H // 32, W // 32, Hp, Wp)
-        outs = [f1, f2, f3, f4]
-        return outs, None
+        return [f1, f2, f3, f4]
 
     # ------------------------------------------------------------------ SAM ViT block (IE:382-423)
     def _block(self, bp, rel, x, B, Hp, Wp, relg=None):

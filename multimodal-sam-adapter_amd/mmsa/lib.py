@@ -31,6 +31,7 @@ F = c_float
 SIGNATURES = {
     "mmsa_version": [],
     "mmsa_last_error": [],
+    "mmsa_debug_poison_lds": [ctypes.c_uint, P],
     "mmsa_event_create": [POINTER(c_void_p)],
     "mmsa_event_record": [P, P],
     "mmsa_event_elapsed_ms": [P, P, POINTER(c_float)],
@@ -79,8 +80,13 @@ def last_error() -> str:
     return _lib.mmsa_last_error().decode()
 
 
+POISON_LDS = os.environ.get("MMSA_DEBUG_POISON_LDS") == "1"   # testing aid: NaN-fill every CU's LDS before every launch
+
+
 def call(name, *args):
     """Invoke an entry point; raise RuntimeError(mmsa_last_error()) on a non-zero return code."""
+    if POISON_LDS and not name.startswith(("mmsa_event", "mmsa_debug")):
+        _lib.mmsa_debug_poison_lds(0x7FC07FC0, args[-1])   # the stream is the last argument of every launching entry point
     rc = getattr(_lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {last_error()}")

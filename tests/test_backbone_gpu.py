@@ -99,3 +99,44 @@ def test_rejects_wrong_inputs():
         m(torch.zeros(1, 6, 256, 256, device=DEV))  # H=W=img_size required (AM:240-241)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 224, 224, device=DEV))
+
+
+def test_no_reads_of_unwritten_scratch():
+    """Every scratch buffer is NaN-filled and the LDS of every CU is NaN-filled before every launch: a kernel that reads global
+    scratch or LDS it (or its producer) has not written would change the outputs or make them non-finite."""
+    from mmsa import lib
+    cfg, orc, m = _build("tiny256")
+    del orc
+    x = make_input(cfg, batch=2, seed=31).to(DEV)
+    m.multistream = False
+    ref = [t.clone() for t in m(x)[0]]
+    torch.cuda.synchronize()
+    m._ws.poison()
+    lib.POISON_LDS = True
+    try:
+        outs = m(x)[0]
+        torch.cuda.synchronize()
+    finally:
+        lib.POISON_LDS = False
+    for a, b in zip(outs, ref):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_results_do_not_depend_on_concurrent_work():
+    """Pipelined mode (the SPM of the next batch runs on side streams underneath the ViT blocks of the current one) returns, bit
+    for bit, what forward() returns -- over many calls: the overlap must not change a single value.  (It did once: see the
+    header of csrc/conv_pair.hip.)"""
+    cfg, orc, m = _build("vitl1024")
+    del orc
+    x = make_input(cfg, batch=2, seed=41).to(DEV)
+    ref = [t.clone() for t in m(x)[0]]
+    assert m.forward_pipelined(x) is None
+    for it in range(40):
+        outs, _ = m.forward_pipelined(x)
+        torch.cuda.synchronize()
+        for a, b in zip(outs, ref):
+            assert torch.equal(a, b), f"call {it}: pipelined output differs from forward()"
+    last, _ = m.forward_pipelined(None)   # drain
+    for a, b in zip(last, ref):
+        assert torch.equal(a, b)
+    assert m.forward_pipelined(None) is None
