@@ -445,19 +445,22 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             if getattr(self, "_pipe_stream", None) is None or self._pipe_stream.device != x_next.device:
                 self._pipe_stream = torch.cuda.Stream(device=x_next.device)
             sa = self._pipe_stream
+            self._ws.get("pl_tick", 1, 1).zero_()   # a node before the fork: forking off a capture stream that has recorded nothing yet crashed hipStreamEndCapture
             sa.wait_stream(main)
             with torch.cuda.stream(sa):
-                ev = self._spm(x_next, B, H, W, c1, cbuf, Nc)
-                sa.wait_event(ev)   # neck level 0 (c1) is joined inside this stage: the tail of the next call needs it
+                joins = self._spm(x_next, B, H, W, c1, cbuf, Nc, join=False)
             nxt = dict(x=x_next, set=q, dims=(B, H, W), c1=c1, c=cbuf)
-            if os.environ.get("MMSA_PIPE_SERIAL") == "1":   # debugging aid: no overlap between the two stages
-                main.wait_stream(sa)
         outs = None
         if cur is not None:
             B, H, W = cur["dims"]
             outs = self._vit(cur["x"], B, H, W, cur["c1"], cur["c"], None)
         if nxt is not None:
-            main.wait_stream(self._pipe_stream)   # join: the next call (or graph replay) starts after both stages
+            # join: the next call (or graph replay) starts after both stages.  Every neck stream is joined by THIS stream, not by
+            # the SPM's: under HIP-graph capture a forked stream that waits on another forked stream's event crashed
+            # hipStreamEndCapture (ROCm 7.2; tools/cap_min3.py), the capture's origin stream may.
+            for e in joins:
+                main.wait_event(e)
+            main.wait_stream(self._pipe_stream)
         self._pl_cur = nxt
         return (outs, None) if outs is not None else None
 
@@ -577,7 +580,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
 
     # ------------------------------------------------------------------ spatial prior module (AM:929-964)
-    def _spm(self, x, B, H, W, c1_out, cbuf, Nc):
+    def _spm(self, x, B, H, W, c1_out, cbuf, Nc, join=True):
         pk, ws = self._packed, self._ws
         D = self.cfg["embed_dim"]
         chans = self.channels
@@ -620,6 +623,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 joins.append(e)
         # c1 (level 0, the heaviest) is consumed only by the tail (BK:316-337): its stream is joined there, so it runs
         # underneath the ViT blocks; the injectors need levels 1..3
+        if not join:
+            return joins   # pipelined mode: the caller's stream joins every level
         for e in joins[1:]:
             main.wait_event(e)
         return joins[0]

@@ -49,7 +49,24 @@ for _ in range(2):
         torch.cuda.synchronize()
 torch.cuda.synchronize()
 print("eager pipelined == forward:", all(torch.equal(a, b) for a, b in zip(outs, ref)))
-gs = [graph_of(lambda: m.forward_pipelined(x)[0]) for _ in range(2)]   # two parities (buffer set 0 / 1)
+dbg = os.environ.get("PB_DBG", "")
+if dbg == "noB":
+    m._vit = lambda *a, **k: [torch.zeros(1, device=dev)]
+if dbg == "noA":
+    def _stub(x_, B_, H_, W_, c1_, c_, Nc_):
+        c1_[:1].zero_()
+        e = torch.cuda.Event(); e.record(torch.cuda.current_stream()); return e
+    m._spm = _stub
+m.multistream = os.environ.get("PB_MULTI", "1") == "1"
+print("capturing, multistream =", m.multistream, flush=True)
+gs = []
+for par in range(2):   # two parities (buffer set 0 / 1): one call per graph, no warm-up call in between (it would flip the parity)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m.forward_pipelined(x)[0]
+    torch.cuda.synchronize()
+    gs.append((g, out))
+    print("captured parity", par, flush=True)
 k = [0]
 
 
