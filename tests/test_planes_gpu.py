@@ -261,3 +261,40 @@ def test_global_attention_fused_relpos(ops, H):
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
     assert_close(out.view(B, H, W, D), ref, what=f"global attention fused rel-pos {H}x{W}")
+
+
+@pytest.mark.parametrize("M,N,K,mode", [
+    (70000, 200, 96, "C"),        # 548 tiles on 256 persistent workgroups (3 per workgroup), 3 k-tiles, ragged M and N
+    (9000, 1100, 160, "P"),       # 324 tiles, 5 k-tiles, planes-only output, ragged right edge
+    (33000, 130, 32, "C"),        # one k-tile per output tile: every k-tile is a tile boundary
+    (600, 4100, 64, "CP"),        # 3 x 33 tiles, two k-tiles, both outputs
+    (66000, 384, 1536, "Cres"),   # deep K, residual, 774 tiles
+])
+def test_gemm_persistent_tile_stream(ops, M, N, K, mode):
+    """The LDS-DMA kernel's continuous (tile, k-tile) stream: several output tiles per workgroup, few k-tiles per tile, ragged
+    edges -- against fp64, and bit-identical when repeated (the ping-pong schedule has no timing-dependent result)."""
+    a = torch.randn(M, K, generator=g(120)) * 0.5
+    w = torch.randn(N, K, generator=g(121)) / K ** 0.5
+    b = torch.randn(N, generator=g(122))
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    ref = (ad.double() @ wd.double().t() + bd.double())
+    res = None
+    if mode == "Cres":
+        res = torch.randn(M, N, generator=g(123)).to(DEV)
+        ref = ref + res.double()
+    else:
+        ref = torch.relu(ref)
+    ref = ref.float()
+    ap = ops.split_planes(ad, kpad=K)
+    pl = ops.split_planes(wd)
+    outs = []
+    for rep in range(3):
+        out = torch.full((M, N), float("nan"), device=DEV) if "C" in mode else None
+        outp = ops.alloc_planes(M, N, DEV) if "P" in mode else None
+        ops.gemm(ap, pl, out, bias=bd, act="none" if mode == "Cres" else "relu", resid=res, out_planes=outp)
+        got = out if out is not None else planes_to_float(outp)
+        outs.append(got.clone())
+        if out is not None and outp is not None:
+            assert_close(planes_to_float(outp), ref, tol=3e-5, what="planes output")
+    assert_close(outs[0], ref, tol=3e-5, what=f"gemm {M}x{N}x{K} {mode}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
