@@ -78,6 +78,7 @@ def main():
         hkw = dict(HEAD_CONFIGS["head_vitl"]["kwargs"])
         hkw["in_channels"] = [cfg["kwargs"]["embed_dim"]] * 4
         head = mmsa.build_head(dict(type="SegformerHead", **hkw))
+        model.emit_planes = os.environ.get("MMSA_EMIT_PLANES", "1") == "1"   # the tail also writes its four maps as planes: the head skips its NCHW -> planes pass
 
     def encoder_step():
         return model(x)[0]

@@ -158,8 +158,9 @@ int mmsa_ca_apply(const float* z, long ldz, const float* att, long lda, float* o
 
 /* --- tail (BK:316-337): out NCHW [B,C,Hc,Wc] = (cmap + bilinear(xtok)) * bn_scale + bn_shift; cmap image b starts at b*cstrideB --- */
 int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok, long ldx, const float* bn_scale,
-                   const float* bn_shift, float* out, int B, int Hc, int Wc, int Hx, int Wx, int C,
-                   mmsa_stream_t stream);
+                   const float* bn_shift, float* out, uint16_t* out_planes /* optional: the same map token-major
+                   [B*Hc*Wc, 2*C] as interleaved planes, for the decode head's first 1x1 conv */, long ldp,
+                   int B, int Hc, int Wc, int Hx, int Wx, int C, mmsa_stream_t stream);
 
 /* --- global attention with the rel-pos terms computed in the kernel (Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 on a
  *     window_size = 0 block): planes in / out as mmsa_attention_planes; relpos_planes = interleaved planes of a [256, 64] matrix, rows

@@ -9,8 +9,8 @@
 
 __global__ __launch_bounds__(256) void tail_fuse_kernel(const float* __restrict__ cmap, long ldc, long cstrideB, const float* __restrict__ xtok, long ldx,
                                                         const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
-                                                        float* __restrict__ out, int Hc, int Wc, int Hx, int Wx, int C,
-                                                        float rh, float rw) {
+                                                        float* __restrict__ out, unsigned short* __restrict__ outp, long ldp,
+                                                        int Hc, int Wc, int Hx, int Wx, int C, float rh, float rw) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int pix0 = blockIdx.x * 32;          // pixel index within the image (h*Wc + w)
@@ -39,6 +39,13 @@ __global__ __launch_bounds__(256) void tail_fuse_kernel(const float* __restrict_
       const float v10 = xb[((long)h1 * Wx + w0) * ldx], v11 = xb[((long)h1 * Wx + w1) * ldx];
       const float r = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
       v = (v + r) * bn_scale[c] + bn_shift[c];
+      if (outp) {   // the same map token-major as interleaved planes: the A operand of the decode head's first 1x1 conv
+        unsigned short hh, ll;
+        split_bf16(v, hh, ll);
+        unsigned short* q_ = outp + ((long)b * npix + pix) * ldp + ilv(c);
+        q_[0] = hh;
+        q_[32] = ll;
+      }
     }
     tile[pl][tx] = v;
   }
@@ -53,14 +60,15 @@ __global__ __launch_bounds__(256) void tail_fuse_kernel(const float* __restrict_
 }
 
 extern "C" int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok, long ldx, const float* bn_scale,
-                              const float* bn_shift, float* out, int B, int Hc, int Wc, int Hx, int Wx, int C,
-                              hipStream_t stream) {
+                              const float* bn_shift, float* out, unsigned short* out_planes, long ldp, int B, int Hc, int Wc,
+                              int Hx, int Wx, int C, hipStream_t stream) {
   MMSA_CHECK_ARG(cmap && xtok && bn_scale && bn_shift && out, "tail_fuse: null pointer");
   MMSA_CHECK_ARG(B > 0 && Hc > 0 && Wc > 0 && Hx > 0 && Wx > 0 && C > 0, "tail_fuse: bad shape");
+  MMSA_CHECK_ARG(!out_planes || ((C & 31) == 0 && ldp >= 2L * C), "tail_fuse: planes output needs C % 32 == 0 and ldp >= 2C");
   // scale_factor s = Hc/Hx is what the reference passes (4, 2, 1, 0.5); PyTorch uses 1/s as the source step
   const float rh = (float)Hx / (float)Hc, rw = (float)Wx / (float)Wc;
   dim3 grid(cdiv((long)Hc * Wc, 32), cdiv(C, 32), B);
-  hipLaunchKernelGGL(tail_fuse_kernel, grid, dim3(256), 0, stream, cmap, ldc, cstrideB, xtok, ldx, bn_scale, bn_shift, out, Hc, Wc, Hx, Wx, C, rh, rw);
+  hipLaunchKernelGGL(tail_fuse_kernel, grid, dim3(256), 0, stream, cmap, ldc, cstrideB, xtok, ldx, bn_scale, bn_shift, out, out_planes, ldp, Hc, Wc, Hx, Wx, C, rh, rw);
   MMSA_CHECK_LAUNCH("tail_fuse");
   return MMSA_OK;
 }

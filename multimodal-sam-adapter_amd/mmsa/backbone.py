@@ -499,14 +499,20 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.split_planes(cbuf[bi * Nc:bi * Nc + n2], kpad=D, out=c2p.rows(bi * n2, (bi + 1) * n2))
         ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=n2 * 2 * D,
                  stride_r=(H // 4) * (W // 4) * D, stride_c=(H // 4) * (W // 4) * D, pixel_shuffle=(H // 8, W // 8, D))
-        f1 = torch.empty(B, D, H // 4, W // 4, device=dev)
-        ops.tail_fuse(c1, (H // 4) * (W // 4) * D, xs[1], *pk["bn"][0], f1, B, H // 4, W // 4, Hp, Wp)
-        f2 = torch.empty(B, D, H // 8, W // 8, device=dev)
-        ops.tail_fuse(cbuf, Nc * D, xs[2], *pk["bn"][1], f2, B, H // 8, W // 8, Hp, Wp)
-        f3 = torch.empty(B, D, Hp, Wp, device=dev)
-        ops.tail_fuse(cbuf[n2:], Nc * D, xs[3], *pk["bn"][2], f3, B, Hp, Wp, Hp, Wp)
-        f4 = torch.empty(B, D, H // 32, W // 32, device=dev)
-        ops.tail_fuse(cbuf[n2 + n3:], Nc * D, xs[4], *pk["bn"][3], f4, B, H // 32, W // 32, Hp, Wp)
+        # emit_planes (set by the decode head's caller, e.g. bench.py / mmsa.inference): every output map is also written
+        # token-major as interleaved planes and attached to the returned tensor (`_mmsa_planes`), so that mmsa.SegformerHead
+        # feeds its first 1x1 convs without the NCHW -> planes transposition of 0.7 GB per step
+        emit = bool(getattr(self, "emit_planes", False)) and D % 32 == 0
+        outs = []
+        for k, (src, cs, (hh, wwd)) in enumerate(((c1, (H // 4) * (W // 4) * D, (H // 4, W // 4)), (cbuf, Nc * D, (H // 8, W // 8)),
+                                                  (cbuf[n2:], Nc * D, (Hp, Wp)), (cbuf[n2 + n3:], Nc * D, (H // 32, W // 32)))):
+            f = torch.empty(B, D, hh, wwd, device=dev)
+            fpl = ws.planes(f"f{k + 1}_out", B * hh * wwd, D) if emit else None
+            ops.tail_fuse(src, cs, xs[k + 1], *pk["bn"][k], f, B, hh, wwd, Hp, Wp, out_planes=fpl)
+            if emit:
+                f._mmsa_planes = fpl
+            outs.append(f)
+        f1, f2, f3, f4 = outs
         return [f1, f2, f3, f4]
 
     # ------------------------------------------------------------------ SAM ViT block (IE:382-423)

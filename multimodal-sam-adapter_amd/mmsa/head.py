@@ -133,8 +133,10 @@ class SegformerHead(nn.Module):
             x = x.contiguous()
             h, w = x.shape[2:]
             rows = B * h * w
-            xp = self._planes(f"x{i}", rows, ci, dev)
-            lib.call("mmsa_nchw_to_planes", x.data_ptr(), ci * h * w, xp.p.data_ptr(), 2 * xp.kpad, B, ci, h * w, ops._stream())
+            xp = getattr(inputs[self.in_index[i]], "_mmsa_planes", None)   # written by the backbone's tail (emit_planes)
+            if not isinstance(xp, ops.Planes) or xp.n != rows or xp.k != ci or xp.p.device != dev:
+                xp = self._planes(f"x{i}", rows, ci, dev)
+                lib.call("mmsa_nchw_to_planes", x.data_ptr(), ci * h * w, xp.p.data_ptr(), 2 * xp.kpad, B, ci, h * w, ops._stream())
             br = pk["branch"][i]
             yp = self._planes(f"y{i}", rows, ch, dev)
             ops.gemm(xp, br["w"], bias=br["shift"], act="relu", out_planes=yp)

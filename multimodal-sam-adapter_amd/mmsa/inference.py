@@ -15,6 +15,13 @@ def _resize_into(logits, canvas, y0, x0, hc, wc, count=None, accumulate=False):
              y0, x0, hc, wc, count.data_ptr() if count is not None else None, 1 if accumulate else 0, ops._stream())
 
 
+def _pair(backbone, head):
+    """With this package's head behind this package's backbone, the backbone's tail also emits its maps as planes for the head."""
+    from .head import SegformerHead
+    if isinstance(head, SegformerHead) and hasattr(backbone, "_vit"):
+        backbone.emit_planes = True
+
+
 def _check(img):
     if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4:
         raise RuntimeError("mmsa.inference: img must be a float32 [B, C, H, W] GPU tensor (there is no CPU path)")
@@ -24,6 +31,7 @@ def _check(img):
 def encode_decode(backbone, head, img):
     """ED:85-95: logits of the head resized (bilinear, align_corners=False) to the input size -> [B, classes, H, W]."""
     _check(img)
+    _pair(backbone, head)
     feats, _ = backbone(img)
     lg = head(feats)
     out = torch.empty(img.shape[0], lg.shape[1], img.shape[2], img.shape[3], device=img.device)
@@ -56,6 +64,7 @@ def slide_inference(backbone, head, img, crop_size, stride, max_batch=8):
     if H < crop_size[0] or W < crop_size[1]:
         raise RuntimeError("mmsa.slide_inference: the image must be at least as large as the crop")
     boxes = crop_boxes(H, W, crop_size, stride)
+    _pair(backbone, head)
     preds = count = None
     jobs = [(b, box) for box in boxes for b in range(B)]
     for s in range(0, len(jobs), max_batch):

@@ -58,7 +58,7 @@ SIGNATURES = {
     "mmsa_gelu_gate": [P, L, P, L, L, I, P],
     "mmsa_pool_hw": [P, L, P, L, I, I, I, I, P],
     "mmsa_ca_apply": [P, L, P, L, P, L, P, L, I, I, I, I, P],
-    "mmsa_tail_fuse": [P, L, L, P, L, P, P, P, I, I, I, I, I, I, P],
+    "mmsa_tail_fuse": [P, L, L, P, L, P, P, P, P, L, I, I, I, I, I, I, P],
     "mmsa_global_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, F, P],
     "mmsa_window_attention_planes": [P, L, P, P, P, P, L, I, I, I, I, I, I, F, P],
     "mmsa_nchw_to_planes": [P, L, P, L, I, I, L, P],

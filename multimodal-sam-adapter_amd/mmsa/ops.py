@@ -395,8 +395,9 @@ def ca_apply(z, att, out, b, h, w, out_planes=None):
     return out if out is not None else out_planes
 
 
-def tail_fuse(cmap, cstride_b, xtok, bn_scale, bn_shift, out, b, hc, wc, hx, wx):
+def tail_fuse(cmap, cstride_b, xtok, bn_scale, bn_shift, out, b, hc, wc, hx, wx, out_planes=None):
     pc, _, c, ldc = _mat(cmap, "cmap")
     px, _, _, ldx = _mat(xtok, "xtok")
-    lib.call("mmsa_tail_fuse", pc, ldc, cstride_b, px, ldx, _chk(bn_scale), _chk(bn_shift), _chk(out), b, hc, wc, hx, wx, c, _stream())
+    pp, ldp = (out_planes.p.data_ptr(), 2 * out_planes.kpad) if out_planes is not None else (None, 0)
+    lib.call("mmsa_tail_fuse", pc, ldc, cstride_b, px, ldx, _chk(bn_scale), _chk(bn_shift), _chk(out), pp, ldp, b, hc, wc, hx, wx, c, _stream())
     return out

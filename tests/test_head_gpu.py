@@ -69,3 +69,23 @@ def test_head_rejects():
         head(make_head_inputs(HEAD_CONFIGS["head_tiny"]))  # CPU tensors: no CPU path
     with pytest.raises(NotImplementedError):
         head.train()
+
+
+def test_head_takes_planes_attached_by_the_backbone_tail():
+    """backbone.emit_planes: the tail writes f1..f4 also as token-major planes (attached to the returned tensors); the head then
+    skips its NCHW -> planes pass.  Same logits, bit for bit, as from the bare NCHW tensors."""
+    import mmsa
+    from tests.configs import CONFIGS, make_input
+    cfg, hcfg = CONFIGS["tiny256"], HEAD_CONFIGS["head_tiny"]
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m.load_state_dict(seeded_state_dict(m, seed=cfg["seed"]))
+    h = mmsa.build_head(dict(type="SegformerHead", **hcfg["kwargs"]))
+    h.load_state_dict(seeded_state_dict(h, seed=hcfg["seed"]))
+    h = h.to(DEV)
+    x = make_input(cfg, batch=2).to(DEV)
+    plain = h(m(x)[0]).clone()
+    m.emit_planes = True
+    fs = m(x)[0]
+    assert all(hasattr(f, "_mmsa_planes") for f in fs)
+    assert torch.equal(h(fs), plain)
+    assert torch.equal(h([f.clone() for f in fs]), plain)   # clones carry no planes: the transposing path again
