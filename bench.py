@@ -72,6 +72,8 @@ def main():
     torch.manual_seed(1234)
     model = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
     x = make_input(cfg, batch=a.batch, seed=1234 + rank).to(dev)
+    if os.environ.get("MMSA_FUSE_DWLN") == "1":   # A/B aid: ConvNeXt depthwise conv + LayerNorm as one kernel (slower: csrc/conv_ln.hip)
+        model.fuse_dwconv_ln = True
 
     head = None
     if not a.no_head:

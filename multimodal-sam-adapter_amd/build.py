@@ -10,7 +10,7 @@ OUT = os.path.join(HERE, "mmsa", "libmmsa_hip.so")
 
 
 # sources compiled without the SLP vectoriser: see the header of csrc/conv_pair.hip
-NO_SLP = {"conv_pair.hip"}
+NO_SLP = {"conv_pair.hip", "conv_ln.hip"}
 
 
 def needs_build():

@@ -670,9 +670,15 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             d = ws.get(t + "tmp", 2 * P, c)
             n = ws.planes(t + "n", 2 * P, c)
             hbuf = ws.planes(t + "h", 2 * P, 4 * c)
+            # one-kernel depthwise conv + LayerNorm (csrc/conv_ln.hip): correct, but slower than the pair (64 vs 31 + 26 us at
+            # C = 384: see its header) -- off unless asked for
+            fused = ops.dwconv7_ln_supported(c) and getattr(self, "fuse_dwconv_ln", False)
             for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
-                ops.dwconv(cur, blk["dw"], blk["dw_b"], d, 2 * B, hh, wwd, 7, imgs_per_group=B)
-                ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n, group_rows=P, w_gstride=c)
+                if fused:   # depthwise conv + LayerNorm in one kernel: the conv output never goes to memory
+                    ops.dwconv7_ln(cur, blk["dw"], blk["dw_b"], blk["nw"], blk["nb"], 1e-6, n, 2 * B, hh, wwd, imgs_per_group=B)
+                else:
+                    ops.dwconv(cur, blk["dw"], blk["dw_b"], d, 2 * B, hh, wwd, 7, imgs_per_group=B)
+                    ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n, group_rows=P, w_gstride=c)
                 ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf, batch=2, m=P, stride_a=P * 2 * n.kpad,
                          stride_w=blk["pw1"].n * 2 * blk["pw1"].kpad, stride_bias=4 * c, stride_cp=P * 2 * hbuf.kpad)
                 ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur, batch=2, m=P,

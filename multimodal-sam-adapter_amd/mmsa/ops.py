@@ -320,6 +320,19 @@ def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=N
     return out if out is not None else out_planes
 
 
+def dwconv7_ln(x, w, bias, ln_w, ln_b, eps, out_planes, b, h, wd, imgs_per_group=0):
+    """7x7 depthwise conv + LayerNorm over channels -> interleaved planes (ConvNeXt block front half, one kernel)."""
+    px, _, c, ldx = _mat(x, "x")
+    pp, _, _, ldp = out_planes.mat("y planes")
+    lib.call("mmsa_dwconv7_ln", px, ldx, h * wd * ldx, _chk(w), _chk(bias), _chk(ln_w), _chk(ln_b), eps, pp, ldp, h * wd * ldp,
+             b, h, wd, c, imgs_per_group, _stream())
+    return out_planes
+
+
+def dwconv7_ln_supported(c):
+    return c % 16 == 0 and 16 <= c <= 384
+
+
 def gconv(x, w, bias, out, b, h, wd, groups, cin_g, cout_g, k, act="none"):
     px, _, _, ldx = _mat(x, "x")
     po, _, _, ldo = _mat(out, "y")

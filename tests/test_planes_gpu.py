@@ -298,3 +298,27 @@ def test_gemm_persistent_tile_stream(ops, M, N, K, mode):
             assert_close(planes_to_float(outp), ref, tol=3e-5, what="planes output")
     assert_close(outs[0], ref, tol=3e-5, what=f"gemm {M}x{N}x{K} {mode}")
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("C,H,W", [(96, 19, 13), (192, 16, 24), (384, 9, 17), (32, 8, 8), (256, 5, 6)])
+def test_dwconv7_layernorm_fused(ops, C, H, W):
+    """ConvNeXt block front half in one kernel (7x7 depthwise conv + channel LayerNorm -> planes), two image groups with their own
+    conv and norm weights, partial edge tiles -- against torch in double."""
+    nimg, ipg = 4, 2
+    x = torch.randn(nimg, H, W, C, generator=g(130))
+    w = torch.randn(2, C, 7, 7, generator=g(131)) * 0.1
+    bias = torch.randn(2, C, generator=g(132)) * 0.1
+    lw, lb = torch.randn(2, C, generator=g(133)), torch.randn(2, C, generator=g(134))
+    ref = []
+    for i in range(nimg):
+        gi = i // ipg
+        y = F.conv2d(x[i].permute(2, 0, 1)[None].double(), w[gi].double()[:, None], bias[gi].double(), padding=3, groups=C)[0].permute(1, 2, 0)
+        ref.append(F.layer_norm(y, (C,), lw[gi].double(), lb[gi].double(), 1e-6))
+    ref = torch.stack(ref).reshape(nimg * H * W, C).float()
+    wt = w.reshape(2, C, 49).permute(0, 2, 1).contiguous().to(DEV)          # tap-major [groups][49][C]
+    outp = ops.alloc_planes(nimg * H * W, C, DEV)
+    ops.dwconv7_ln(x.reshape(nimg * H * W, C).to(DEV), wt, bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, outp, nimg, H, W, imgs_per_group=ipg)
+    assert_close(planes_to_float(outp), ref, tol=2e-5, what=f"dwconv7 + LN fused, C={C}")
+    again = ops.alloc_planes(nimg * H * W, C, DEV)
+    ops.dwconv7_ln(x.reshape(nimg * H * W, C).to(DEV), wt, bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, again, nimg, H, W, imgs_per_group=ipg)
+    assert torch.equal(again.p, outp.p)
