@@ -135,7 +135,7 @@ int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, co
                      int B, int H, int W, int C, int k, int act,
                      int imgs_per_group /* > 0: image group g = b / imgs_per_group uses w + g*k*k*C, bias + g*C */, mmsa_stream_t stream);
 /* ConvNeXt block front half fused: 7x7 depthwise conv (TC:69-70,102) + LayerNorm over channels (TC:103-106, eps as given) ->
-   interleaved planes [B*H*W, 2*Cpad] (the A operand of pointwise_conv1).  C: multiple of 16, <= 384.  Weights tap-major [49][C];
+   interleaved planes [B*H*W, 2*C] (the A operand of pointwise_conv1).  C: multiple of 64, <= 384.  Weights tap-major [49][C];
    imgs_per_group > 0: image group g = b / imgs_per_group uses w + g*49*C and bias / ln_w / ln_b + g*C. */
 int mmsa_dwconv7_ln(const float* x, long ldx, long xstrideB, const float* w, const float* bias, const float* ln_w, const float* ln_b,
                     float eps, uint16_t* y_planes, long ldp, long pstrideB, int B, int H, int W, int C, int imgs_per_group,

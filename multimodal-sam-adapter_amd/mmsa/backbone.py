@@ -670,8 +670,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             d = ws.get(t + "tmp", 2 * P, c)
             n = ws.planes(t + "n", 2 * P, c)
             hbuf = ws.planes(t + "h", 2 * P, 4 * c)
-            # one-kernel depthwise conv + LayerNorm (csrc/conv_ln.hip): correct, but slower than the pair (64 vs 31 + 26 us at
-            # C = 384: see its header) -- off unless asked for
+            # one-kernel depthwise conv + LayerNorm (csrc/conv_ln.hip): 42.6 vs 31 + 26 us at C = 384, but step-neutral (its
+            # 122-KiB workgroups push the overlapping neck streams off the CUs: see its header) -- off unless asked for
             fused = ops.dwconv7_ln_supported(c) and getattr(self, "fuse_dwconv_ln", False)
             for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
                 if fused:   # depthwise conv + LayerNorm in one kernel: the conv output never goes to memory

@@ -330,7 +330,7 @@ def dwconv7_ln(x, w, bias, ln_w, ln_b, eps, out_planes, b, h, wd, imgs_per_group
 
 
 def dwconv7_ln_supported(c):
-    return c % 16 == 0 and 16 <= c <= 384
+    return c % 64 == 0 and 64 <= c <= 384
 
 
 def gconv(x, w, bias, out, b, h, wd, groups, cin_g, cout_g, k, act="none"):

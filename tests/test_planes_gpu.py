@@ -300,7 +300,7 @@ def test_gemm_persistent_tile_stream(ops, M, N, K, mode):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("C,H,W", [(96, 19, 13), (192, 16, 24), (384, 9, 17), (32, 8, 8), (256, 5, 6)])
+@pytest.mark.parametrize("C,H,W", [(64, 19, 13), (192, 16, 24), (384, 9, 17), (128, 8, 8), (256, 5, 6), (384, 64, 64)])
 def test_dwconv7_layernorm_fused(ops, C, H, W):
     """ConvNeXt block front half in one kernel (7x7 depthwise conv + channel LayerNorm -> planes), two image groups with their own
     conv and norm weights, partial edge tiles -- against torch in double."""
