@@ -7,6 +7,7 @@
 //                 K order = (c, kh, kw) = the reference weight's flattened order, zero padded to Kpad.
 // These are fp32 VALU kernels (exact fp32 like the reference), 16-byte channel vectors per lane.
 #include "common.h"
+#include <stdlib.h>
 
 // weights repacked tap-major: w[(kh*k+kw)*C + c]
 __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restrict__ x, long ldx, long xstrideB,
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(256) void gconv_tiled_kernel(const float* __restric
 // vectoriser (build.py).
 int mmsa_dwpair_nhwc_launch(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W, int C, hipStream_t stream);
 
+bool mmsa_gconv3_mfma_launch(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W, int G, int cin_g,
+                             int cout_g, hipStream_t stream);   // gconv_mfma.hip
+
 template <int COUT>
 static void launch_gconv_tiled(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W, int G,
                                int cin_g, int k, hipStream_t stream) {
@@ -261,6 +265,11 @@ extern "C" int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const f
                                int B, int H, int W, int G, int cin_g, int cout_g, int k, int act, hipStream_t stream) {
   MMSA_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && G > 0 && cin_g > 0 && cout_g > 0, "gconv_nhwc: bad args");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "gconv_nhwc: odd kernel <= 7 expected, got %d", k);
+  static const bool no_mfma = getenv("MMSA_GCONV_VALU") != nullptr;   // A/B aid: the FMA kernels for the 3x3 case too
+  if (!bias && act == ACT_NONE && k == 3 && !no_mfma && mmsa_gconv3_mfma_launch(x, ldx, w, y, ldy, B, H, W, G, cin_g, cout_g, stream)) {
+    MMSA_CHECK_LAUNCH("gconv_nhwc(3x3 mfma)");
+    return MMSA_OK;
+  }
   if (!bias && act == ACT_NONE && (k == 1 || k == 3)) {
     bool done = true;
     switch (cout_g) {

@@ -432,3 +432,21 @@ def test_tail_fuse(ops, scale):
                   xt.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), inv.to(DEV),
                   (bn.bias.data - bn.running_mean * inv).to(DEV), out, B, Hc, Wc, Hx, Wx)
     assert_close(out, ref, tol=1e-5, what=f"tail x{scale}")
+
+
+@pytest.mark.parametrize("cg,H,W", [(9, 19, 33), (18, 16, 16), (36, 21, 17), (72, 32, 32), (3, 7, 5), (40, 9, 9)])
+def test_gconv3_on_the_matrix_pipe(ops, cg, H, W):
+    """Grouped 3x3 conv (groups 32, cin_g = cout_g) as an fp32-MFMA implicit GEMM: the GFE qkv2 widths of the four neck levels,
+    partial tiles, channel counts that are not multiples of the 8-channel chunk or of the 16-column n-tile."""
+    B, groups = 2, 32
+    conv = torch.nn.Conv2d(cg * groups, cg * groups, 3, padding=1, groups=groups, bias=False)
+    x = torch.randn(B, cg * groups, H, W, generator=g(140))
+    ref = conv(x.double().float()).detach()
+    ref64 = F.conv2d(x.double(), conv.weight.detach().double(), padding=1, groups=groups).float()
+    w = conv.weight.detach().reshape(groups, cg, cg, 9).permute(0, 3, 2, 1).contiguous().to(DEV)
+    out = torch.full((B * H * W, cg * groups), float("nan"), device=DEV)
+    ops.gconv(x.permute(0, 2, 3, 1).reshape(-1, cg * groups).contiguous().to(DEV), w, None, out, B, H, W, groups, cg, cg, 3)
+    assert_close(out.view(B, H, W, -1).permute(0, 3, 1, 2), ref64, tol=1e-5, what=f"gconv 3x3 cin_g=cout_g={cg}")
+    again = torch.empty_like(out)
+    ops.gconv(x.permute(0, 2, 3, 1).reshape(-1, cg * groups).contiguous().to(DEV), w, None, again, B, H, W, groups, cg, cg, 3)
+    assert torch.equal(out, again)
