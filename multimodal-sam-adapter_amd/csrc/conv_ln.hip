@@ -12,8 +12,8 @@
 //   * the 16 lanes that share a strip are one DPP row: the LayerNorm sums (mean, then centred second moment) are 4 xor-shuffles,
 //     no LDS, no barrier, fixed order (bit-identical run to run); biased variance, per-stream weights.
 // Measured (ViT-L step, stage 2, C = 384, 4 images of 64 x 64): 42.6 us against 31 + 26 us for the kernel pair, 73 against ~80 us at
-// C = 192 -- but the STEP does not get faster (37.7 ms either way): a 122-KiB workgroup owns its CU, so the neck levels that run on
-// side streams underneath the ConvNeXt chain lose the CUs the small-LDS pair leaves them.  Hence off by default
+// C = 192 -- but neither the ConvNeXt chain alone (8.10 vs 8.13 ms, tools/spm_time.py) nor the step (37.7 ms) gets faster: in the
+// replayed graph the tail of one small kernel overlaps the ramp of the next, which one 122-KiB workgroup per CU cannot.  Hence off by default
 // (backbone.fuse_dwconv_ln); kept as a tested operator.  History: one 4 x 4 x all-channel tile per workgroup (154 KiB halo, 6.25 x
 // input re-reads) took 64.6 us; this layout with the tap weights fetched from L2 per kernel row took 79 us (one L2 round trip per
 // row and wave, nothing to hide it behind at one wave per SIMD) -- staging them in LDS gave 42.6 us.
