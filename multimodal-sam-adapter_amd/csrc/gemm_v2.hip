@@ -35,6 +35,8 @@ struct GemmV2Args {
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;
   int nbm, nbn, ntiles;
+  int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
+               // that fills the CUs better: N = 384 gives 3 tiles of 128 (192 tiles on 256 CUs for the ConvNeXt pw2 GEMMs) or 4 of 96 (256 tiles)
   int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 10 = epilogue without its global stores
 };
 
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     const int per_b_ = a.nbm * a.nbn;                                            \
     const int bz_ = t_ / per_b_;                                                 \
     const int r_ = t_ - bz_ * per_b_;                                            \
-    const int m0_ = (r_ / a.nbn) * V2_BM, n0_ = (r_ % a.nbn) * V2_BN;            \
+    const int m0_ = (r_ / a.nbn) * V2_BM, n0_ = (r_ % a.nbn) * a.bn;             \
     const int ab_ = m0_ + wave * 32 + drow, wb_ = n0_ + wave * 16 + drow;        \
     const unsigned short* ap_ = a.Ap + (long)bz_ * a.strideA;                    \
     const unsigned short* wp_ = a.Wp + (long)bz_ * a.strideW;                    \
@@ -145,7 +147,9 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   const int frag_hi = l15 * 128 + fslot * 16;
   const int frag_lo = l15 * 128 + (fslot ^ 4) * 16;
   const int fa = (wm * 64) * 128;                    // activation rows of this wave, + mi*2048
-  const int fw = V2_A_BYTES + (wn * 64) * 128;       // weight rows of this wave, + ni*2048
+  const bool ni4 = a.bn == V2_BN;                    // wave-uniform: four n-tiles per wave (128-column tiles) or three (96)
+  const int swid = ni4 ? 64 : 48;                    // columns of this wave's strip
+  const int fw = V2_A_BYTES + (wn * swid) * 128;     // weight rows of this wave, + ni*2048
 
   // ---- prefetch cursor (runs 2 iterations ahead of the compute cursor)
   int pf_tile = rb, pf_kt = 0, pf_st = 0, pf_j = 0;
@@ -201,8 +205,10 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
     }                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
-      wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                             \
-      wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                             \
+      if (i < 3 || ni4) {                                                                                   \
+        wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                           \
+        wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                           \
+      }                                                                                                     \
     }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     MFMA_CHUNK(0)                                                                                           \
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (do_pf) { GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w); GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024); } \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    MFMA_CHUNK(3)                                                                                           \
+    if (ni4) { MFMA_CHUNK(3) }                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (do_pf) {   /* advance the prefetch cursor (source pointers of the next output tile when the k loop wraps) */ \
       pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                   \
@@ -281,8 +287,10 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
     }                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
-      wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                             \
-      wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                             \
+      if (i < 3 || ni4) {                                                                                   \
+        wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                           \
+        wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                           \
+      }                                                                                                     \
     }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     STAMP(1)                                                                                                \
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
     MFMA_CHUNK(2)                                                                                           \
-    MFMA_CHUNK(3)                                                                                           \
+    if (ni4) { MFMA_CHUNK(3) }                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (do_pf) {                                                                                            \
       pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                   \
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       const int per_b = a.nbm * a.nbn;
       const int bz = tile / per_b;
       const int rt = tile - bz * per_b;
-      const int m0 = (rt / a.nbn) * V2_BM, n0 = (rt % a.nbn) * V2_BN;
+      const int m0 = (rt / a.nbn) * V2_BM, n0 = (rt % a.nbn) * a.bn;
       const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
       const float* colscale = a.colscale ? a.colscale + (long)bz * a.strideBias : nullptr;   // per-column vectors share the batch stride
       const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
@@ -358,10 +366,11 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
         nowait = 2;
       }
       float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
-      const int nb_ = n0 + wn * 64;
+      const int nb_ = n0 + wn * swid;
       const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
       const int cl = (lane & 15) * 4;
-      const int n = nb_ + cl;
+      const bool lane_ok = cl < swid;        // 96-column tiles: the lanes of the (skipped) fourth n-tile only keep the loads in bounds
+      const int n = nb_ + (lane_ok ? cl : 0);
       // column parameters of this lane's 4 columns: loaded ONCE per tile, unconditionally (clamped index)
       float bv[4], cv[4];
 #pragma unroll
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       };
       // wave-uniform: whole 64-column strip inside N, 16-byte aligned (and, for the planes output of a pixel-shuffle
       // store, inside one destination row: ps_C a multiple of 64)
-      const bool fast = vec_ok && (nb_ + 64 <= a.N) && (!GEN || !Cp || a.out_mode != 1 || (a.ps_C & 63) == 0);
+      const bool fast = vec_ok && (nb_ + swid <= a.N) && (ni4 || !Cp) && (!GEN || !Cp || a.out_mode != 1 || (a.ps_C & 63) == 0);
       // The four 16-row sub-tiles are handled by a ROLLED loop: the code always takes accumulator column 0 and then
       // rotates the columns down by register moves (48 v_mov per pass).  Fully unrolled -- with the activation switch
       // expanded per element -- the epilogue was ~100 KiB of straight-line code, far beyond the 64 KiB instruction
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             }
             const int m = mb + rl;
             if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
-            else if (m < a.M) {
+            else if (m < a.M && lane_ok) {
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
               if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             const int i = e >> 2, r = e & 3;
             const int rl = rl0 + 4 * i;
             const int m = mb + rl;
-            if (m >= a.M || n + r >= a.N) continue;
+            if (m >= a.M || n + r >= a.N || !lane_ok) continue;
             float x = stg[rl * 68 + cl + r];
             {
               int ci = n + r;
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             }
             const int m = mb + rl;
             if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
-            else if (m < a.M) {
+            else if (m < a.M && lane_ok) {
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
               if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
@@ -542,7 +551,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
             const int i = e >> 2, r = e & 3;
             const int rl = rl0 + 4 * i;
             const int m = mb + rl;
-            if (m >= a.M || n + r >= a.N) continue;
+            if (m >= a.M || n + r >= a.N || !lane_ok) continue;
             float x = stg[rl * 68 + cl + r];
             {
               int ci = n + r;
@@ -599,6 +608,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
   a.nbm = cdiv(M, V2_BM);
+  a.bn = V2_BN;
   a.nbn = cdiv(N, V2_BN);
   a.ntiles = a.nbm * a.nbn * batch;
   static const int dbg = getenv("MMSA_GEMM_DEBUG") ? atoi(getenv("MMSA_GEMM_DEBUG")) : 0;
@@ -617,6 +627,20 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1)
 #undef V2_ATTR
+  }
+  // 96-column tiles when they occupy the CUs better: rounds(tiles) x relative tile cost (0.75) against rounds of 128-column tiles.
+  // fp32 output only (the planes epilogue writes whole 64-column strips) and no pixel-shuffle / broadcast-residual store.
+  if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96) {
+    static const bool no96 = getenv("MMSA_GEMM_NO96") != nullptr;   // A/B aid
+    const int nbn96 = cdiv(N, 96);
+    const long t96 = (long)a.nbm * nbn96 * batch;
+    const double c128 = (double)cdiv(a.ntiles, g_num_cus), c96 = 0.75 * (double)cdiv(t96, g_num_cus);
+    // same number of column tiles -> nothing to gain from narrower ones (ragged last tile aside)
+    if (!no96 && c96 < c128 - 1e-9) {
+      a.bn = 96;
+      a.nbn = nbn96;
+      a.ntiles = (int)t96;
+    }
   }
   const int grid = a.ntiles < g_num_cus ? a.ntiles : g_num_cus;   // one resident workgroup per CU (144 KiB LDS each)
   const bool gen = out_mode != 0 || resid_mod > 0;

@@ -268,7 +268,11 @@ def test_global_attention_fused_relpos(ops, H):
     (9000, 1100, 160, "P"),       # 324 tiles, 5 k-tiles, planes-only output, ragged right edge
     (33000, 130, 32, "C"),        # one k-tile per output tile: every k-tile is a tile boundary
     (600, 4100, 64, "CP"),        # 3 x 33 tiles, two k-tiles, both outputs
-    (66000, 384, 1536, "Cres"),   # deep K, residual, 774 tiles
+    (66000, 384, 1536, "Cres"),   # deep K, residual, 774 tiles of 128 columns -> 1032 tiles of 96 columns (fewer idle CUs in the last round)
+    (16384, 384, 1536, "Cres"),   # the ConvNeXt stage-2 pw2 shape: 192 tiles of 128 columns -> 256 tiles of 96
+    (43008, 192, 1024, "C"),      # MSDA offsets + weights projection: 336 tiles either way, 96-column tiles are 3/4 of the work
+    (8192, 576, 1024, "C"),       # injector projection: 160 -> 192 tiles
+    (5000, 300, 64, "C"),         # 96-column tiles with a ragged right edge (300 = 3 x 96 + 12) and a ragged bottom
 ])
 def test_gemm_persistent_tile_stream(ops, M, N, K, mode):
     """The LDS-DMA kernel's continuous (tile, k-tile) stream: several output tiles per workgroup, few k-tiles per tile, ragged
