@@ -6,13 +6,25 @@
 
 A "step" = one forward of the drop-in backbone `SAMAdapterbimodalMixModNewInTwinConvNEW` (ViT-L SAM encoder +
 RGB+LiDAR adapter, BASELINE configs[1]: 1024x1024, batch 2 per GPU) followed by the drop-in `SegformerHead`
-(-> logits [B,25,256,256]) on synthetic tensors that are already resident in HBM, random-init weights of that
-architecture.  N > 1: one process per GPU, the batch is sharded (weak scaling: 2 images per rank, nothing shared on
-the data path) and every step ends with the pipeline's ONE exchange: an RCCL all-gather of the per-rank logits
-(SURVEY 8e).  The step is the same at every N (at N=1 the gather is the identity), so per-N values are comparable.
-`--no-head` times the encoder forward alone; the default run also reports it as `encoder_only`.
+(-> logits [B,25,256,256]) on synthetic tensors that are already resident in HBM, weights of that architecture from
+the build's seeded "live" generator (tests/weights.py: every parameter and buffer non-trivial -- the same weights the
+golden vectors of tests/golden/model_vitl1024.npz were captured with).  N > 1: one process per GPU, the batch is
+sharded (weak scaling: 2 images per rank, nothing shared on the data path) and every step ends with the pipeline's ONE
+exchange: an RCCL all-gather of the per-rank logits.  The step is the same at every N (at N=1 the gather is
+the identity), so per-N values are comparable.  `--no-head` times the encoder forward alone; the default run also
+reports it as `encoder_only`.
+
+`--gpus N` with no WORLD_SIZE in the environment: this process starts the N ranks itself (one child per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, reference launch pattern segmentation/dist_test.sh:7-9) BEFORE it makes any GPU
+call and relays rank 0's JSON line.  Under an existing WORLD_SIZE (torch.distributed.run) it is one of the ranks.
+
 Rank 0 prints ONE JSON line; `value` is the whole-job images/s (max-over-ranks time, barrier + synchronize on both
 sides of exactly K steps).
+
+What is timed is what is verified (`verified` object, checked OUTSIDE the timed region on every rank):
+  * the HIP-graph replay of the step returns, bit for bit, what the eager launch sequence returns;
+  * with the golden input of tests/golden/model_vitl1024.npz copied into image 0 of the graph's input buffer, the
+    REPLAYED graph's f1..f4 match the reference's golden probes within the 1e-3 gate.
 
 Extra objects:
   roofline     -- the dominant kernel family (the split3 GEMM: gemm_v2_kernel / gemm_split3_kernel): algorithmic FLOPs
@@ -20,11 +32,16 @@ Extra objects:
                   measured live in a single-stream profiled pass of one step right after the timed region (events on
                   the launch stream), against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline -- the CPU oracle (oracle/ref_encoder.py, a PyTorch-CPU restatement validated against the reference)
-                  timed on this box's host cores on ONE 1024x1024 image (rank 0, N=1 only).
+                  timed on this box's physical host cores on ONE 1024x1024 image (rank 0, N=1 only): one small warm-up
+                  forward, then the median of up to 3 runs inside a 45 s budget.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -33,25 +50,92 @@ for p in (ROOT, os.path.join(ROOT, "multimodal-sam-adapter_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-FLOPS_PER_IMAGE = 4.5207e12      # algorithmic GEMM/conv/bmm FLOPs per 1024^2 ViT-L image
+FLOPS_PER_IMAGE = {"vitl1024": 4.5207e12, "vitb512": 0.5411e12}   # algorithmic GEMM/conv/bmm FLOPs per image
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (BASELINE configs[1]: 2)")
-    ap.add_argument("--config", default="vitl1024", choices=["vitl1024", "vitb512", "tiny256"])
+    ap.add_argument("--config", default="vitl1024", choices=["vitl1024", "vith1024", "vitb512", "tiny256"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed graph-vs-eager / golden-probe checks")
+    ap.add_argument("--default-init", action="store_true", help="A/B aid: default-init weights instead of the seeded live generator")
     ap.add_argument("--no-head", action="store_true", help="time the encoder forward only (no decode head, no all-gather)")
-    a = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """Parent of a self-launched multi-GPU run: starts one child per GPU and relays rank 0's stdout.  Makes no GPU call
+    (torch.cuda.device_count() does not initialise the device on this image)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"[bench] --gpus {n} asked for but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout.read().decode()
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def physical_cores():
+    """(physical core count, CPU model name) from /proc/cpuinfo; falls back to os.cpu_count()."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(n, 1), model
+
+
+def latest_profile(pattern):
+    """Newest profiles/rNN_<pattern> (round number order)."""
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{pattern}")))
+    return fs[-1] if fs else None
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -66,24 +150,33 @@ def main():
 
     import mmsa
     from mmsa.dist import allgather_logits
-    from tests.configs import CONFIGS, HEAD_CONFIGS, make_input
+    from tests.configs import CONFIGS, HEAD_CONFIGS, make_input, probe_index
+    from tests.weights import seeded_state_dict
 
     cfg = CONFIGS[a.config]
     torch.manual_seed(1234)
     model = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    if not a.default_init:
+        model.load_state_dict(seeded_state_dict(model, seed=cfg["seed"]))
     x = make_input(cfg, batch=a.batch, seed=1234 + rank).to(dev)
     if os.environ.get("MMSA_FUSE_DWLN") == "1":   # A/B aid: ConvNeXt depthwise conv + LayerNorm as one kernel (slower: csrc/conv_ln.hip)
         model.fuse_dwconv_ln = True
 
     head = None
     if not a.no_head:
-        hkw = dict(HEAD_CONFIGS["head_vitl"]["kwargs"])
+        hcfg = HEAD_CONFIGS["head_vitl"]
+        hkw = dict(hcfg["kwargs"])
         hkw["in_channels"] = [cfg["kwargs"]["embed_dim"]] * 4
         head = mmsa.build_head(dict(type="SegformerHead", **hkw))
+        if not a.default_init:
+            head.load_state_dict(seeded_state_dict(head, seed=hcfg["seed"]))
         model.emit_planes = os.environ.get("MMSA_EMIT_PLANES", "1") == "1"   # the tail also writes its four maps as planes: the head skips its NCHW -> planes pass
 
+    feats = [None]
+
     def encoder_step():
-        return model(x)[0]
+        feats[0] = model(x)[0]
+        return feats[0]
 
     def local_step():                      # everything that is captured in the HIP graph
         fs = encoder_step()
@@ -134,6 +227,7 @@ def main():
         return dt
 
     replay, local_out, graphed = capture(local_step)
+    graph_feats = feats[0]                 # the four output maps the captured graph writes (fixed addresses)
     gathered = [None]
 
     def run():
@@ -142,11 +236,51 @@ def main():
             gathered[0] = allgather_logits(local_out)
 
     dt = timed(run)
-    graph = graphed or None
     imgs = a.batch * world * a.steps
     value = imgs / dt
     if head is not None and use_dist and rank == 0:
         assert gathered[0].shape[0] == world * a.batch
+
+    # ---- what was timed is what is verified (untimed; every rank)
+    verified = None
+    if not a.no_verify:
+        verified = {}
+        replay()
+        torch.cuda.synchronize()
+        got_out = local_out.clone()
+        got_f = [f.clone() for f in graph_feats]
+        if graphed:
+            e_out = local_step()
+            torch.cuda.synchronize()
+            same = bool(torch.equal(e_out, got_out)) and all(bool(torch.equal(u, v)) for u, v in zip(feats[0], got_f))
+            verified["graph_replay_equals_eager_bitwise"] = same
+            if not same:
+                raise SystemExit("[bench] the HIP-graph replay does not reproduce the eager step bit for bit")
+        gfile = os.path.join(ROOT, "tests", "golden", f"model_{a.config}.npz")
+        if os.path.exists(gfile) and not a.default_init:
+            import numpy as np
+            g = np.load(gfile)
+            if any(k.endswith("_probe") for k in g.files):
+                keep = x[0].clone()
+                x[0].copy_(make_input(cfg, batch=1)[0].to(dev))       # the golden input into image 0 of the graph's input buffer
+                replay()
+                torch.cuda.synchronize()
+                worst = 0.0
+                for i, f in enumerate(graph_feats):
+                    f0 = f[0]
+                    pi = probe_index(f0.numel(), 2048, seed=100 + i).to(dev)
+                    got = f0.flatten()[pi].double().cpu()
+                    ref = torch.from_numpy(g[f"f{i+1}_probe"]).double()
+                    r = float((got - ref).norm() / ref.norm())
+                    mx = float((got - ref).abs().max() / ref.abs().max())
+                    worst = max(worst, r, mx)
+                verified["replayed_graph_vs_reference_golden_probes_max_rel"] = round(worst, 7)
+                verified["golden"] = f"tests/golden/model_{a.config}.npz (f1..f4, 2048 probes each, image 0)"
+                if not worst <= 1e-3:
+                    raise SystemExit(f"[bench] replayed graph misses the golden probes: {worst:.3e} > 1e-3")
+                x[0].copy_(keep)
+                replay()
+                torch.cuda.synchronize()
 
     encoder_only = None
     if head is not None and world == 1:
@@ -168,19 +302,19 @@ def main():
         flops, ms = mmsa.ops.collect_gemm_profile(prof)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic, tnote = None, "not measured"
-        tfile = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")   # written by tools/pmc_traffic.sh (rocprofv3 --pmc passes)
-        if os.path.exists(tfile) and a.config == "vitl1024":
+        tfile = latest_profile("gemm_traffic.json")   # written by tools/pmc_traffic.sh (rocprofv3 --pmc passes)
+        if tfile and a.config == "vitl1024":
             tj = json.load(open(tfile))
             traffic = round(tj["traffic_bytes_per_launch"])
-            tnote = ("HBM-side bytes per launch (average over the step's GEMM launches) from profiles/r01_gemm_traffic.json: rocprofv3 "
+            tnote = (f"HBM-side bytes per launch (average over the step's GEMM launches) from profiles/{os.path.basename(tfile)}: rocprofv3 "
                      "--pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes of this workload")
-        mfile = os.path.join(ROOT, "profiles", "r01_mfma_util.json")   # written by tools/pmc_mfma.sh (rocprofv3 --pmc MfmaUtil / MOPS passes)
+        mfile = latest_profile("mfma_util.json")   # written by tools/pmc_mfma.sh (rocprofv3 --pmc MfmaUtil / MOPS passes)
         mfma = None
-        if os.path.exists(mfile) and a.config == "vitl1024":
+        if mfile and a.config == "vitl1024":
             mj = json.load(open(mfile))
             mfma = {"gemm_family_mfma_util_pct": round(mj["gemm_family"]["mfma_util_pct"], 1), "gemm_family_mfma_tflops_counted": round(mj["gemm_family"]["mfma_tflops"], 1),
                     "whole_step_mfma_util_pct": round(mj["whole_step"]["mfma_util_pct"], 1), "whole_step_mfma_tflops_counted": round(mj["whole_step"]["mfma_tflops"], 1),
-                    "source": "profiles/r01_mfma_util.json: rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{BF16,F32} passes of this workload"}
+                    "source": f"profiles/{os.path.basename(mfile)}: rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{{BF16,F32}} passes of this workload"}
         roofline = {"bound": "mfma", "kernel": "split3 GEMM (gemm_v2_kernel + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                     "compulsory_bytes_per_launch": round(mmsa.ops.collect_gemm_profile.bytes / max(len(prof), 1)),
@@ -191,31 +325,41 @@ def main():
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.config == "vitl1024":
         from oracle import ref_encoder as R  # CPU baseline leg only
+        ncores, cpu_model = physical_cores()
+        torch.set_num_threads(ncores)
+        tiny = CONFIGS["tiny256"]
+        R.OracleEncoder(**tiny["kwargs"])(make_input(tiny, batch=1))      # warm-up: thread pool, oneDNN primitives
         orc = R.OracleEncoder(**cfg["kwargs"])
         xc = make_input(cfg, batch=1, seed=1234)
-        nthr = torch.get_num_threads()
-        tc = time.perf_counter()
-        orc(xc)
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": round(1.0 / tcpu, 4), "unit": "images/s", "cores": nthr, "kind": "port",
-               "sample": f"1 image 1024x1024 ViT-L RGB+LiDAR, fp32 PyTorch-CPU oracle, {tcpu:.1f} s"}
+        times, t_all = [], time.perf_counter()
+        while len(times) < 3 and (not times or time.perf_counter() - t_all + times[-1] < 45.0):
+            tc = time.perf_counter()
+            orc(xc)
+            times.append(time.perf_counter() - tc)
+        tcpu = statistics.median(times)
+        cpu = {"value": round(1.0 / tcpu, 4), "unit": "images/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model,
+               "sample": f"1 image 1024x1024 ViT-L RGB+LiDAR, fp32 PyTorch-CPU oracle, {ncores} threads (physical cores), tiny warm-up forward then "
+                         f"median of {len(times)} run(s): " + ", ".join(f"{t:.1f}" for t in times) + " s"}
 
     if rank == 0:
-        end_to_end_tflops = value * FLOPS_PER_IMAGE / 1e12 if a.config == "vitl1024" else None
+        fpi = FLOPS_PER_IMAGE.get(a.config)
+        headline = a.config == "vitl1024"
         out = {
             "metric": "images/sec encoder fwd @1024x1024 RGB+LiDAR ViT-L",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3-split MFMA (fp32 accumulate, fp32 activations)", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
-                       if a.config == "vitl1024" else f"{a.config} (not the BASELINE workload)",
+                       if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else
                                 "encoder forward + SegformerHead logits [B,25,H/4,W/4] + all-gather of logits across ranks",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       "weights": "default init" if a.default_init else "seeded live generator (tests/weights.py), every parameter / buffer non-trivial",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graphed),
                        "collective": ("one RCCL all_gather_into_tensor of the logits per step" if (head is not None and use_dist)
                                       else "none (single rank)" if head is not None else "none (encoder only)")},
+            "verified": verified,
             "encoder_only": encoder_only,
-            "end_to_end_algorithmic_tflops": round(end_to_end_tflops, 1) if end_to_end_tflops else None,
+            "end_to_end_algorithmic_tflops": round(value * fpi / 1e12, 1) if fpi else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         try:   # RCCL prints a banner through C stdio; flush it so that the JSON line is the LAST line of stdout

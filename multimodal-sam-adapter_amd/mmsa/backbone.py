@@ -421,11 +421,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         return self._ws.get("c1" + tag, B * (H // 4) * (W // 4), D), self._ws.get("c" + tag, B * Nc, D), Nc
 
     def forward(self, x):
-        x, B, H, W = self._prepare(x)
-        # ---- spatial prior module -> c1, c
-        c1, cbuf, Nc = self._cbufs(B, H, W)
-        c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
-        return self._vit(x, B, H, W, c1, cbuf, c1_ready), None
+        if not x.is_cuda:
+            raise RuntimeError("mmsa: input must be a GPU tensor; the MI355X backbone has no CPU path")
+        with torch.cuda.device(x.device):    # launches go to the current stream of the input's device
+            x, B, H, W = self._prepare(x)
+            # ---- spatial prior module -> c1, c
+            c1, cbuf, Nc = self._cbufs(B, H, W)
+            c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
+            return self._vit(x, B, H, W, c1, cbuf, c1_ready), None
 
     def forward_pipelined(self, x_next):
         """Throughput mode (two-stage software pipeline over consecutive batches).  The spatial prior module depends only on
@@ -436,6 +439,13 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         outputs it returns (None on the first call; pass None to drain).  Per batch the arithmetic and the results are those of
         forward(), bit for bit."""
         cur = getattr(self, "_pl_cur", None)
+        dev_ = x_next.device if x_next is not None else (cur["x"].device if cur is not None else None)
+        if dev_ is None:
+            return None
+        with torch.cuda.device(dev_):
+            return self._forward_pipelined(x_next, cur)
+
+    def _forward_pipelined(self, x_next, cur):
         main = torch.cuda.current_stream()
         nxt = None
         if x_next is not None:
@@ -503,6 +513,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # token-major as interleaved planes and attached to the returned tensor (`_mmsa_planes`), so that mmsa.SegformerHead
         # feeds its first 1x1 convs without the NCHW -> planes transposition of 0.7 GB per step
         emit = bool(getattr(self, "emit_planes", False)) and D % 32 == 0
+        if not hasattr(self, "_planes_gen"):
+            self._planes_gen = [0]
+        self._planes_gen[0] += 1     # the f*_out planes of earlier calls are overwritten below: their holders see live() == False
         outs = []
         for k, (src, cs, (hh, wwd)) in enumerate(((c1, (H // 4) * (W // 4) * D, (H // 4, W // 4)), (cbuf, Nc * D, (H // 8, W // 8)),
                                                   (cbuf[n2:], Nc * D, (Hp, Wp)), (cbuf[n2 + n3:], Nc * D, (H // 32, W // 32)))):
@@ -510,7 +523,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             fpl = ws.planes(f"f{k + 1}_out", B * hh * wwd, D) if emit else None
             ops.tail_fuse(src, cs, xs[k + 1], *pk["bn"][k], f, B, hh, wwd, Hp, Wp, out_planes=fpl)
             if emit:
-                f._mmsa_planes = fpl
+                f._mmsa_planes = fpl.stamp(self._planes_gen)
             outs.append(f)
         f1, f2, f3, f4 = outs
         return [f1, f2, f3, f4]

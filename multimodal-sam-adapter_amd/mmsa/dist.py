@@ -29,15 +29,35 @@ def shard_range(global_batch, rk=None, ws=None):
     return lo, lo + base + (1 if rk < rem else 0)
 
 
-def allgather_logits(local):
-    """[B_loc, ...] on every rank -> [world * B_loc, ...] (rank-major) with ONE collective."""
+def allgather_logits(local, global_batch=None):
+    """[B_loc, ...] on every rank -> [global batch, ...] (rank-major) with ONE collective.
+
+    `global_batch` = None: every rank holds the same number of images (the bench's weak-scaling step).  With a global batch that
+    `shard_range` split unevenly (not divisible by the world size) pass it: every rank pads its shard to ceil(global_batch / world)
+    images, so the collective has identical sizes everywhere, and the padding is dropped after the gather."""
     ws = world()
     if ws == 1:
         return local
     local = local.contiguous()
-    out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if global_batch is None:
+        out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local)
+        return out
+    sizes = [shard_range(global_batch, r, ws) for r in range(ws)]
+    mine = sizes[rank()][1] - sizes[rank()][0]
+    if local.shape[0] != mine:
+        raise ValueError(f"rank {rank()} holds {local.shape[0]} images but its shard of a global batch of {global_batch} is {mine}")
+    cap = max(hi - lo for lo, hi in sizes)
+    if cap == 0:
+        return local
+    if mine < cap:
+        pad = torch.zeros((cap - mine,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((ws * cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
-    return out
+    if all(hi - lo == cap for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * cap:r * cap + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 
 def max_over_ranks(seconds, device):

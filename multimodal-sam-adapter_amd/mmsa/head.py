@@ -78,6 +78,13 @@ class SegformerHead(nn.Module):
     def init_weights(self):
         pass
 
+    def forward_test(self, inputs, img_metas=None, test_cfg=None):
+        """BaseDecodeHead.forward_test (mmseg 0.20.2; called by EncoderDecoder._decode_head_forward_test, ED:129-133)."""
+        return self.forward(inputs)
+
+    def forward_train(self, inputs, img_metas, gt_semantic_seg, train_cfg):
+        raise NotImplementedError("mmsa: the MI355X decode head implements the inference forward path only (no losses)")
+
     @torch.no_grad()
     def _pack(self, dev):
         sd = {k: v.detach().to(dev, torch.float32) for k, v in self.state_dict().items() if v.dtype.is_floating_point}
@@ -116,10 +123,15 @@ class SegformerHead(nn.Module):
 
     @torch.no_grad()
     def forward(self, inputs):
-        xs = [inputs[i] for i in self.in_index]          # BaseDecodeHead._transform_inputs('multiple_select')
-        x0 = xs[0]
+        x0 = inputs[self.in_index[0]]
         if not x0.is_cuda:
             raise RuntimeError("mmsa SegformerHead: inputs must live on the GPU (there is no CPU path)")
+        with torch.cuda.device(x0.device):    # launches go to the current stream of the tensors' device
+            return self._forward(inputs)
+
+    def _forward(self, inputs):
+        xs = [inputs[i] for i in self.in_index]          # BaseDecodeHead._transform_inputs('multiple_select')
+        x0 = xs[0]
         dev = x0.device
         if self._packed is None or self._packed["wc"].p.device != dev:
             self._packed = self._pack(dev)
@@ -133,8 +145,11 @@ class SegformerHead(nn.Module):
             x = x.contiguous()
             h, w = x.shape[2:]
             rows = B * h * w
-            xp = getattr(inputs[self.in_index[i]], "_mmsa_planes", None)   # written by the backbone's tail (emit_planes)
-            if not isinstance(xp, ops.Planes) or xp.n != rows or xp.k != ci or xp.p.device != dev:
+            # planes of this map written by the backbone's tail (emit_planes).  They live in the backbone's workspace and are
+            # overwritten by its NEXT forward: `live()` is false for the maps of an earlier call, which are re-derived from the
+            # NCHW tensor instead of silently reading the other image's planes.
+            xp = getattr(inputs[self.in_index[i]], "_mmsa_planes", None)
+            if not isinstance(xp, ops.Planes) or xp.n != rows or xp.k != ci or xp.p.device != dev or not xp.live():
                 xp = self._planes(f"x{i}", rows, ci, dev)
                 lib.call("mmsa_nchw_to_planes", x.data_ptr(), ci * h * w, xp.p.data_ptr(), 2 * xp.kpad, B, ci, h * w, ops._stream())
             br = pk["branch"][i]
@@ -153,6 +168,6 @@ class SegformerHead(nn.Module):
                  ops._stream())
         lt = self._buf("logit_tokens", (B * H * W, pk["ncp"]), dev=dev)
         ops.gemm(fp, pk["wc"], lt, bias=pk["bc"])
-        out = self._buf("logits", (B, self.num_classes, H, W), dev=dev)
+        out = torch.empty(B, self.num_classes, H, W, device=dev)   # a fresh tensor per call, like the reference's (no aliasing across calls)
         lib.call("mmsa_tokens_to_nchw", lt.data_ptr(), pk["ncp"], out.data_ptr(), B, H * W, self.num_classes, ops._stream())
         return out

@@ -9,6 +9,20 @@ from . import lib
 from . import ops
 
 
+def _on_device(fn):
+    """Run an entry point with its first tensor argument's device current (launches go to that device's current stream)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        t = next((a for a in args if isinstance(a, torch.Tensor)), None)
+        if t is None or not t.is_cuda:
+            return fn(*args, **kw)     # _check raises the "no CPU path" error
+        with torch.cuda.device(t.device):
+            return fn(*args, **kw)
+    return wrapped
+
+
 def _resize_into(logits, canvas, y0, x0, hc, wc, count=None, accumulate=False):
     b, c, hs, ws = logits.shape
     lib.call("mmsa_bilinear_accum_nchw", logits.data_ptr(), c * hs * ws, b, c, hs, ws, canvas.data_ptr(), canvas.shape[2], canvas.shape[3],
@@ -27,6 +41,7 @@ def _check(img):
         raise RuntimeError("mmsa.inference: img must be a float32 [B, C, H, W] GPU tensor (there is no CPU path)")
 
 
+@_on_device
 @torch.no_grad()
 def encode_decode(backbone, head, img):
     """ED:85-95: logits of the head resized (bilinear, align_corners=False) to the input size -> [B, classes, H, W]."""
@@ -55,6 +70,7 @@ def crop_boxes(h_img, w_img, crop_size, stride):
     return boxes
 
 
+@_on_device
 @torch.no_grad()
 def slide_inference(backbone, head, img, crop_size, stride, max_batch=8):
     """ED:191-234 without the optional rescale: averaged logits [B, classes, H, W] of overlapping windows.  All windows have
@@ -83,12 +99,14 @@ def slide_inference(backbone, head, img, crop_size, stride, max_batch=8):
     return preds
 
 
+@_on_device
 @torch.no_grad()
 def whole_inference(backbone, head, img):
     """ED: whole-image mode = encode_decode on the full input."""
     return encode_decode(backbone, head, img)
 
 
+@_on_device
 @torch.no_grad()
 def argmax_map(seg_logit):
     """ED:449,477: softmax is monotonic, the prediction is the per-pixel argmax over the class axis -> uint8 [B, H, W]."""

@@ -37,6 +37,8 @@ def collect_gemm_profile(prof):
 
 
 def _stream():
+    """The current stream of the current device.  Every entry point runs under `torch.cuda.device(tensor.device)` (the module
+    forwards set it) and `_chk` refuses tensors of another device, so a launch never goes to device A's stream with device B's memory."""
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -47,6 +49,9 @@ def _chk(t, dtype=torch.float32, name="tensor"):
         raise RuntimeError(f"mmsa: {name} must live on the GPU (got {t.device}); there is no CPU path")
     if t.dtype != dtype:
         raise RuntimeError(f"mmsa: {name} must be {dtype}, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"mmsa: {name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call under torch.cuda.device(tensor.device)")
     return t.data_ptr()
 
 
@@ -66,6 +71,15 @@ class Planes:
         self.n = p.shape[0] if n is None else n
         self.kpad = p.shape[1] // 2 if kpad is None else kpad
         self.k = self.kpad if k is None else k
+        self.gen = None   # (cell, value): set by a producer whose buffer is reused; live() tells whether it still holds this data
+
+    def stamp(self, cell):
+        """Mark these planes as valid while `cell[0]` keeps its current value (the producer bumps it when it reuses the buffer)."""
+        self.gen = (cell, cell[0])
+        return self
+
+    def live(self):
+        return self.gen is None or self.gen[0][0] == self.gen[1]
 
     def rows(self, lo, hi=None):
         """Row slice (same columns)."""

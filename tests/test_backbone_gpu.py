@@ -140,3 +140,90 @@ def test_results_do_not_depend_on_concurrent_work():
     for a, b in zip(last, ref):
         assert torch.equal(a, b)
     assert m.forward_pipelined(None) is None
+
+
+def test_graph_replayed_step_is_the_verified_step(golden_dir):
+    """bench.py's timed path: ViT-L batch 2, side streams on, emit_planes, backbone + head captured as ONE HIP graph and replayed.
+    The replayed graph must (a) reproduce the eager launch sequence bit for bit and (b) hit the reference's golden probes of
+    tests/golden/model_vitl1024.npz (golden input in image 0) -- what is timed is what is verified."""
+    import mmsa
+    from tests.configs import HEAD_CONFIGS
+    cfg, orc, m = _build("vitl1024")
+    del orc
+    hcfg = HEAD_CONFIGS["head_vitl"]
+    head = mmsa.build_head(dict(type="SegformerHead", **hcfg["kwargs"]))
+    head.load_state_dict(seeded_state_dict(head, seed=hcfg["seed"]))
+    m.multistream, m.emit_planes = True, True
+    x = make_input(cfg, batch=2, seed=1234).to(DEV)
+    x[0].copy_(make_input(cfg)[0].to(DEV))          # image 0 = the golden input
+    holder = {}
+
+    def step():
+        holder["fs"] = m(x)[0]
+        return head(holder["fs"])
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    eager_logits = step().clone()
+    eager_fs = [f.clone() for f in holder["fs"]]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_logits = step()
+    g_fs = holder["fs"]
+    g = np.load(os.path.join(golden_dir, "model_vitl1024.npz"))
+    for rep in range(3):
+        for t in [g_logits] + list(g_fs):
+            t.fill_(float("nan"))                  # a replay must rewrite every output
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_logits, eager_logits), f"replay {rep}: logits differ from the eager step"
+        for i, (a, b) in enumerate(zip(g_fs, eager_fs)):
+            assert torch.equal(a, b), f"replay {rep}: f{i+1} differs from the eager step"
+            pi = probe_index(a[0].numel(), 2048, seed=100 + i)
+            assert_close(a[0].flatten()[pi.to(DEV)].cpu(), torch.from_numpy(g[f"f{i+1}_probe"]), what=f"replayed graph f{i+1} probes vs golden")
+
+
+def test_two_instances_on_two_streams_bit_exact():
+    """Two encoder instances running concurrently on two HIP streams (different shapes: ViT-L 1024 batch 1 next to ViT-B 512
+    batch 2, with and without the decode head) return, bit for bit, what each returns alone -- 12 overlapped rounds."""
+    import mmsa
+    from tests.configs import HEAD_CONFIGS
+    cfg_a, orc, ma = _build("vitl1024")
+    cfg_b, orc, mb = _build("vitb512")
+    del orc
+    hcfg = HEAD_CONFIGS["head_vitl"]
+    heads = []
+    for D in (cfg_a["kwargs"]["embed_dim"], cfg_b["kwargs"]["embed_dim"]):
+        kw = dict(hcfg["kwargs"], in_channels=[D] * 4)
+        h = mmsa.build_head(dict(type="SegformerHead", **kw))
+        h.load_state_dict(seeded_state_dict(h, seed=hcfg["seed"]))
+        heads.append(h)
+    xa = make_input(cfg_a, batch=1, seed=3).to(DEV)
+    xb = make_input(cfg_b, batch=2, seed=4).to(DEV)
+    ma.emit_planes = True
+
+    def run(m, h, x):
+        fs = m(x)[0]
+        return [f.clone() for f in fs] + [h(fs).clone()]
+
+    ref_a, ref_b = run(ma, heads[0], xa), run(mb, heads[1], xb)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(12):
+        sa.wait_stream(torch.cuda.current_stream())
+        sb.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sa):
+            got_a = run(ma, heads[0], xa)
+        with torch.cuda.stream(sb):
+            got_b = run(mb, heads[1], xb)
+            if it % 2:
+                got_b = run(mb, heads[1], xb)
+        torch.cuda.synchronize()
+        for u, v in zip(got_a + got_b, ref_a + ref_b):
+            assert torch.equal(u, v), f"round {it}: a result changed under concurrent work"

@@ -89,3 +89,30 @@ def test_head_takes_planes_attached_by_the_backbone_tail():
     assert all(hasattr(f, "_mmsa_planes") for f in fs)
     assert torch.equal(h(fs), plain)
     assert torch.equal(h([f.clone() for f in fs]), plain)   # clones carry no planes: the transposing path again
+
+
+def test_head_through_the_reference_call_signature_and_no_aliasing():
+    """EncoderDecoder._decode_head_forward_test calls `decode_head.forward_test(x, img_metas, test_cfg)` (ED:129-133); results of
+    successive calls are separate tensors (the reference returns fresh tensors), and maps of an EARLIER backbone call are not
+    served from planes that the backbone has overwritten since."""
+    import mmsa
+    from tests.configs import CONFIGS, make_input
+    cfg, hcfg = CONFIGS["tiny256"], HEAD_CONFIGS["head_tiny"]
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m.load_state_dict(seeded_state_dict(m, seed=cfg["seed"]))
+    h = mmsa.build_head(dict(type="SegformerHead", **hcfg["kwargs"]))
+    h.load_state_dict(seeded_state_dict(h, seed=hcfg["seed"]))
+    xa, xb = make_input(cfg, batch=2, seed=1).to(DEV), make_input(cfg, batch=2, seed=2).to(DEV)
+    la = h.forward_test(m(xa)[0], img_metas=[{}], test_cfg=dict(mode="whole")).clone()
+    lb = h(m(xb)[0]).clone()
+    assert not torch.equal(la, lb)
+    m.emit_planes = True
+    fa = m(xa)[0]
+    fb = m(xb)[0]          # overwrites the planes buffers that fa's maps point to
+    out_a = h(fa)
+    out_b = h(fb)
+    assert out_a.data_ptr() != out_b.data_ptr()
+    assert torch.equal(out_a, la), "head(feats of an earlier call) must not read the later call's planes"
+    assert torch.equal(out_b, lb)
+    with pytest.raises(NotImplementedError):
+        h.forward_train(fa, [{}], None, None)

@@ -121,7 +121,11 @@ def _dp_worker(rank, world, port, q):
     local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 2, 3).contiguous() * 10 + rank
     allg = D.allgather_logits(local)
     slow = D.max_over_ranks(0.5 + rank, torch.device("cpu"))
-    q.put((rank, lo, hi, allg.clone(), slow))
+    # a global batch the world size does not divide: 7 images over 2 ranks = shards of 4 and 3, padded to equal collective sizes
+    lo7, hi7 = D.shard_range(7, rank, world)
+    loc7 = torch.arange(lo7, hi7, dtype=torch.float32).view(-1, 1).expand(-1, 5).contiguous()
+    all7 = D.allgather_logits(loc7, global_batch=7)
+    q.put((rank, lo, hi, allg.clone(), slow, (lo7, hi7), all7.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,7 +143,9 @@ def test_data_parallel_harness_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, g0, s0), (r1, lo1, hi1, g1, s1) = res
+    (r0, lo0, hi0, g0, s0, sh0, u0), (r1, lo1, hi1, g1, s1, sh1, u1) = res
+    assert (sh0, sh1) == ((0, 4), (4, 7))
+    assert torch.equal(u0, u1) and u0.shape == (7, 5) and u0[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
     assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 6)
     assert torch.equal(g0, g1) and g0.shape == (6, 2, 3)
     assert g0[:, 0, 0].tolist() == [0.0, 10.0, 20.0, 31.0, 41.0, 51.0]  # rank-major order
@@ -191,3 +197,38 @@ def test_convnext_checkpoint_duplication_matches_reference(golden_dir, tmp_path)
     cs = sum(sd[k].double().abs().sum().item() for k in gold["loaded"])
     assert abs(cs - float(gold["checksum"])) < 1e-9 * float(gold["checksum"])
     assert int(gold["n_twin"]) == len(twin)
+
+
+def test_no_lane_swizzled_packed_fp32():
+    """The library is built without hipcc's SLP vectoriser (build.py): no v_pk_{fma,mul,add}_f32 whose low lane selects the high
+    half of a register pair -- the instruction form behind round 1's wrong upper halves under concurrent streams."""
+    from tools.isa_audit import audit
+    n, npk, bad = audit(os.path.join(ROOT, "multimodal-sam-adapter_amd", "mmsa", "libmmsa_hip.so"))
+    assert n >= 10 and not bad, bad[:5]
+
+
+def test_head_has_the_decode_head_test_surface():
+    """BaseDecodeHead's inference surface used by the reference's EncoderDecoder (ED:129-133): forward_test(inputs, img_metas,
+    test_cfg) exists and reaches forward (which refuses CPU tensors loudly); forward_train is refused, not missing."""
+    import mmsa
+    from tests.configs import HEAD_CONFIGS, make_head_inputs
+    cfg = HEAD_CONFIGS["head_tiny"]
+    head = mmsa.build_head(dict(type="SegformerHead", **cfg["kwargs"]))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        head.forward_test(make_head_inputs(cfg), [dict()], dict(mode="whole"))
+    with pytest.raises(NotImplementedError):
+        head.forward_train(make_head_inputs(cfg), [dict()], None, None)
+    assert callable(mmsa.register_head)
+
+
+def test_bench_parent_starts_no_ranks_without_gpus():
+    """`python bench.py --gpus 2` with no WORLD_SIZE is the self-launching parent: it must decide from the device COUNT alone
+    (no GPU initialisation) and fail loudly when there are fewer GPUs than ranks (this container has none)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("GPUs present: the parent would really launch")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "--gpus 2 asked for" in r.stderr

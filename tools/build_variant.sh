@@ -7,7 +7,7 @@ P=$ROOT/multimodal-sam-adapter_amd
 OUT=$1; SRC=$2; shift 2
 mkdir -p $(dirname $ROOT/$OUT)
 B=$(basename $SRC .hip)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value "$@" -c $P/csrc/$SRC -o /tmp/variant_${B}_$$.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -fno-slp-vectorize "$@" -c $P/csrc/$SRC -o /tmp/variant_${B}_$$.o
 OBJS=$(ls $P/build/*.o | grep -v "/$B.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/$OUT $OBJS /tmp/variant_${B}_$$.o
 echo built $OUT
