@@ -45,14 +45,30 @@ int mmsa_event_destroy(void* ev);
 /* activation codes of the fused epilogues */
 enum { MMSA_ACT_NONE = 0, MMSA_ACT_GELU = 1, MMSA_ACT_RELU = 2, MMSA_ACT_RELU6 = 3, MMSA_ACT_HSWISH = 4, MMSA_ACT_SIGMOID = 5 };
 
-/* --- reference native op ------------------------------------------------------------------------------------
- * ms_deform_attn_forward (vision.cpp:14).  value [N,S,M,D], spatial_shapes int64 [L,2] (H,W), level_start_index
- * int64 [L], sampling_loc [N,Lq,M,L,P,2] (x,y in [0,1]), attn_weight [N,Lq,M,L,P]; out [N,Lq,M*D] (overwritten).
+/* scalar type codes of the dtype-dispatched entry points (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF) */
+enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
+
+/* --- reference native ops -----------------------------------------------------------------------------------
+ * ms_deform_attn_forward (vision.cpp:14 -> ms_deform_attn.h:20-39 -> cuda/ms_deform_attn_cuda.cu:20-80).
+ * value [N,S,M,D], spatial_shapes int64 [L,2] (H,W), level_start_index int64 [L], sampling_loc [N,Lq,M,L,P,2] (x,y in
+ * [0,1]), attn_weight [N,Lq,M,L,P]; out [N,Lq,M*D] (overwritten).  `dtype` = the scalar type of value / sampling_loc /
+ * attn_weight / out (ms_deform_attn_cuda.cu:64 dispatches float, double and half; f16 is computed in fp32 here).
  * Error behaviour mirrors ms_deform_attn_cuda.cu:52: batch % min(batch, im2col_step) must be 0. */
-int mmsa_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                const float* sampling_loc, const float* attn_weight, float* out, int batch,
+int mmsa_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const void* sampling_loc, const void* attn_weight, void* out, int batch,
                                 int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                                int num_point, int im2col_step, mmsa_stream_t stream);
+                                int num_point, int im2col_step, int dtype, mmsa_stream_t stream);
+
+/* ms_deform_attn_backward (vision.cpp:15 -> ms_deform_attn.h:42-61 -> cuda/ms_deform_attn_cuda.cu:83-151, kernels
+ * ms_deform_im2col_cuda.cuh:301-920).  grad_output [N,Lq,M*D]; grad_value / grad_sampling_loc / grad_attn_weight have the
+ * shapes of value / sampling_loc / attn_weight and are caller-allocated; the call zero-fills and then fully writes them on
+ * `stream` (the reference returns freshly allocated zeros-initialised tensors, :121-123).  grad_value is a scatter of
+ * floating-point atomic adds like the reference's, so its last bits depend on the arrival order. */
+int mmsa_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                                 void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int batch,
+                                 int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                 int num_point, int im2col_step, int dtype, mmsa_stream_t stream);
 
 /* Fused hot-path form of MSDeformAttn.forward's middle part (ops/modules/ms_deform_attn.py:105-127): takes the raw
  * output `raw` [N*Lq, ldraw] of the concatenated sampling_offsets|attention_weights projection

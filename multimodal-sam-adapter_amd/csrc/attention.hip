@@ -44,11 +44,11 @@ struct AttnArgs {
 // REL (with PL, FB, HD = 64): the rel-pos terms are computed in the kernel's prologue (MFMA, like wattn.hip) instead of being
 // read from the prepass output
 template <int HD, bool PL, bool FB, bool REL = false>
-__global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(AttnArgs a) {
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
   constexpr int DT = HD / 16;            // output d tiles
-  constexpr int VSTR = (HD == 64) ? 160 : 96;  // V row stride in bytes (bank-conflict-free tr reads)
+  constexpr int VSTR = 2 * HD + 32;      // V row stride in bytes: 96 / 160 / 224 -- 8 consecutive rows tile the 64 banks exactly (conflict-free tr reads)
   constexpr int KPL = NCH * 64 * 16;     // bytes per K plane
   constexpr int VPL = 64 * VSTR;         // bytes per V plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, FB ? 2 : 1) void attn_kernel(AttnArgs a) {
 static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head_dim, int window_size, float scale,
                             bool planes, hipStream_t stream) {
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0 && window_size >= 0, "attention: bad shape");
-  MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "attention: head_dim %d not supported (32 or 64)", head_dim);
+  MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32 || head_dim == 96, "attention: head_dim %d not supported (32, 64 or 96; other widths are zero-padded per head by the caller, e.g. ViT-H's 80 -> 96)", head_dim);
   const int D = heads * head_dim;
   MMSA_CHECK_ARG(a.ldq >= (planes ? 6L : 3L) * D && (a.ldq & 7) == 0 && a.ldo >= (planes ? 2L : 1L) * D && (a.ldo & 3) == 0,
                  "attention: bad leading dimensions");
@@ -498,7 +498,7 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
       return MMSA_ERR_ARG;
     }
   }
-  const int VSTR = head_dim == 64 ? 160 : 96;
+  const int VSTR = 2 * head_dim + 32;
   const bool fb = window_size == 0 && W == 64 && (H % 4) == 0;   // one key block = one image row: bias terms hoisted (see kernel)
   const size_t smem = 2 * (head_dim / 8) * 64 * 16 + 2 * 64 * VSTR + (size_t)128 * (a.KHs + (fb ? 0 : a.KWs)) * sizeof(float);
   MMSA_CHECK_ARG(smem <= 160 * 1024, "attention: bias tables do not fit LDS (KH=%d KW=%d)", a.KH, a.KW);
@@ -514,6 +514,9 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
       hipLaunchKernelGGL((attn_kernel<64, true, true, true>), grid, dim3(256), smem, stream, a);
     } else if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
     else { if (fb) ATTN_LAUNCH(64, false, true); else ATTN_LAUNCH(64, false, false); }
+  } else if (head_dim == 96) {
+    if (planes) { if (fb) ATTN_LAUNCH(96, true, true); else ATTN_LAUNCH(96, true, false); }
+    else { if (fb) ATTN_LAUNCH(96, false, true); else ATTN_LAUNCH(96, false, false); }
   } else {
     if (planes) { if (fb) ATTN_LAUNCH(32, true, true); else ATTN_LAUNCH(32, true, false); }
     else { if (fb) ATTN_LAUNCH(32, false, true); else ATTN_LAUNCH(32, false, false); }
@@ -632,7 +635,7 @@ static int relpos_launch(const float* qkv, const unsigned short* qp, long ldq, c
                          const float* Rw, float* rp, int B, int H, int W, int heads, int head_dim, int window_size,
                          hipStream_t stream) {
   MMSA_CHECK_ARG((qkv || qp) && Rh && Rw && rp, "relpos_bias: null pointer");
-  MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32, "relpos_bias: head_dim %d not supported", head_dim);
+  MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32 || head_dim == 96, "relpos_bias: head_dim %d not supported", head_dim);
   MMSA_CHECK_ARG((ldq & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)Rh) | ((uintptr_t)Rw)) & 15) == 0 &&
                  (((uintptr_t)qp) & 7) == 0, "relpos_bias: alignment");
   const int KH = window_size ? window_size : H, KW = window_size ? window_size : W;
@@ -642,6 +645,7 @@ static int relpos_launch(const float* qkv, const unsigned short* qp, long ldq, c
   dim3 grid(H + W, heads, B);
 #define RP_LAUNCH(HD_, PL_) hipLaunchKernelGGL((relpos_kernel<HD_, PL_>), grid, dim3(256), smem, stream, qkv, qp, ldq, Rh, Rw, rp, H, W, heads, window_size, KH, KW)
   if (head_dim == 64) { if (qp) RP_LAUNCH(64, true); else RP_LAUNCH(64, false); }
+  else if (head_dim == 96) { if (qp) RP_LAUNCH(96, true); else RP_LAUNCH(96, false); }
   else { if (qp) RP_LAUNCH(32, true); else RP_LAUNCH(32, false); }
 #undef RP_LAUNCH
   MMSA_CHECK_LAUNCH("relpos_bias");

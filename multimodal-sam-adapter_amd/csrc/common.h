@@ -9,6 +9,9 @@
 #define MMSA_ERR_ARG (-1)
 #define MMSA_ERR_LAUNCH (-2)
 
+// scalar type codes of the dtype-dispatched entry points (include/mmsa.h)
+enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
+
 extern "C" const char* mmsa_last_error(void);
 void mmsa_set_error(const char* fmt, ...);
 

@@ -12,6 +12,7 @@
 // D*4-byte segment (128 B at D=32) -> fully coalesced gathers that stay L2/MALL resident
 // (value maps are <= 44 MB fp32).  Sampling locations / weights are read once per pair (broadcast loads).
 #include "common.h"
+#include <hip/hip_fp16.h>
 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void msda_kernel(
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void msda_kernel(
   // 32-bit index arithmetic (N*Lq*M*d4 < 2^32, checked by the launcher): the four 64-bit div/mod of the first version
   // were a quarter of the kernel's instructions
   const unsigned pair = (blockIdx.x * blockDim.x + threadIdx.x) / (unsigned)d4;
-  const int c = ((threadIdx.x) % d4) * 4;       // blockDim.x is a multiple of d4
+  const int c = ((threadIdx.x) % d4) * 4;       // blockDim.x is a multiple of d4 (msda_block)
   const unsigned npairs = (unsigned)N * (unsigned)Lq * (unsigned)M;
   if (pair >= npairs) return;
   const unsigned bq = pair / (unsigned)M;
@@ -100,12 +101,18 @@ __global__ __launch_bounds__(256) void msda_kernel(
 }
 
 
-// Generic scalar path (any D): one lane per output element.  Used for head widths the vector path does
-// not cover (e.g. the reference's own known-answer fixture OPS/test.py:16-33 has D = 2).
+// Generic path (any D, any dtype): one lane per output element, arithmetic in AT (float for f32 / f16 storage, double for f64).
+// Used for head widths the vector path does not cover (e.g. the reference's own known-answer fixture OPS/test.py:16-33 has
+// D = 2) and for the f16 / f64 instantiations of the reference's dispatch (ms_deform_attn_cuda.cu:64).
+template <typename T> struct msda_acc { typedef float type; };
+template <> struct msda_acc<double> { typedef double type; };
+
+template <typename T>
 __global__ __launch_bounds__(256) void msda_scalar_kernel(
-    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-    const float* __restrict__ loc, const float* __restrict__ aw, float* __restrict__ out,
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const T* __restrict__ loc, const T* __restrict__ aw, T* __restrict__ out,
     int N, int S, int M, int D, int L, int Lq, int P) {
+  typedef typename msda_acc<T>::type AT;
   const long total = (long)N * Lq * M * D;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int c = (int)(idx % D);
@@ -114,29 +121,129 @@ __global__ __launch_bounds__(256) void msda_scalar_kernel(
     const int b = (int)(pair / M / Lq);
     const long lw = pair * L * P;
     const long vstride = (long)M * D;
-    const float* vb = value + (long)b * S * vstride + (long)m * D + c;
-    float acc = 0.f;
+    const T* vb = value + (long)b * S * vstride + (long)m * D + c;
+    AT acc = 0;
     for (int l = 0; l < L; ++l) {
       const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-      const float* vl = vb + (long)lsi[l] * vstride;
+      const T* vl = vb + (long)lsi[l] * vstride;
       for (int p = 0; p < P; ++p) {
-        const float lx = loc[(lw + l * P + p) * 2], ly = loc[(lw + l * P + p) * 2 + 1];
-        const float wgt = aw[lw + l * P + p];
-        const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-          const float lh = h_im - h_low, lwf = w_im - w_low, hh = 1.f - lh, hw = 1.f - lwf;
+        const AT lx = (AT)loc[(lw + l * P + p) * 2], ly = (AT)loc[(lw + l * P + p) * 2 + 1];
+        const AT wgt = (AT)aw[lw + l * P + p];
+        const AT h_im = ly * H - (AT)0.5, w_im = lx * W - (AT)0.5;
+        if (h_im > -1 && w_im > -1 && h_im < (AT)H && w_im < (AT)W) {
+          const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
+          const AT lh = h_im - h_low, lwf = w_im - w_low, hh = 1 - lh, hw = 1 - lwf;
           const int h_high = h_low + 1, w_high = w_low + 1;
-          float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-          if (h_low >= 0 && w_low >= 0) v1 = vl[((long)h_low * W + w_low) * vstride];
-          if (h_low >= 0 && w_high <= W - 1) v2 = vl[((long)h_low * W + w_high) * vstride];
-          if (h_high <= H - 1 && w_low >= 0) v3 = vl[((long)h_high * W + w_low) * vstride];
-          if (h_high <= H - 1 && w_high <= W - 1) v4 = vl[((long)h_high * W + w_high) * vstride];
+          AT v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+          if (h_low >= 0 && w_low >= 0) v1 = (AT)vl[((long)h_low * W + w_low) * vstride];
+          if (h_low >= 0 && w_high <= W - 1) v2 = (AT)vl[((long)h_low * W + w_high) * vstride];
+          if (h_high <= H - 1 && w_low >= 0) v3 = (AT)vl[((long)h_high * W + w_low) * vstride];
+          if (h_high <= H - 1 && w_high <= W - 1) v4 = (AT)vl[((long)h_high * W + w_high) * vstride];
           acc += (hh * hw * v1 + hh * lwf * v2 + lh * hw * v3 + lh * lwf * v4) * wgt;
         }
       }
     }
-    out[idx] = acc;
+    out[idx] = (T)acc;
+  }
+}
+
+// ---- backward (ms_deform_attn_backward, vision.cpp:15 -> ms_deform_attn_cuda.cu:83-151 -> ms_deform_im2col_cuda.cuh:301-920 kernels
+// with the per-sample arithmetic of :86-160): for every (b, q, m, c) and sample (l, p), with g = grad_output[b,q,m,c],
+//   grad_value[corner]      += w_corner * g * attn_weight                      (scatter: atomics, like the reference)
+//   grad_attn_weight[b,q,m,l,p] = sum_c g * bilinear(value)
+//   grad_sampling_loc[..., x] = sum_c W_l * (d bilinear / d w) * g * attn_weight,  [..., y] likewise with H_l
+// One lane per (b, q, m, c): the lanes of a (q, m) pair hold the channel partials of the two per-sample gradients; when D is a
+// power of two <= 64 they are summed with xor-shuffles inside the lane group and written once (no atomics, deterministic, where
+// the reference block-reduces through shared memory); any other D adds the partials with float atomics into zeroed outputs.
+__device__ __forceinline__ void msda_atomic_add(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void msda_atomic_add(double* p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void msda_atomic_add(__half* p, float v) {
+  // 16-bit float atomics are packed pairs on gfx950 (global_atomic_pk_add_f16): add (v, 0) or (0, v) to the aligned pair
+  const uintptr_t a = (uintptr_t)p;
+  __half2* p2 = reinterpret_cast<__half2*>(a & ~(uintptr_t)3);
+  const __half hv = __float2half(v), z = __float2half(0.f);
+  unsafeAtomicAdd(p2, (a & 2) ? __halves2half2(z, hv) : __halves2half2(hv, z));
+}
+
+template <typename T, bool SHFL>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const T* __restrict__ loc, const T* __restrict__ aw, const T* __restrict__ gout,
+    T* __restrict__ gvalue, T* __restrict__ gloc, T* __restrict__ gaw,
+    int N, int S, int M, int D, int L, int Lq, int P) {
+  typedef typename msda_acc<T>::type AT;
+  const long total = (long)N * Lq * M * D;
+  const long idx0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = idx0 < total;            // inactive lanes still take part in the shuffles with zero partials
+  const long idx = active ? idx0 : total - 1;
+  const int c = (int)(idx % D);
+  const long pair = idx / D;
+  const int m = (int)(pair % M);
+  const int b = (int)(pair / M / Lq);
+  const long lw = pair * L * P;
+  const long vstride = (long)M * D;
+  const long voff = (long)b * S * vstride + (long)m * D + c;
+  const AT g = active ? (AT)gout[idx] : (AT)0;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const long lbase = voff + (long)lsi[l] * vstride;
+    for (int p = 0; p < P; ++p) {
+      const long si = lw + l * P + p;
+      const AT lx = (AT)loc[si * 2], ly = (AT)loc[si * 2 + 1];
+      const AT wgt = (AT)aw[si];
+      const AT h_im = ly * H - (AT)0.5, w_im = lx * W - (AT)0.5;
+      AT g_w = 0, g_x = 0, g_y = 0;
+      if (h_im > -1 && w_im > -1 && h_im < (AT)H && w_im < (AT)W) {
+        const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
+        const AT lh = h_im - h_low, lwf = w_im - w_low, hh = 1 - lh, hw = 1 - lwf;
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const AT tg = g * wgt;
+        AT val = 0, dh = 0, dw = 0;
+        if (h_low >= 0 && w_low >= 0) {
+          const long o = lbase + ((long)h_low * W + w_low) * vstride;
+          const AT v = (AT)value[o];
+          val += hh * hw * v; dh -= hw * v; dw -= hh * v;
+          if (active) msda_atomic_add(gvalue + o, hh * hw * tg);
+        }
+        if (h_low >= 0 && w_high <= W - 1) {
+          const long o = lbase + ((long)h_low * W + w_high) * vstride;
+          const AT v = (AT)value[o];
+          val += hh * lwf * v; dh -= lwf * v; dw += hh * v;
+          if (active) msda_atomic_add(gvalue + o, hh * lwf * tg);
+        }
+        if (h_high <= H - 1 && w_low >= 0) {
+          const long o = lbase + ((long)h_high * W + w_low) * vstride;
+          const AT v = (AT)value[o];
+          val += lh * hw * v; dh += hw * v; dw -= lh * v;
+          if (active) msda_atomic_add(gvalue + o, lh * hw * tg);
+        }
+        if (h_high <= H - 1 && w_high <= W - 1) {
+          const long o = lbase + ((long)h_high * W + w_high) * vstride;
+          const AT v = (AT)value[o];
+          val += lh * lwf * v; dh += lwf * v; dw += lh * v;
+          if (active) msda_atomic_add(gvalue + o, lh * lwf * tg);
+        }
+        g_w = g * val;
+        g_x = (AT)W * dw * tg;
+        g_y = (AT)H * dh * tg;
+      }
+      if constexpr (SHFL) {
+        for (int o = D >> 1; o > 0; o >>= 1) {
+          g_w += __shfl_xor(g_w, o, 64);
+          g_x += __shfl_xor(g_x, o, 64);
+          g_y += __shfl_xor(g_y, o, 64);
+        }
+        if (active && c == 0) {
+          gaw[si] = (T)g_w;
+          gloc[si * 2] = (T)g_x;
+          gloc[si * 2 + 1] = (T)g_y;
+        }
+      } else if (active) {
+        msda_atomic_add(gaw + si, g_w);
+        msda_atomic_add(gloc + si * 2, g_x);
+        msda_atomic_add(gloc + si * 2 + 1, g_y);
+      }
+    }
   }
 }
 
@@ -144,39 +251,91 @@ static int msda_check(int N, int S, int M, int D, int L, int Lq, int P, const ch
   MMSA_CHECK_ARG(N > 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq > 0 && P > 0, "%s: bad shape", name);
   return MMSA_OK;
 }
+// workgroup size of the vector kernel: the largest multiple of D/4 lanes that fits 256 (D = 40 -> 250 threads)
+static int msda_block(int channels) { const int d4 = channels >> 2; return (256 / d4) * d4; }
+static size_t msda_elt(int dtype) { return dtype == MMSA_DT_F16 ? 2 : dtype == MMSA_DT_F64 ? 8 : 4; }
 
 // Drop-in for ms_deform_attn_forward (vision.cpp:14).  All pointers are DEVICE pointers, tensors
 // contiguous with the reference's layouts; `out` is [batch, num_query, num_heads*channels] and is fully
 // overwritten (the reference zero-fills then writes, ms_deform_attn_cuda.cu:54).  `im2col_step` is
 // accepted and validated like the reference (batch %% min(batch, im2col_step) == 0, :52) but the launch
-// covers the whole batch at once.
-extern "C" int mmsa_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes,
-                                           const int64_t* level_start_index, const float* sampling_loc,
-                                           const float* attn_weight, float* out, int batch, int spatial_size,
+// covers the whole batch at once.  dtype: the scalar type of value / sampling_loc / attn_weight / out, the reference's
+// AT_DISPATCH_FLOATING_TYPES_AND_HALF (ms_deform_attn_cuda.cu:64); f16 computes in fp32 and rounds the result once.
+extern "C" int mmsa_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
+                                           const int64_t* level_start_index, const void* sampling_loc,
+                                           const void* attn_weight, void* out, int batch, int spatial_size,
                                            int num_heads, int channels, int num_levels, int num_query,
-                                           int num_point, int im2col_step, hipStream_t stream) {
+                                           int num_point, int im2col_step, int dtype, hipStream_t stream) {
   MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out, "ms_deform_attn_forward: null pointer");
+  MMSA_CHECK_ARG(dtype == MMSA_DT_F32 || dtype == MMSA_DT_F16 || dtype == MMSA_DT_F64, "ms_deform_attn_forward: dtype %d not supported (0 f32, 1 f16, 2 f64)", dtype);
   int rc = msda_check(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, "ms_deform_attn_forward");
   if (rc) return rc;
   const int step = batch < im2col_step ? batch : im2col_step;
   MMSA_CHECK_ARG(step > 0 && batch % step == 0, "batch(%d) must divide im2col_step(%d)", batch, step);
-  const bool vec = (channels & 3) == 0 && channels <= 1024 && 256 % (channels >> 2) == 0 &&
+  const bool vec = dtype == MMSA_DT_F32 && (channels & 3) == 0 && channels <= 1024 &&
                    ((((uintptr_t)value) | ((uintptr_t)out)) & 15) == 0;
   if (!vec) {
     const long total = (long)batch * num_query * num_heads * channels;
     int blocks = cdiv(total, 256);
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(msda_scalar_kernel, dim3(blocks), dim3(256), 0, stream, value, spatial_shapes, level_start_index,
-                       sampling_loc, attn_weight, out, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
+#define MSDA_SCALAR(T_)                                                                                                   \
+    hipLaunchKernelGGL(msda_scalar_kernel<T_>, dim3(blocks), dim3(256), 0, stream, (const T_*)value, spatial_shapes,      \
+                       level_start_index, (const T_*)sampling_loc, (const T_*)attn_weight, (T_*)out, batch, spatial_size,  \
+                       num_heads, channels, num_levels, num_query, num_point)
+    if (dtype == MMSA_DT_F16) MSDA_SCALAR(__half);
+    else if (dtype == MMSA_DT_F64) MSDA_SCALAR(double);
+    else MSDA_SCALAR(float);
+#undef MSDA_SCALAR
     MMSA_CHECK_LAUNCH("ms_deform_attn_forward(scalar)");
     return MMSA_OK;
   }
   const long threads = (long)batch * num_query * num_heads * (channels >> 2);
   MMSA_CHECK_ARG(threads < (1L << 31), "ms_deform_attn_forward: problem too large for the 32-bit index arithmetic");
-  hipLaunchKernelGGL(msda_kernel<false>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, value, spatial_shapes,
-                     level_start_index, sampling_loc, attn_weight, nullptr, 0L, nullptr, out,
+  const int bs = msda_block(channels);
+  hipLaunchKernelGGL(msda_kernel<false>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, (const float*)value, spatial_shapes,
+                     level_start_index, (const float*)sampling_loc, (const float*)attn_weight, nullptr, 0L, nullptr, (float*)out,
                      (long)num_heads * channels, nullptr, 0L, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   MMSA_CHECK_LAUNCH("ms_deform_attn_forward");
+  return MMSA_OK;
+}
+
+// Drop-in for ms_deform_attn_backward (vision.cpp:15 -> ms_deform_attn_cuda.cu:83-151).  grad_output [N,Lq,M*D]; the three
+// gradients have the shapes of value / sampling_loc / attn_weight and are fully (over)written: the library zero-fills
+// grad_value (and, on the atomics path, the other two) on `stream` first, where the reference allocates zeros (:121-123).
+extern "C" int mmsa_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                            const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                                            void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int batch,
+                                            int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                            int num_point, int im2col_step, int dtype, hipStream_t stream) {
+  MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && grad_output && grad_value &&
+                 grad_sampling_loc && grad_attn_weight, "ms_deform_attn_backward: null pointer");
+  MMSA_CHECK_ARG(dtype == MMSA_DT_F32 || dtype == MMSA_DT_F16 || dtype == MMSA_DT_F64, "ms_deform_attn_backward: dtype %d not supported (0 f32, 1 f16, 2 f64)", dtype);
+  int rc = msda_check(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, "ms_deform_attn_backward");
+  if (rc) return rc;
+  const int step = batch < im2col_step ? batch : im2col_step;
+  MMSA_CHECK_ARG(step > 0 && batch % step == 0, "batch(%d) must divide im2col_step(%d)", batch, step);
+  MMSA_CHECK_ARG(dtype != MMSA_DT_F16 || (((uintptr_t)grad_value) & 3) == 0, "ms_deform_attn_backward: f16 grad_value must be 4-byte aligned");
+  const size_t es = msda_elt(dtype);
+  const long nsamp = (long)batch * num_query * num_heads * num_levels * num_point;
+  const bool shfl = channels <= 64 && (channels & (channels - 1)) == 0;
+  if (hipMemsetAsync(grad_value, 0, (size_t)batch * spatial_size * num_heads * channels * es, stream) != hipSuccess ||
+      (!shfl && (hipMemsetAsync(grad_sampling_loc, 0, (size_t)nsamp * 2 * es, stream) != hipSuccess ||
+                 hipMemsetAsync(grad_attn_weight, 0, (size_t)nsamp * es, stream) != hipSuccess))) {
+    mmsa_set_error("ms_deform_attn_backward: hipMemsetAsync failed");
+    return MMSA_ERR_LAUNCH;
+  }
+  const long total = (long)batch * num_query * num_heads * channels;
+  MMSA_CHECK_ARG(cdiv(total, 256) < (1L << 31) - 1, "ms_deform_attn_backward: problem too large");
+#define MSDA_BWD(T_, S_)                                                                                                  \
+  hipLaunchKernelGGL((msda_bwd_kernel<T_, S_>), dim3(cdiv(total, 256)), dim3(256), 0, stream, (const T_*)value, spatial_shapes, \
+                     level_start_index, (const T_*)sampling_loc, (const T_*)attn_weight, (const T_*)grad_output, (T_*)grad_value, \
+                     (T_*)grad_sampling_loc, (T_*)grad_attn_weight, batch, spatial_size, num_heads, channels, num_levels,  \
+                     num_query, num_point)
+  if (dtype == MMSA_DT_F16) { if (shfl) MSDA_BWD(__half, true); else MSDA_BWD(__half, false); }
+  else if (dtype == MMSA_DT_F64) { if (shfl) MSDA_BWD(double, true); else MSDA_BWD(double, false); }
+  else { if (shfl) MSDA_BWD(float, true); else MSDA_BWD(float, false); }
+#undef MSDA_BWD
+  MMSA_CHECK_LAUNCH("ms_deform_attn_backward");
   return MMSA_OK;
 }
 
@@ -196,11 +355,12 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
   if (rc) return rc;
   MMSA_CHECK_ARG(ldraw >= (long)num_heads * num_levels * num_point * 3, "msda_fused: ldraw too small");
   MMSA_CHECK_ARG(!out || (ldo >= (long)num_heads * channels && (ldo & 3) == 0), "msda_fused: bad ldo");
-  MMSA_CHECK_ARG((channels & 3) == 0 && channels <= 1024 && 256 % (channels >> 2) == 0, "msda_fused: channels per head D=%d must be a multiple of 4 with 256 %% (D/4) == 0", channels);
+  MMSA_CHECK_ARG((channels & 3) == 0 && channels <= 1024, "msda_fused: channels per head D=%d must be a multiple of 4 (<= 1024)", channels);
   MMSA_CHECK_ARG(((((uintptr_t)value) | ((uintptr_t)out)) & 15) == 0, "msda_fused: value/out must be 16-byte aligned");
   const long threads = (long)batch * num_query * num_heads * (channels >> 2);
   MMSA_CHECK_ARG(threads < (1L << 31), "msda_fused: problem too large for the 32-bit index arithmetic");
-  hipLaunchKernelGGL(msda_kernel<true>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, value, spatial_shapes,
+  const int bs = msda_block(channels);
+  hipLaunchKernelGGL(msda_kernel<true>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, value, spatial_shapes,
                      level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, batch, spatial_size,
                      num_heads, channels, num_levels, num_query, num_point);
   MMSA_CHECK_LAUNCH("msda_fused");

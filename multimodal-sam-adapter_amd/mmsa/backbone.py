@@ -114,8 +114,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             if c % 32 != 0:
                 raise ValueError("ConvNeXt stage widths must be multiples of 32 (groups=32 convs, GroupNorm(32))")
         hd = D // num_heads
-        if hd not in (32, 64):
-            raise NotImplementedError(f"mmsa: attention head_dim {hd} not supported by the HIP kernel (32 or 64)")
+        if D % num_heads or ops.pad32(hd) not in (32, 64, 96):
+            raise NotImplementedError(f"mmsa: attention head_dim {hd} not supported by the HIP kernels (up to 96; widths that are "
+                                      "not multiples of 32 run zero-padded per head, e.g. ViT-H's 80 as 96)")
         self.img_size = vit["img_size"]
         self.embed_dim = D
         self.interaction_indexes = self.cfg["interaction_indexes"]
@@ -126,27 +127,26 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         self._ws = None
         self.register_load_state_dict_post_hook(lambda m, _: m.invalidate())
         self.init_weights(pretrained)
-        if isinstance(checkpoint, str) and os.path.isfile(checkpoint):   # URLs (the shipped configs) cannot be fetched here: skipped
-            self.load_convnext_checkpoint(checkpoint)
+        # TwinConvNeXt.init_weights (TC:382-443) loads `checkpoint` -- a URL in every shipped config.  There is no network here:
+        # a local mirror can be named in MMSA_CONVNEXT_CKPT; a checkpoint that cannot be read is reported, never skipped silently.
+        if isinstance(checkpoint, str) and checkpoint not in ("", "check"):
+            local = checkpoint if os.path.isfile(checkpoint) else os.environ.get("MMSA_CONVNEXT_CKPT", "")
+            if os.path.isfile(local):
+                self.load_convnext_checkpoint(local)
+            else:
+                import warnings
+                warnings.warn(f"mmsa: ConvNeXt checkpoint '{checkpoint}' is not a local file and MMSA_CONVNEXT_CKPT names no mirror: "
+                              "TwinConvNeXt keeps its random initialisation (the reference downloads and loads it, TC:382-443)")
         self.eval()
 
     # ------------------------------------------------------------------ plugin surface
     def init_weights(self, pretrained=None):
-        """IE:305-315: load a (SAM) checkpoint non-strictly when a path is given (the container conventions of
-        mmcv_custom/checkpoint.py:343-360: 'state_dict' / 'model' / 'module' wrappers, 'module.' and 'encoder.' prefixes)."""
+        """IE:305-315: a path loads a (SAM) checkpoint with the reference's non-strict loader semantics
+        (mmcv_custom/checkpoint.py:319-514, restated in mmsa/checkpoint.py: wrappers, 'module.' / 'encoder.' prefixes, size-mismatched
+        keys skipped with a warning)."""
         if isinstance(pretrained, str):
-            ck = torch.load(pretrained, map_location="cpu")
-            sd = ck
-            if isinstance(ck, dict):
-                for key in ("state_dict", "model", "module"):
-                    if key in ck and isinstance(ck[key], dict):
-                        sd = ck[key]
-                        break
-            if list(sd.keys())[0].startswith("module."):
-                sd = {k[7:]: v for k, v in sd.items()}
-            if sorted(sd.keys())[0].startswith("encoder"):
-                sd = {k.replace("encoder.", ""): v for k, v in sd.items() if k.startswith("encoder.")}
-            self.load_state_dict(sd, strict=False)
+            from .checkpoint import load_pretrained
+            self._pretrained_report = load_pretrained(self, pretrained)
 
     def load_convnext_checkpoint(self, path):
         """TwinConvNeXt.init_weights (TC:403-443): a single-stream ConvNeXt checkpoint is loaded into BOTH streams -- every key
@@ -198,18 +198,44 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         pk["pe_w"] = planes(sd["patch_embed.proj.weight"].reshape(D, -1))  # K order (c,kh,kw)
         pk["pe_b"] = sd["patch_embed.proj.bias"].contiguous()
         pk["blocks"] = []
+        # Head widths that are not a multiple of the 32-wide MFMA k-block (ViT-H: 1280 / 16 = 80) run ZERO-PADDED per head
+        # (80 -> 96): the qkv projection gets zero rows (and zero bias) for the pad channels, the output projection zero
+        # columns, the rel-pos tables zero columns.  q.k, the rel-pos terms and the proj output are unchanged -- every added
+        # term is an exact zero -- and the softmax scale stays head_dim^-0.5 of the true width.
+        heads_ = cfg["num_heads"]
+        hd_true = D // heads_
+        hd_ = ops.pad32(hd_true)
+        Da = heads_ * hd_            # attention width (= D unless padded)
+        self._hd_true, self._hd_pad = hd_true, hd_
+
+        def pad_head_rows(w, groups):   # [groups*heads*hd_true, ...] -> [groups*heads*hd_, ...]
+            if hd_ == hd_true:
+                return w.contiguous()
+            v = w.reshape(groups, heads_, hd_true, *w.shape[1:])
+            out = v.new_zeros(groups, heads_, hd_, *w.shape[1:])
+            out[:, :, :hd_true] = v
+            return out.reshape(groups * heads_ * hd_, *w.shape[1:]).contiguous()
+
+        def pad_cols(t):                # [L, hd_true] -> [L, hd_]
+            if hd_ == hd_true:
+                return t
+            out = t.new_zeros(t.shape[0], hd_)
+            out[:, :hd_true] = t
+            return out
+
         for i in range(cfg["depth"]):
             b = f"blocks.{i}."
+            qkv_w, qkv_bias = pad_head_rows(sd[b + "attn.qkv.weight"], 3), pad_head_rows(sd[b + "attn.qkv.bias"], 3)
+            proj_w = pad_head_rows(sd[b + "attn.proj.weight"].t(), 1).t().contiguous()    # zero COLUMNS for the pad channels
             pk["blocks"].append(dict(
                 n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
-                qkv=planes(sd[b + "attn.qkv.weight"]), qkv_b=sd[b + "attn.qkv.bias"].contiguous(),
-                qkv_bp=ops.split_planes(sd[b + "attn.qkv.bias"].reshape(1, -1).contiguous(), kpad=3 * D),  # k = v of pad tokens
-                proj=planes(sd[b + "attn.proj.weight"]), proj_b=sd[b + "attn.proj.bias"],
+                qkv=planes(qkv_w), qkv_b=qkv_bias,
+                qkv_bp=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da),  # k = v of pad tokens
+                proj=planes(proj_w), proj_b=sd[b + "attn.proj.bias"],
                 lin1=planes(sd[b + "mlp.lin1.weight"]), lin1_b=sd[b + "mlp.lin1.bias"],
                 lin2=planes(sd[b + "mlp.lin2.weight"]), lin2_b=sd[b + "mlp.lin2.bias"],
-                rph=sd[b + "attn.rel_pos_h"], rpw=sd[b + "attn.rel_pos_w"],
+                rph=pad_cols(sd[b + "attn.rel_pos_h"]), rpw=pad_cols(sd[b + "attn.rel_pos_w"]),
                 ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"]))
-        hd_ = D // cfg["num_heads"]
         for blk in pk["blocks"]:   # windowed blocks with head_dim 64: rel-pos tables packed for the fused window kernel
             wsz = blk["ws"]
             if wsz and wsz <= 14 and hd_ == 64:
@@ -258,6 +284,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 return [merge(u, v) for u, v in zip(ax, ay)]
             return stack2(ax, ay)
         pk["twin2"] = merge(pk["twin"]["x"], pk["twin"]["y"])
+        del pk["twin"]     # only the stacked form is used by the forward (and written by checkpoint.save_packed)
         # --- fusion neck
         f = "spm.smart_fusion."
         pk["neck"] = []
@@ -375,7 +402,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # rel-pos gather tables (IE:554-584)
         g["rel"] = []
         ws = cfg["window_size"]
-        hd_ = cfg["embed_dim"] // cfg["num_heads"]
+        hd_ = self._hd_pad
         g["relg"] = []
         for blk in pk["blocks"]:
             relg = None
@@ -532,25 +559,27 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     def _block(self, bp, rel, x, B, Hp, Wp, relg=None):
         ws, cfg = self._ws, self.cfg
         D, heads = cfg["embed_dim"], cfg["num_heads"]
-        hd = D // heads
+        hd = self._hd_pad                 # head width the kernels see (zero-padded to a multiple of 32: _pack)
+        scale = self._hd_true ** -0.5     # IE:445: head_dim ** -0.5 of the model's true width
+        Da = heads * hd
         T = Hp * Wp
         # intermediate activations travel as bf16 hi/lo planes: split once by the producer, consumed by the
         # GEMM / attention kernels with plain 16-byte copies (same bytes as fp32, no re-splitting per column block)
         n = ws.planes("blk_n", B * T, D)
         ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
-        qkv = ws.planes("blk_qkv", B * T, 3 * D)
+        qkv = ws.planes("blk_qkv", B * T, 3 * Da)
         ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
-        ao = ws.planes("blk_ao", B * T, D)
+        ao = ws.planes("blk_ao", B * T, Da)
         if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
-            ops.window_attention(qkv, bp["qkv_bp"], bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+            ops.window_attention(qkv, bp["qkv_bp"], bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
         elif relg is not None:           # global block on a 64-wide grid: flash kernel with the rel-pos terms fused
-            ops.global_attention(qkv, bp["qkv_bp"], relg, ao, B, Hp, Wp, heads, hd, hd ** -0.5)
+            ops.global_attention(qkv, bp["qkv_bp"], relg, ao, B, Hp, Wp, heads, hd, scale)
         else:
             kk = 2 * wsz if wsz else Hp + Wp
             rp = ws.get("blk_rp", B * heads * T, kk)
             ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
-            ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, hd ** -0.5)
+            ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, scale)
         ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
         ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
         h = ws.planes("blk_h", B * T, bp["lin1"].n)

@@ -1,0 +1,152 @@
+"""Checkpoint ingestion of the drop-in backbone.
+
+  load_pretrained(model, path)   -- what ImageEncoderViT.init_weights does (IE:305-315): the reference's non-strict
+                                    `mmcv_custom.load_checkpoint` (segmentation/mmcv_custom/checkpoint.py:319-514) restated for the
+                                    keys a SAM image-encoder checkpoint has.
+  convert_sam_release(sd)        -- segmentation/tools/SAM_checkpoint_convert.py:15-33: keep 'image_encoder' keys, drop the neck,
+                                    strip the 'image_encoder.' prefix.
+  save_packed / load_packed      -- the backbone's one-time weight pre-pack (bf16 hi/lo planes, folded norms, re-laid-out conv
+                                    weights) written once next to the plain state dict (torch zip-pickle, Appendix A.3 keys), so
+                                    that a serving process does not re-split 456 M parameters at its first forward.
+
+Pinned by tests/test_host_cpu.py against tests/golden/sam_ckpt.npz, which the reference's own loader and converter produced on
+seeded checkpoints (tools/oracle/make_golden.py::gen_sam_ckpt)."""
+import warnings
+
+import torch
+
+from . import ops
+
+PACK_FORMAT = 2
+
+
+def unwrap_state_dict(ck):
+    """checkpoint.py:343-360: 'state_dict' / 'model' / 'module' containers, then a leading 'module.' (DataParallel) prefix on the
+    FIRST key strips 7 characters from every key, then -- when the first key in sorted order starts with 'encoder' (MoBY) -- only
+    'encoder.' keys are kept, with that substring removed."""
+    if not isinstance(ck, dict):
+        raise RuntimeError("No state_dict found in checkpoint file")        # checkpoint.py:339-341
+    sd = ck
+    for key in ("state_dict", "model", "module"):
+        if key in ck:
+            sd = ck[key]
+            break
+    if list(sd.keys())[0].startswith("module."):
+        sd = {k[7:]: v for k, v in sd.items()}
+    if sorted(list(sd.keys()))[0].startswith("encoder"):
+        sd = {k.replace("encoder.", ""): v for k, v in sd.items() if k.startswith("encoder.")}
+    return dict(sd)
+
+
+def _resize_pos_embed_like_reference(sd, model):
+    """checkpoint.py:447-470 as it acts on THIS model (4-D SAM pos_embed [1, Hp, Wp, C], `patch_embed.num_patches` =
+    (img/patch)^2): num_extra_tokens = pos_embed.shape[-2] - num_patches, orig_size = int(sqrt(ckpt.shape[-2] - num_extra_tokens)),
+    new_size = int(sqrt(num_patches)).  For a checkpoint grid equal to the model's the two sizes coincide and nothing happens (the
+    resize to the input resolution is done at forward time, BK:136-143); any other grid makes the reference's reshape fail, which
+    is reported here instead of silently loading something else."""
+    if "pos_embed" not in sd:
+        return
+    pe = sd["pos_embed"]
+    num_patches = (model.cfg["img_size"] // model.cfg["patch_size"]) ** 2
+    num_extra = model.pos_embed.shape[-2] - num_patches
+    orig_size = int((pe.shape[-2] - num_extra) ** 0.5)
+    new_size = int(num_patches ** 0.5)
+    if orig_size != new_size:
+        raise RuntimeError(f"pos_embed of the checkpoint ({tuple(pe.shape)}) does not match the model's ({tuple(model.pos_embed.shape)}): "
+                           "the reference's loader (mmcv_custom/checkpoint.py:460-470) cannot resize a 4-D SAM position embedding "
+                           "either; build the model with the checkpoint's pretrained_size")
+
+
+def load_pretrained(model, path, map_location="cpu"):
+    """Non-strict load with the reference's semantics: unexpected and missing keys are tolerated, a key whose shape differs from
+    the model's is SKIPPED with a warning (mmcv's load_state_dict collects the size-mismatch message of
+    nn.Module._load_from_state_dict and only warns, checkpoint.py:44-113).  Returns (loaded, skipped, unexpected) key lists."""
+    sd = unwrap_state_dict(torch.load(path, map_location=map_location))
+    _resize_pos_embed_like_reference(sd, model)
+    own = model.state_dict()
+    good, skipped, unexpected = {}, [], []
+    for k, v in sd.items():
+        if k not in own:
+            unexpected.append(k)
+        elif tuple(own[k].shape) != tuple(v.shape):
+            skipped.append(k)
+        else:
+            good[k] = v
+    if skipped:
+        warnings.warn("mmsa: size mismatch, not loaded (the model keeps its initialisation): " + ", ".join(skipped))
+    model.load_state_dict(good, strict=False)
+    return sorted(good), skipped, unexpected
+
+
+def convert_sam_release(state_dict):
+    """tools/SAM_checkpoint_convert.py:15-33 on an in-memory SAM release state dict."""
+    kept = {k: v for k, v in state_dict.items() if "image_encoder" in k}
+    kept = {k: v for k, v in kept.items() if "neck" not in k}
+    return {k.replace("image_encoder.", ""): v for k, v in kept.items()}
+
+
+# ---------------------------------------------------------------------------------------------- packed form
+def _enc(o):
+    if isinstance(o, ops.Planes):
+        full = getattr(o, "full", None)
+        return {"__planes__": True, "p": (full if full is not None else o.p).cpu(), "n": o.n, "k": o.k, "kpad": o.kpad, "stacked": full is not None}
+    if isinstance(o, torch.Tensor):
+        return o.cpu()
+    if isinstance(o, dict):
+        return {k: _enc(v) for k, v in o.items() if k not in ("geom", "dev")}
+    if isinstance(o, (list, tuple)):
+        return [_enc(v) for v in o]
+    return o
+
+
+def _dec(o, dev):
+    if isinstance(o, dict) and o.get("__planes__"):
+        buf = o["p"].to(dev)
+        if o["stacked"]:
+            pl = ops.Planes(buf[:o["n"]], o["n"], o["k"], o["kpad"])
+            pl.full = buf
+            return pl
+        return ops.Planes(buf, o["n"], o["k"], o["kpad"])
+    if isinstance(o, torch.Tensor):
+        return o.to(dev)
+    if isinstance(o, dict):
+        return {k: _dec(v, dev) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_dec(v, dev) for v in o]
+    return o
+
+
+def _fingerprint(sd):
+    """Cheap identity of a state dict: key list + a double checksum (order-independent sums are exact enough to tell weights apart)."""
+    return [list(sd.keys()), float(sum(v.double().abs().sum().item() for v in sd.values() if v.dtype.is_floating_point))]
+
+
+def save_packed(model, path, device="cuda"):
+    """Pack `model`'s current weights on `device` (runs the HIP split kernels once) and write {state_dict, packed, fingerprint}."""
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        pk = model._pack(dev)
+        torch.cuda.synchronize(dev)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save({"format": PACK_FORMAT, "cfg": model.cfg, "state_dict": sd, "packed": _enc(pk), "fingerprint": _fingerprint(sd)}, path)
+
+
+def load_packed(model, path, device="cuda"):
+    """Load a file written by save_packed: the plain state dict (strict) AND the packed planes, so the first forward skips _pack.
+    Refuses a file packed for another architecture or whose planes do not belong to the weights it carries."""
+    blob = torch.load(path, map_location="cpu")
+    if not isinstance(blob, dict) or blob.get("format") != PACK_FORMAT:
+        raise RuntimeError(f"{path}: not an mmsa packed checkpoint (format {PACK_FORMAT})")
+    if blob["cfg"] != model.cfg:
+        raise RuntimeError(f"{path}: packed for a different architecture")
+    if blob["fingerprint"] != _fingerprint(blob["state_dict"]):
+        raise RuntimeError(f"{path}: state dict and packed planes do not belong together")
+    model.load_state_dict(blob["state_dict"], strict=True)       # invalidates any earlier pack (post hook)
+    dev = torch.device(device)
+    pk = _dec(blob["packed"], dev)
+    pk["geom"] = {}
+    pk["dev"] = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+    model._packed = pk
+    hd = model.cfg["embed_dim"] // model.cfg["num_heads"]
+    model._hd_true, model._hd_pad = hd, ops.pad32(hd)
+    return model

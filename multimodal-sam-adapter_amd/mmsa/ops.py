@@ -189,19 +189,47 @@ def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None,
     return out if out is not None else out_planes
 
 
-def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
-    """Drop-in for MultiScaleDeformableAttention.ms_deform_attn_forward (ops/src/vision.cpp:14)."""
-    for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
+MSDA_DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}   # MMSA_DT_* (include/mmsa.h)
+
+
+def _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
+    dt = value.dtype
+    if dt not in MSDA_DTYPES:
+        raise RuntimeError(f"ms_deform_attn: dtype {dt} not supported (float32, float16, float64)")   # the reference's dispatch set
+    for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")) + tuple(extra):
         if not t.is_contiguous():
             raise RuntimeError(f"{n} tensor has to be contiguous")  # ms_deform_attn_cuda.cu:28-32
+        if t.dtype != dt:
+            raise RuntimeError(f"{n} must have the dtype of value ({dt}), got {t.dtype}")
     if not (spatial_shapes.is_contiguous() and level_start_index.is_contiguous()):
         raise RuntimeError("spatial_shapes / level_start_index tensor has to be contiguous")
+    return dt
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Drop-in for MultiScaleDeformableAttention.ms_deform_attn_forward (ops/src/vision.cpp:14); float32 / float16 / float64."""
+    dt = _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     n, s, m, d = value.shape
     _, lq, _, l, p, _ = sampling_loc.shape
-    out = torch.empty(n, lq, m * d, dtype=torch.float32, device=value.device)
-    lib.call("mmsa_ms_deform_attn_forward", _chk(value), _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64),
-             _chk(sampling_loc), _chk(attn_weight), out.data_ptr(), n, s, m, d, l, lq, p, im2col_step, _stream())
+    out = torch.empty(n, lq, m * d, dtype=dt, device=value.device)
+    lib.call("mmsa_ms_deform_attn_forward", _chk(value, dt), _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64),
+             _chk(sampling_loc, dt), _chk(attn_weight, dt), out.data_ptr(), n, s, m, d, l, lq, p, im2col_step, MSDA_DTYPES[dt], _stream())
     return out
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    """Drop-in for MultiScaleDeformableAttention.ms_deform_attn_backward (ops/src/vision.cpp:15) ->
+    [grad_value, grad_sampling_loc, grad_attn_weight]."""
+    dt = _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=((grad_output, "grad_output"),))
+    n, s, m, d = value.shape
+    _, lq, _, l, p, _ = sampling_loc.shape
+    if tuple(grad_output.shape) != (n, lq, m * d):
+        raise RuntimeError(f"grad_output must be [{n}, {lq}, {m * d}], got {tuple(grad_output.shape)}")
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+    lib.call("mmsa_ms_deform_attn_backward", _chk(value, dt), _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64),
+             _chk(sampling_loc, dt), _chk(attn_weight, dt), _chk(grad_output, dt), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+             n, s, m, d, l, lq, p, im2col_step, MSDA_DTYPES[dt], _stream())
+    return [gv, gl, ga]
 
 
 def msda_fused(value2d, spatial_shapes, level_start_index, raw, ref_points, out, batch, spatial, heads, d, levels, lq, points,

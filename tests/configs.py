@@ -20,12 +20,19 @@ _VITL = dict(img_size=1024, modalities_name=["rgb", "lidar"], modalities_ch=[3, 
 _VITB = dict(_VITL, img_size=512, embed_dim=768, depth=12, num_heads=12, deform_num_heads=12,
              interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]], global_attn_indexes=[2, 5, 8, 11])
 
+# the pinnable half of BASELINE.json configs[4]: SAM ViT-H (IE:188-303 with embed_dim 1280, depth 32, 16 heads -> head_dim 80,
+# global blocks per the comment at IE:206) behind the same RGB+LiDAR adapter.  NOT the headline workload; the 3-modality / fp8 part
+# of that config has no reference implementation (TC:296-316).
+_VITH = dict(_VITL, embed_dim=1280, depth=32, num_heads=16, deform_num_heads=16,
+             interaction_indexes=[[0, 7], [8, 15], [16, 23], [24, 31]], global_attn_indexes=[7, 15, 23, 31])
+
 CONFIGS = {
     "tiny224": dict(kwargs=dict(_TINY, img_size=224), batch=1, seed=1, in_seed=5),
     "tiny256": dict(kwargs=dict(_TINY, img_size=256), batch=1, seed=2, in_seed=6),
     "tiny320": dict(kwargs=dict(_TINY, img_size=320), batch=1, seed=3, in_seed=7),
     "vitb512": dict(kwargs=_VITB, batch=1, seed=4, in_seed=8),
     "vitl1024": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9),
+    "vith1024": dict(kwargs=_VITH, batch=1, seed=17, in_seed=18),
 }
 
 
@@ -96,4 +103,21 @@ def fake_convnext_checkpoint(twin_keys_shapes, seed=41):
         else:
             continue
         sd[base + "." + rest] = torch.randn(shp, generator=g) * 0.1
+    return sd
+
+
+def fake_sam_checkpoint(vit_keys_shapes, seed=51, drop=True):
+    """A seeded SAM image-encoder state dict (pos_embed, patch_embed.proj.*, blocks.N.*) for the given key/shape list.  With `drop`:
+    block 2 is missing entirely, blocks.1.attn.rel_pos_h has a wrong length (a 63-row table) and an unexpected 'neck.0.weight' is
+    present -- the three irregularities a non-strict load has to survive (checkpoint.py:343-360, load_state_dict :44-113)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in vit_keys_shapes:
+        if drop and k.startswith("blocks.2."):
+            continue
+        if drop and k == "blocks.1.attn.rel_pos_h":
+            shp = (63, shp[1])
+        sd[k] = torch.randn(shp, generator=g) * 0.1
+    if drop:
+        sd["neck.0.weight"] = torch.ones(4, 4)
     return sd

@@ -227,3 +227,43 @@ def test_two_instances_on_two_streams_bit_exact():
         torch.cuda.synchronize()
         for u, v in zip(got_a + got_b, ref_a + ref_b):
             assert torch.equal(u, v), f"round {it}: a result changed under concurrent work"
+
+
+def test_vith1024_probes(golden_dir):
+    """The pinnable half of BASELINE.json configs[4]: SAM ViT-H (embed 1280, depth 32, 16 heads -> head_dim 80, run zero-padded to 96
+    per head; MSDA heads of 40 channels) behind the RGB+LiDAR adapter at 1024x1024, against probes of the imported reference."""
+    cfg, orc, m = _build("vith1024")
+    del orc
+    g = np.load(os.path.join(golden_dir, "model_vith1024.npz"))
+    fs, _ = m(make_input(cfg).to(DEV))
+    for i, f in enumerate(fs):
+        pi = probe_index(f.numel(), 2048, seed=100 + i)
+        got = f.flatten()[pi.to(DEV)].cpu()
+        ref = torch.from_numpy(g[f"f{i+1}_probe"])
+        assert_close(got, ref, what=f"vith1024 f{i+1} probes")
+        st = g[f"f{i+1}_stats"]
+        assert abs(f.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-3 * st[3]
+
+
+def test_packed_checkpoint_round_trip(tmp_path):
+    """mmsa.checkpoint.save_packed / load_packed: a model restored from the packed file (plain state dict + pre-split planes) returns,
+    bit for bit, what the model that wrote it returns, without running _pack again."""
+    import mmsa
+    from mmsa import checkpoint as C
+    cfg, orc, m = _build("tiny256")
+    del orc
+    x = make_input(cfg, batch=2, seed=5).to(DEV)
+    ref = [f.clone() for f in m(x)[0]]
+    path = str(tmp_path / "tiny.packed.pth")
+    C.save_packed(m, path, device=DEV)
+    m2 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    C.load_packed(m2, path, device=DEV)
+
+    def boom(dev):
+        raise AssertionError("_pack must not run after load_packed")
+    m2._pack = boom
+    for a, b in zip(m2(x)[0], ref):
+        assert torch.equal(a, b)
+    other = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **CONFIGS["tiny224"]["kwargs"]))
+    with pytest.raises(RuntimeError, match="different architecture"):
+        C.load_packed(other, path, device=DEV)

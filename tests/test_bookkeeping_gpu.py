@@ -7,8 +7,8 @@ reference functions on an index tensor).
 How attention is made to reveal the permutation: every token's K is a +-a code of its in-window position p (taken from the
 golden table), its Q is the code of the position NEXT to it in the same window (the next non-pad slot, cyclically), its V carries
 its own token id.  The diagonal-dominant logits make the softmax exactly one-hot in fp32 (margin > 60 in the exponent), so the
-kernel returns for token t exactly the id of the token that the reference's window_partition places in the successor slot of
-t's window; a token gathered into a wrong window / slot, a pad slot that is not bias-valued, or an output scattered to a wrong
+kernel returns for token t the id (to ~1e-7 relative; rounded to the integer) of the token that the reference's window_partition
+places in the successor slot of t's window; a token gathered into a wrong window / slot, a pad slot that is not bias-valued, or an output scattered to a wrong
 row changes integers.  Ids < 2^16 are exact in the bf16 hi+lo planes."""
 import os
 
@@ -21,22 +21,22 @@ DEV = "cuda:0"
 GEOMS = [(14, 14, 14), (16, 16, 14), (20, 20, 14), (64, 64, 14), (32, 32, 14)]   # all five of tests/golden/bookkeeping.npz
 
 
-def _codes(n, hd, seed):
-    """n distinct +-1 codes of length hd with a verified correlation margin."""
+def _codes(n, hd, seed, max_corr):
+    """n distinct +-1 codes of length hd whose pairwise correlations stay <= max_corr * hd (verified)."""
     g = torch.Generator().manual_seed(seed)
-    for _ in range(50):
+    for _ in range(200):
         c = (torch.randint(0, 2, (n, hd), generator=g) * 2 - 1).float()
         gram = c @ c.t()
         gram.fill_diagonal_(-hd)
-        if gram.max().item() <= hd * 0.6:
+        if gram.max().item() <= hd * max_corr:
             return c
     raise AssertionError("no code set with the required margin")
 
 
-def _expected_and_qkv(win, B, H, W, ws, hd, amp):
+def _expected_and_qkv(win, B, H, W, ws, hd, amp, max_corr):
     """win: golden [B*nW, ws, ws] (token id + 1, 0 = pad).  Returns qkv fp32 [B*H*W, 3*hd] and expected ids [B*H*W]."""
     nslot = ws * ws
-    codes = _codes(nslot, hd, seed=1000 + H) * amp
+    codes = _codes(nslot, hd, 1000 + H, max_corr) * amp
     flat = torch.from_numpy(win).reshape(-1, nslot)            # [windows, slots]
     T = B * H * W
     q = torch.zeros(T, hd)
@@ -63,15 +63,16 @@ def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws):
     g = np.load(os.path.join(golden_dir, "bookkeeping.npz"))
     win = g[f"wp_{H}_{W}_{ws}"]
     B, hd = 2, 64
-    qkv, expect = _expected_and_qkv(win, B, H, W, ws, hd, amp=4.0)     # logits: 64*16/8 = 128 on the match, <= 0.6*128 elsewhere
+    qkv, expect = _expected_and_qkv(win, B, H, W, ws, hd, amp=4.0, max_corr=0.6)     # logits: 64*16/8 = 128 on the match, <= 0.6*128 elsewhere
     qp = ops.split_planes(qkv.to(DEV))
     bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)    # pad slots: k = v = bias = 0
     relp = ops.window_relpos_planes(torch.zeros(2 * ws - 1, hd, device=DEV), torch.zeros(2 * ws - 1, hd, device=DEV), ws)
     out = ops.alloc_planes(B * H * W, hd, DEV)
     ops.window_attention(qp, bias_p, relp, out, B, H, W, 1, hd, ws, hd ** -0.5)
     got = ops.planes_to_float(out).cpu()
-    assert torch.equal(got, got.round()), "non-integer output: the softmax was not one-hot"
-    ids = got.to(torch.int64)
+    # the softmax is one-hot up to the rounding of exp2 / the normalisation (1e-7 relative): ids are recovered by rounding
+    assert (got - got.round()).abs().max() < 1e-2, "the softmax was not one-hot"
+    ids = got.round().to(torch.int64)
     assert torch.equal(ids, expect[:, None].expand(-1, hd)), f"window bookkeeping differs for {H}x{W} ws={ws}"
     # and the inverse table of the reference: window_unpartition(window_partition(idx)) == idx, i.e. every token was written
     assert torch.equal(torch.from_numpy(g[f"wu_{H}_{W}_{ws}"]).reshape(-1), torch.arange(1, B * H * W + 1))
@@ -85,15 +86,15 @@ def test_window_bookkeeping_bit_exact_generic_kernel(golden_dir, H, W, ws):
     g = np.load(os.path.join(golden_dir, "bookkeeping.npz"))
     win = g[f"wp_{H}_{W}_{ws}"]
     B, hd = 2, 32
-    qkv, expect = _expected_and_qkv(win, B, H, W, ws, hd, amp=8.0)     # logits: 32*64/sqrt(32) = 362 on the match
+    qkv, expect = _expected_and_qkv(win, B, H, W, ws, hd, amp=8.0, max_corr=0.75)     # logits: 32*64/sqrt(32) = 362 on the match, <= 272 elsewhere
     qp = ops.split_planes(qkv.to(DEV))
     bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)
     rp = torch.zeros(B * H * W, 2 * ws, device=DEV)
     out = ops.alloc_planes(B * H * W, hd, DEV)
     ops.attention(qp, bias_p, rp, out, B, H, W, 1, hd, ws, hd ** -0.5)
     got = ops.planes_to_float(out).cpu()
-    assert torch.equal(got, got.round())
-    assert torch.equal(got.to(torch.int64), expect[:, None].expand(-1, hd)), f"window bookkeeping differs for {H}x{W} ws={ws}"
+    assert (got - got.round()).abs().max() < 1e-2
+    assert torch.equal(got.round().to(torch.int64), expect[:, None].expand(-1, hd)), f"window bookkeeping differs for {H}x{W} ws={ws}"
 
 
 def test_rel_pos_gather_index_bit_exact_on_device(golden_dir):

@@ -125,7 +125,9 @@ def _dp_worker(rank, world, port, q):
     lo7, hi7 = D.shard_range(7, rank, world)
     loc7 = torch.arange(lo7, hi7, dtype=torch.float32).view(-1, 1).expand(-1, 5).contiguous()
     all7 = D.allgather_logits(loc7, global_batch=7)
-    q.put((rank, lo, hi, allg.clone(), slow, (lo7, hi7), all7.clone()))
+    # plain Python lists through the queue: a tensor travels as a file descriptor that the parent can only fetch while this
+    # process is still alive (a FileNotFoundError race at exit otherwise)
+    q.put((rank, lo, hi, allg.tolist(), slow, (lo7, hi7), all7.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -145,6 +147,7 @@ def test_data_parallel_harness_gloo_world2():
         assert p.exitcode == 0
     (r0, lo0, hi0, g0, s0, sh0, u0), (r1, lo1, hi1, g1, s1, sh1, u1) = res
     assert (sh0, sh1) == ((0, 4), (4, 7))
+    u0, u1, g0, g1 = torch.tensor(u0), torch.tensor(u1), torch.tensor(g0), torch.tensor(g1)
     assert torch.equal(u0, u1) and u0.shape == (7, 5) and u0[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
     assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 6)
     assert torch.equal(g0, g1) and g0.shape == (6, 2, 3)
@@ -232,3 +235,72 @@ def test_bench_parent_starts_no_ranks_without_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "--gpus 2 asked for" in r.stderr
+
+
+def _tiny_backbone(**extra):
+    import mmsa
+    from tests.configs import CONFIGS
+    return mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **dict(CONFIGS["tiny256"]["kwargs"], **extra)))
+
+
+def test_sam_checkpoint_ingestion_matches_the_reference_loader(golden_dir, tmp_path):
+    """init_weights(pretrained) against the reference's own mmcv_custom.load_checkpoint (checkpoint.py:319-514) run on the same seeded
+    checkpoint (tests/golden/sam_ckpt.npz case A): 'state_dict' wrapper + 'module.' prefix, an unexpected key, a missing block and
+    a rel-pos table of the wrong length.  Same keys loaded, same keys left at their initialisation, same checksum."""
+    from tests.configs import fake_sam_checkpoint
+    g = np.load(os.path.join(golden_dir, "sam_ckpt.npz"))
+    m0 = _tiny_backbone()
+    vit = [(k, tuple(v.shape)) for k, v in m0.state_dict().items() if k.startswith(("pos_embed", "patch_embed.", "blocks."))]
+    plain = fake_sam_checkpoint(vit, seed=51)
+    path = str(tmp_path / "sam_a.pth")
+    torch.save({"state_dict": {"module." + k: v for k, v in plain.items()}, "meta": {"epoch": 3}}, path)
+    with pytest.warns(UserWarning, match="size mismatch"):
+        m = _tiny_backbone(pretrained=path)
+    sd = m.state_dict()
+    loaded = [k for k, _ in vit if k in plain and plain[k].shape == sd[k].shape and torch.equal(plain[k], sd[k])]
+    assert loaded == list(g["a_loaded"])
+    assert [k for k, _ in vit if k not in loaded] == list(g["a_not_loaded"])
+    assert "blocks.1.attn.rel_pos_h" in list(g["a_not_loaded"])
+    chk = sum(sd[k].double().abs().sum().item() for k in loaded)
+    assert abs(chk - float(g["a_checksum"])) <= 1e-9 * float(g["a_checksum"])
+    rep = m._pretrained_report
+    assert rep[1] == ["blocks.1.attn.rel_pos_h"] and rep[2] == ["neck.0.weight"]
+
+
+def test_sam_release_conversion_matches_the_reference_tool(golden_dir, tmp_path):
+    """convert_sam_release against the reference's tools/SAM_checkpoint_convert.py::remove_neck_from_checkpoint (case B of the
+    fixture): same surviving key set, and the converted checkpoint loads every ViT key."""
+    from mmsa.checkpoint import convert_sam_release
+    from tests.configs import fake_sam_checkpoint
+    g = np.load(os.path.join(golden_dir, "sam_ckpt.npz"))
+    m0 = _tiny_backbone()
+    vit = [(k, tuple(v.shape)) for k, v in m0.state_dict().items() if k.startswith(("pos_embed", "patch_embed.", "blocks."))]
+    raw = {"image_encoder." + k: v for k, v in fake_sam_checkpoint(vit, seed=52, drop=False).items()}
+    raw["image_encoder.neck.0.weight"] = torch.ones(4, 4)
+    raw["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = torch.ones(2, 8)
+    raw["mask_decoder.iou_token.weight"] = torch.ones(1, 8)
+    conv = convert_sam_release(raw)
+    assert sorted(conv.keys()) == list(g["b_converted_keys"])
+    path = str(tmp_path / "sam_b.pth")
+    torch.save(conv, path)
+    m = _tiny_backbone(pretrained=path)
+    sd = m.state_dict()
+    assert [k for k, _ in vit if torch.equal(conv[k], sd[k])] == list(g["b_loaded"]) and len(g["b_not_loaded"]) == 0
+    chk = sum(sd[k].double().abs().sum().item() for k, _ in vit)
+    assert abs(chk - float(g["b_checksum"])) <= 1e-9 * float(g["b_checksum"])
+
+
+def test_unreadable_convnext_checkpoint_is_reported(monkeypatch):
+    monkeypatch.delenv("MMSA_CONVNEXT_CKPT", raising=False)
+    with pytest.warns(UserWarning, match="ConvNeXt checkpoint"):
+        _tiny_backbone(checkpoint="https://download.openmmlab.com/mmclassification/v0/convnext/convnext-small.pth")
+
+
+def test_checkpoint_unwrap_conventions():
+    from mmsa.checkpoint import unwrap_state_dict
+    t = torch.ones(1)
+    assert unwrap_state_dict({"model": {"module.a.b": t}}) == {"a.b": t}
+    assert unwrap_state_dict({"module": {"encoder.x": t, "zhead.y": t}}) == {"x": t}     # MoBY online branch (checkpoint.py:355-360)
+    assert unwrap_state_dict({"a": t}) == {"a": t}
+    with pytest.raises(RuntimeError):
+        unwrap_state_dict([t])

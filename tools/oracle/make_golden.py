@@ -58,6 +58,38 @@ def gen_msda():
     np.savez_compressed(os.path.join(OUT, "msda.npz"), **out)
 
 
+def gen_msda_bwd():
+    """Gradients of the reference's own ms_deform_attn_core_pytorch (OPS/functions/ms_deform_attn_func.py:53-75), taken by autograd
+    for a seeded upstream gradient: what ms_deform_attn_backward (OPS/src/vision.cpp:15) must return.  Cases: the geometry of the
+    reference's gradient check (OPS/test.py:16-20,77-90: N,M = 1,2; Lq,L,P = 2,2,2; shapes (6,4),(3,2); channels 4) in float64,
+    and the border-sampling injector / extractor-like cases of msda.npz (23 % of taps outside [0,1]) plus a D = 40 head (ViT-H) in
+    float32."""
+    fn = ref_import.ref_functions()["msda_core"]
+    out = {}
+
+    def case(tag, shp, N, M, D, Lq, P, dt, seed, spread):
+        g = torch.Generator().manual_seed(seed)
+        shapes = torch.as_tensor(shp, dtype=torch.long)
+        lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        S, L = int(shapes.prod(1).sum()), len(shp)
+        value = (torch.randn(N, S, M, D, generator=g, dtype=torch.float64)).to(dt).requires_grad_(True)
+        loc = (torch.rand(N, Lq, M, L, P, 2, generator=g, dtype=torch.float64) * spread - (spread - 1) / 2).to(dt).requires_grad_(True)
+        aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g, dtype=torch.float64), -1).view(N, Lq, M, L, P).to(dt).requires_grad_(True)
+        gout = torch.randn(N, Lq, M * D, generator=g, dtype=torch.float64).to(dt)
+        y = fn(value, shapes, loc, aw)
+        gv, gl, ga = torch.autograd.grad(y, (value, loc, aw), gout)
+        out.update({f"{tag}_shapes": shapes.numpy(), f"{tag}_lsi": lsi.numpy(), f"{tag}_value": value.detach().numpy(),
+                    f"{tag}_loc": loc.detach().numpy(), f"{tag}_aw": aw.detach().numpy(), f"{tag}_gout": gout.numpy(),
+                    f"{tag}_gvalue": gv.numpy(), f"{tag}_gloc": gl.numpy(), f"{tag}_gaw": ga.numpy()})
+
+    case("t64", [(6, 4), (3, 2)], 1, 2, 4, 2, 2, torch.float64, 3, 1.0)
+    case("inj", [(16, 12), (8, 6), (4, 3)], 2, 4, 32, 48, 4, torch.float32, 21, 1.3)
+    case("ext", [(8, 6)], 2, 4, 32, 252, 4, torch.float32, 22, 1.3)
+    case("d40", [(8, 6), (4, 3)], 1, 2, 40, 24, 4, torch.float32, 23, 1.3)
+    np.savez_compressed(os.path.join(OUT, "msda_bwd.npz"), **out)
+    print("msda_bwd", sorted(k for k in out if k.endswith("_gvalue")), flush=True)
+
+
 def gen_bookkeeping():
     f = ref_import.ref_functions()
     out = {}
@@ -175,12 +207,76 @@ def gen_ckpt():
     print("convnext ckpt: loaded", len(loaded), "of", len(keys), "twin keys", flush=True)
 
 
+def gen_sam_ckpt():
+    """The reference's OWN checkpoint ingestion on seeded SAM-style checkpoints (tests/golden/sam_ckpt.npz):
+      A. `mmcv_custom.load_checkpoint` (checkpoint.py:319-514) as called by ImageEncoderViT.init_weights (IE:305-315) on a wrapped
+         checkpoint: {'state_dict': {'module.<key>': ...}} with an unexpected key, a missing block and one rel-pos table whose
+         length does not match the model's (skipped with a warning by the non-strict loader);
+      B. a raw SAM release layout ('image_encoder.<key>' + 'image_encoder.neck.*' + prompt/mask-decoder keys) passed through the
+         reference's tools/SAM_checkpoint_convert.py::remove_neck_from_checkpoint (:15-33) and then loaded the same way.
+    Stored: which backbone keys end up equal to their checkpoint tensor, and a checksum of the whole loaded ViT part."""
+    import importlib.util
+    import tempfile
+    from tests.configs import fake_sam_checkpoint
+    cfg = CONFIGS["tiny256"]
+    ref0 = ref_import.build_reference(**cfg["kwargs"])
+    import mmcv_custom.checkpoint as ck          # the reference's loader; its two mmcv helpers are absent from this image
+    ck.is_module_wrapper = lambda m: False       # mmcv.parallel.is_module_wrapper: no DataParallel wrapper here
+    ck.get_dist_info = lambda: (0, 1)            # mmcv.runner.get_dist_info: single process
+    vit = [(k, tuple(v.shape)) for k, v in ref0.state_dict().items()
+           if k.startswith(("pos_embed", "patch_embed.", "blocks."))]
+    tmpd = tempfile.gettempdir()
+    out = {}
+
+    def run(tag, path, plain):
+        torch.manual_seed(0)
+        ref = ref_import.build_reference(**dict(cfg["kwargs"], pretrained=path))
+        sd = ref.state_dict()
+        loaded = [k for k, _ in vit if k in plain and plain[k].shape == sd[k].shape and torch.equal(plain[k], sd[k])]
+        out[f"{tag}_loaded"] = np.array(loaded)
+        out[f"{tag}_not_loaded"] = np.array([k for k, _ in vit if k not in loaded])
+        out[f"{tag}_checksum"] = np.float64(sum(sd[k].double().abs().sum().item() for k in loaded))   # the keys left alone keep an initialisation that is the model's own
+        print("sam ckpt", tag, "loaded", len(loaded), "of", len(vit), flush=True)
+
+    # A: wrapped + prefixed
+    plain = fake_sam_checkpoint(vit, seed=51)
+    pa = os.path.join(tmpd, "mmsa_fake_sam_a.pth")
+    torch.save({"state_dict": {"module." + k: v for k, v in plain.items()}, "meta": {"epoch": 3}}, pa)
+    run("a", pa, plain)
+    # B: raw SAM layout through the reference's converter
+    raw = {"image_encoder." + k: v for k, v in fake_sam_checkpoint(vit, seed=52, drop=False).items()}
+    raw["image_encoder.neck.0.weight"] = torch.ones(4, 4)
+    raw["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = torch.ones(2, 8)
+    raw["mask_decoder.iou_token.weight"] = torch.ones(1, 8)
+    praw, pconv = os.path.join(tmpd, "mmsa_fake_sam_raw.pth"), os.path.join(tmpd, "mmsa_fake_sam_conv.pth")
+    torch.save(raw, praw)
+    spec = importlib.util.spec_from_file_location("sam_convert", os.path.join(ref_import.SEG, "tools", "SAM_checkpoint_convert.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        conv.remove_neck_from_checkpoint(praw, pconv)
+    converted = torch.load(pconv, map_location="cpu")
+    out["b_converted_keys"] = np.array(sorted(converted.keys()))
+    run("b", pconv, converted)
+    np.savez_compressed(os.path.join(OUT, "sam_ckpt.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also ViT-B@512 and ViT-L@1024 (minutes, GBs of RAM)")
+    ap.add_argument("--only", default=None, help="run one generator: msda_bwd | sam_ckpt | model:<config name>")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if a.only:
+        if a.only.startswith("model:"):
+            gen_model(a.only.split(":", 1)[1], full=False)
+        else:
+            globals()["gen_" + a.only]()
+        return
+    gen_msda_bwd()
     gen_msda()
     gen_bookkeeping()
     for n in ("tiny224", "tiny256", "tiny320"):
