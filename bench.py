@@ -51,7 +51,7 @@ for p in (ROOT, os.path.join(ROOT, "multimodal-sam-adapter_amd")):
         sys.path.insert(0, p)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-FLOPS_PER_IMAGE = {"vitl1024": 4.5207e12, "vitb512": 0.5411e12}   # vith1024: no SURVEY figure -> end_to_end_algorithmic_tflops is null   # algorithmic GEMM/conv/bmm FLOPs per image
+FLOPS_PER_IMAGE = {"vitl1024": 4.5207e12, "vitb512": 0.5411e12}   # algorithmic GEMM/conv/bmm FLOPs per image (vith1024: no figure -> null)
 
 
 def parse():
