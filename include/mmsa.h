@@ -37,6 +37,9 @@ const char* mmsa_last_error(void);
 /* HIP events on the launch stream (for bench.py; torch.cuda.Event only sees torch's current stream). */
 /* testing aid: fill the LDS of every CU with `pattern` (finds kernels that read LDS they did not write) */
 int mmsa_debug_poison_lds(unsigned pattern, mmsa_stream_t stream);
+/* testing / A-B aid: force the workgroup flavour of mmsa_gemm_split3's LDS-DMA kernel (4 = 128-row tiles, two workgroups per CU;
+ * 8 = 256-row ping-pong tiles; 0 = automatic by shape).  Results are bit-identical either way (same k order per output element). */
+int mmsa_debug_gemm_flavour(int waves_per_workgroup);
 int mmsa_event_create(void** ev);
 int mmsa_event_record(void* ev, mmsa_stream_t stream);
 int mmsa_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
@@ -221,6 +224,16 @@ int mmsa_bilinear_accum_nchw(const float* src, long src_strideB, int B, int C, i
                              int hc, int wc, float* count, int accumulate, mmsa_stream_t stream);
 int mmsa_div_count_nchw(float* x, const float* count, int B, int C, long HW, mmsa_stream_t stream);
 int mmsa_argmax_nchw(const float* x, unsigned char* out, int B, int C, long HW, mmsa_stream_t stream);
+/* crop extraction of slide inference (ED:205-212) for a batch of windows in one launch: dst[k] = src[b_k, :, y0_k:+hc, x0_k:+wc];
+ * `windows` is a HOST array [n,3] = (image, y0, x0), n <= 64 (copied into the launch arguments). */
+int mmsa_crop_batch_nchw(const float* src, int B, int C, int H, int W, const int* windows, int n, float* dst, int hc, int wc,
+                         mmsa_stream_t stream);
+/* class map of a whole sliding-window frame in one pass (ED:213-225 + ED:449,477): out[b,y,x] = argmax_c (sum over the covering windows,
+ * in window order, of bilinear(logits_k -> hc x wc)[c]) / count -- the same additions in the same order as bilinear_accum + div_count +
+ * argmax without the [B,C,H,W] canvas; one full-size window per image = resize + argmax of whole-image inference.  logits [n,C,hs,ws];
+ * `uncovered` (device int, zeroed by the caller) counts pixels that no window covers (ED:220). */
+int mmsa_slide_argmax(const float* logits, int n, int C, int hs, int ws, const int* windows, unsigned char* out, int B, int H, int W,
+                      int hc, int wc, int* uncovered, mmsa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -40,13 +40,11 @@ struct GemmV2Args {
   int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 10 = epilogue without its global stores
 };
 
-#define V2_BM 256
 #define V2_BN 128
 #define V2_BK 32
-#define V2_A_BYTES (V2_BM * 128)                        // 32 KiB: 256 rows x (64 B hi | 64 B lo)
 #define V2_W_BYTES (V2_BN * 128)                        // 16 KiB
-#define V2_STAGE (V2_A_BYTES + V2_W_BYTES)              // 48 KiB
-#define V2_NST 3
+// per workgroup flavour (template parameter NW of the kernel): rows per tile 256 / 128, A stage 32 / 16 KiB, ring 3 x 48 / 2 x 32 KiB
+#define V2_LDS_BYTES(NW_) (((NW_) == 8 ? 3 : 2) * ((NW_) * 32 * 128 + V2_W_BYTES))
 #ifndef V2_SETPRIO
 #define V2_SETPRIO 0   // s_setprio(1) around the MFMA chunks: measured no effect on this kernel (same-box A/B)
 #endif
@@ -72,9 +70,20 @@ extern "C" int mmsa_debug_stamps(unsigned long long* host_out) {
 #else
 #define STAMP(i_)
 #endif
-template <bool GEN, int ACT, bool PP>
-__global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
+// NW = waves per workgroup.  8: the 256 x 128 tile, 3-slot ring, one workgroup per CU (ping-pong main loop).  4: a 128 x 128 tile
+// (wave tile 64 x 64 as before), 2-slot ring of 32 KiB stages, TWO workgroups per CU: the epilogue of one workgroup (VALU + stores,
+// matrix pipe idle) runs under the k-loop of the other.  For shapes whose epilogue is a large share of a tile's life (few
+// k-tiles: K <= 512, GELU / planes epilogues) that overlap is worth more than the deeper pipeline of the big tile.
+template <bool GEN, int ACT, bool PP, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV2Args a) {
+  static_assert(NW == 8 || (NW == 4 && !PP), "4-wave workgroups run the in-phase main loop");
   constexpr bool EPI_UNROLL = ACT >= 0;
+  constexpr int V2_BM = NW * 32;
+  constexpr int V2_A_BYTES = V2_BM * 128;
+  constexpr int V2_STAGE = V2_A_BYTES + V2_W_BYTES;
+  constexpr int V2_NST = NW == 8 ? 3 : 2;
+  constexpr int WROWS = V2_BN / NW;          // weight rows a wave stages per k-tile: 16 (two DMA instructions) or 32 (four)
+  constexpr int NDMA = 4 + WROWS / 8;        // DMA instructions per wave and k-tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -103,8 +112,8 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
   // rows 8i + drow of a 16-row tile: key = (row_in_16 >> 1) & 7 = (drow >> 1) + 4*(i & 1)
   const int dpiece = ((lane & 7) ^ (drow >> 1)) * 8;         // even 8-row groups; odd groups use dpiece ^ 32
   const int lds_a = wave * 32 * 128;   // this wave's 32 rows of the A image (4 instructions x 8 rows)
-  const int lds_w = wave * 16 * 128;   // 16 rows of the W image (2 instructions)
-  const unsigned short *sa0, *sa1, *sa2, *sa3, *sw0, *sw1;
+  const int lds_w = wave * WROWS * 128;   // this wave's rows of the W image (2 or 4 instructions)
+  const unsigned short *sa0, *sa1, *sa2, *sa3, *sw0, *sw1, *sw2 = nullptr, *sw3 = nullptr;
 
 #define SET_TILE_SRC(tile_)                                                      \
   do {                                                                           \
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     const int bz_ = t_ / per_b_;                                                 \
     const int r_ = t_ - bz_ * per_b_;                                            \
     const int m0_ = (r_ / a.nbn) * V2_BM, n0_ = (r_ % a.nbn) * a.bn;             \
-    const int ab_ = m0_ + wave * 32 + drow, wb_ = n0_ + wave * 16 + drow;        \
+    const int ab_ = m0_ + wave * 32 + drow, wb_ = n0_ + wave * WROWS + drow;     \
     const unsigned short* ap_ = a.Ap + (long)bz_ * a.strideA;                    \
     const unsigned short* wp_ = a.Wp + (long)bz_ * a.strideW;                    \
     sa0 = ap_ + (long)min(ab_, a.M - 1) * a.lda + dpiece;                        \
@@ -122,6 +131,10 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     sa3 = ap_ + (long)min(ab_ + 24, a.M - 1) * a.lda + (dpiece ^ 32);            \
     sw0 = wp_ + (long)min(wb_, a.N - 1) * 2 * K + dpiece;                        \
     sw1 = wp_ + (long)min(wb_ + 8, a.N - 1) * 2 * K + (dpiece ^ 32);             \
+    if constexpr (NW == 4) {                                                     \
+      sw2 = wp_ + (long)min(wb_ + 16, a.N - 1) * 2 * K + dpiece;                 \
+      sw3 = wp_ + (long)min(wb_ + 24, a.N - 1) * 2 * K + (dpiece ^ 32);          \
+    }                                                                            \
   } while (0)
 
 #define ISSUE_DMA(kt_, st_)                                                       \
@@ -134,6 +147,10 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     GLDS16(sa3 + ko_, sb_ + lds_a + 3072);                                        \
     GLDS16(sw0 + ko_, sb_ + V2_A_BYTES + lds_w);                                  \
     GLDS16(sw1 + ko_, sb_ + V2_A_BYTES + lds_w + 1024);                           \
+    if constexpr (NW == 4) {                                                      \
+      GLDS16(sw2 + ko_, sb_ + V2_A_BYTES + lds_w + 2048);                         \
+      GLDS16(sw3 + ko_, sb_ + V2_A_BYTES + lds_w + 3072);                         \
+    }                                                                             \
   } while (0)
 
   f32x4 acc[4][4];  // [ni][mi]
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 #define PREFETCH_NEXT()                                     \
   do {                                                      \
     ISSUE_DMA(pf_kt, pf_st);                                \
-    pf_st = pf_st == 2 ? 0 : pf_st + 1;                     \
+    pf_st = pf_st == V2_NST - 1 ? 0 : pf_st + 1;            \
     ++pf_j;                                                 \
     if (++pf_kt == nk) {                                    \
       pf_kt = 0;                                            \
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     }                                                       \
   } while (0)
   PREFETCH_NEXT();
-  if (total > 1) PREFETCH_NEXT();
+  if (V2_NST == 3 && total > 1) PREFETCH_NEXT();   // the 3-slot ring runs two k-tiles ahead, the 2-slot ring one
 
   int st = 0, tile = rb, nowait = 0, j = 0;
   if constexpr (PP) {   // k-tile 0 must be visible before the first read phase
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 #define K_STEP()                                                                                            \
   {                                                                                                         \
     if (nowait > 0) --nowait;                                                                               \
-    else if (j + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                 \
+    else if (V2_NST == 3 && j + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
     __builtin_amdgcn_s_barrier();                                                                           \
     const bool do_pf = pf_j < total;                                                                        \
@@ -222,11 +239,12 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
     MFMA_CHUNK(2)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (do_pf) { GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w); GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024); } \
+    if constexpr (NW == 4) { if (do_pf) { GLDS16(sw2 + pko, pfb + V2_A_BYTES + lds_w + 2048); GLDS16(sw3 + pko, pfb + V2_A_BYTES + lds_w + 3072); } } \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (ni4) { MFMA_CHUNK(3) }                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (do_pf) {   /* advance the prefetch cursor (source pointers of the next output tile when the k loop wraps) */ \
-      pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                   \
+      pf_st = pf_st == V2_NST - 1 ? 0 : pf_st + 1;                                                          \
       ++pf_j;                                                                                               \
       if (++pf_kt == nk) {                                                                                  \
         pf_kt = 0;                                                                                          \
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
         if (pf_j < total) SET_TILE_SRC(pf_tile);                                                            \
       }                                                                                                     \
     }                                                                                                       \
-    st = st == 2 ? 0 : st + 1;                                                                              \
+    st = st == V2_NST - 1 ? 0 : st + 1;                                                                     \
     ++j;                                                                                                    \
   }
 
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 #pragma unroll 1
       for (int kt = 0; kt < nk; ++kt) K_STEP()
     }
-    const int st_cur = st == 0 ? 2 : st - 1;   // ring slot of the k-tile just consumed: free until the DMA of iteration j+2
+    const int st_cur = st == 0 ? V2_NST - 1 : st - 1;   // ring slot of the k-tile just consumed: free until the next DMA into it (issued after the next barrier)
 
     if (a.debug == 2) { tile += G; continue; }
     // ---- tile boundary.  MFMA layout: lane holds C[m = ..+l15][n = ..+4g .. +3].  Each wave transposes 16 x 64
@@ -362,8 +380,8 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of j, j+1 (already issued) and every store issued so far
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; the next two k-tiles landed for all
-        nowait = 2;
+        __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; the k-tiles already issued (two, or one with the 2-slot ring) landed for all
+        nowait = V2_NST - 1;
       }
       float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
       const int nb_ = n0 + wn * swid;
@@ -588,6 +606,11 @@ __global__ __launch_bounds__(512) void gemm_v2_kernel(GemmV2Args a) {
 }
 
 static int g_num_cus = 0;
+static int g_nw_override = 0;   // testing / A-B aid: 4 or 8 forces the workgroup flavour of every later launch, 0 = automatic
+extern "C" int mmsa_debug_gemm_flavour(int waves_per_workgroup) {
+  g_nw_override = (waves_per_workgroup == 4 || waves_per_workgroup == 8) ? waves_per_workgroup : 0;
+  return MMSA_OK;
+}
 
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
 int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
@@ -607,7 +630,14 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
-  a.nbm = cdiv(M, V2_BM);
+  // workgroup flavour: 4-wave 128-row tiles, two workgroups per CU (epilogue of one under the k-loop of the other), for the
+  // shapes whose tiles are short-lived (few k-tiles); 8-wave 256-row ping-pong tiles otherwise.  MMSA_GEMM_NW = 4 / 8 forces one
+  // (A/B timing); MMSA_GEMM_NW4_MAXK moves the threshold.
+  static const int nw_force = getenv("MMSA_GEMM_NW") ? atoi(getenv("MMSA_GEMM_NW")) : 0;
+  static const int nw4_maxk = getenv("MMSA_GEMM_NW4_MAXK") ? atoi(getenv("MMSA_GEMM_NW4_MAXK")) : 512;
+  const int nw = g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
+  const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
+  a.nbm = cdiv(M, bm);
   a.bn = V2_BN;
   a.nbn = cdiv(N, V2_BN);
   a.ntiles = a.nbm * a.nbn * batch;
@@ -623,8 +653,9 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (getenv("MMSA_GEMM_MAX_GRID")) g_num_cus = atoi(getenv("MMSA_GEMM_MAX_GRID"));   // experiment: leave CUs to concurrent streams
 #define V2_ATTR(GEN_, ACT_)                                                                                                   \
-  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE); \
-  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_NST * V2_STAGE);
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8)); \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1)
 #undef V2_ATTR
   }
@@ -634,7 +665,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     static const bool no96 = getenv("MMSA_GEMM_NO96") != nullptr;   // A/B aid
     const int nbn96 = cdiv(N, 96);
     const long t96 = (long)a.nbm * nbn96 * batch;
-    const double c128 = (double)cdiv(a.ntiles, g_num_cus), c96 = 0.75 * (double)cdiv(t96, g_num_cus);
+    const int slots = g_num_cus * wg_per_cu;
+    const double c128 = (double)cdiv(a.ntiles, slots), c96 = 0.75 * (double)cdiv(t96, slots);
     // same number of column tiles -> nothing to gain from narrower ones (ragged last tile aside)
     if (!no96 && c96 < c128 - 1e-9) {
       a.bn = 96;
@@ -642,13 +674,14 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
       a.ntiles = (int)t96;
     }
   }
-  const int grid = a.ntiles < g_num_cus ? a.ntiles : g_num_cus;   // one resident workgroup per CU (144 KiB LDS each)
+  const int grid = a.ntiles < g_num_cus * wg_per_cu ? a.ntiles : g_num_cus * wg_per_cu;   // resident workgroups: one per CU (144 KiB LDS) or two (64 KiB each)
   const bool gen = out_mode != 0 || resid_mod > 0;
   static const bool pp = getenv("MMSA_GEMM_PP") ? atoi(getenv("MMSA_GEMM_PP")) != 0 : true;   // 0: every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \
   do {                                                                                                                     \
-    if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true>), dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a);   \
-    else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false>), dim3(grid), dim3(512), V2_NST * V2_STAGE, stream, a);    \
+    if (nw == 4) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 4>), dim3(grid), dim3(256), V2_LDS_BYTES(4), stream, a);     \
+    else if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);     \
+    else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);            \
   } while (0)
   if (gen) {
     V2_LAUNCH(true, -1);

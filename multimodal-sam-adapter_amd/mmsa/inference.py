@@ -85,7 +85,7 @@ def slide_inference(backbone, head, img, crop_size, stride, max_batch=8):
     jobs = [(b, box) for box in boxes for b in range(B)]
     for s in range(0, len(jobs), max_batch):
         chunk = jobs[s:s + max_batch]
-        crops = torch.stack([img[b, :, y1:y2, x1:x2] for b, (y1, x1, y2, x2) in chunk], 0).contiguous()
+        crops = _crops(img, chunk, crop_size)
         feats, _ = backbone(crops)
         lg = head(feats)                                   # [n, classes, hc/4, wc/4]
         if preds is None:
@@ -97,6 +97,70 @@ def slide_inference(backbone, head, img, crop_size, stride, max_batch=8):
         raise RuntimeError("mmsa.slide_inference: windows do not cover the image")   # ED:220
     lib.call("mmsa_div_count_nchw", preds.data_ptr(), count.data_ptr(), B, preds.shape[1], H * W, ops._stream())
     return preds
+
+
+def _crops(img, chunk, crop_size, out=None):
+    """ED:205-212 for a batch of windows: one HIP launch (mmsa_crop_batch_nchw), no ATen slicing / stacking."""
+    import ctypes
+    n = len(chunk)
+    if out is None:
+        out = torch.empty(n, img.shape[1], crop_size[0], crop_size[1], device=img.device)
+    tab = (ctypes.c_int * (3 * n))(*[v for b, (y1, x1, _, _) in chunk for v in (b, y1, x1)])
+    lib.call("mmsa_crop_batch_nchw", img.data_ptr(), img.shape[0], img.shape[1], img.shape[2], img.shape[3], tab, n, out.data_ptr(),
+             crop_size[0], crop_size[1], ops._stream())
+    return out
+
+
+@_on_device
+@torch.no_grad()
+def slide_class_map(backbone, head, img, crop_size, stride, max_batch=8):
+    """`simple_test` of a sliding-window frame (ED:191-234 + ED:449,477) -> uint8 class map [B, H, W], without the
+    [B, classes, H, W] logits canvas: every window's logits stay at head resolution and ONE kernel (mmsa_slide_argmax) resizes,
+    sums the overlapping windows in window order, divides by the count and takes the argmax -- the same additions in the same order
+    as slide_inference + argmax_map, so the same class map bit for bit.  All windows of the frame go through the encoder in
+    batches of `max_batch`; with static shapes the whole function is HIP-graph capturable (no host sync inside)."""
+    import ctypes
+    _check(img)
+    img = img.contiguous()
+    B, _, H, W = img.shape
+    if H < crop_size[0] or W < crop_size[1]:
+        raise RuntimeError("mmsa.slide_class_map: the image must be at least as large as the crop")
+    boxes = crop_boxes(H, W, crop_size, stride)
+    _pair(backbone, head)
+    jobs = [(b, box) for box in boxes for b in range(B)]      # the accumulation order of slide_inference
+    if len(jobs) > 64:
+        raise RuntimeError("mmsa.slide_class_map: at most 64 windows per call")
+    lgs = []
+    for s in range(0, len(jobs), max_batch):
+        chunk = jobs[s:s + max_batch]
+        feats, _ = backbone(_crops(img, chunk, crop_size))
+        lgs.append(head(feats))
+    lg = lgs[0] if len(lgs) == 1 else torch.cat(lgs, 0)
+    n = len(jobs)
+    tab = (ctypes.c_int * (3 * n))(*[v for b, (y1, x1, _, _) in jobs for v in (b, y1, x1)])
+    out = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
+    unc = torch.zeros(1, dtype=torch.int32, device=img.device)
+    lib.call("mmsa_slide_argmax", lg.data_ptr(), n, lg.shape[1], lg.shape[2], lg.shape[3], tab, out.data_ptr(), B, H, W,
+             crop_size[0], crop_size[1], unc.data_ptr(), ops._stream())
+    return out, unc          # unc[0] != 0 <=> some pixel is not covered (ED:220); checked by the caller outside a capture
+
+
+@_on_device
+@torch.no_grad()
+def whole_class_map(backbone, head, img):
+    """Whole-image `simple_test`: resize x4 (bilinear, align_corners=False) + argmax fused (ED:90-94,449,477) -> uint8 [B, H, W]."""
+    import ctypes
+    _check(img)
+    _pair(backbone, head)
+    feats, _ = backbone(img)
+    lg = head(feats)
+    B, _, H, W = img.shape
+    tab = (ctypes.c_int * (3 * B))(*[v for b in range(B) for v in (b, 0, 0)])
+    out = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
+    unc = torch.zeros(1, dtype=torch.int32, device=img.device)
+    lib.call("mmsa_slide_argmax", lg.data_ptr(), B, lg.shape[1], lg.shape[2], lg.shape[3], tab, out.data_ptr(), B, H, W, H, W,
+             unc.data_ptr(), ops._stream())
+    return out
 
 
 @_on_device

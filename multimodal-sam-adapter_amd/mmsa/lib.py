@@ -32,6 +32,7 @@ SIGNATURES = {
     "mmsa_version": [],
     "mmsa_last_error": [],
     "mmsa_debug_poison_lds": [ctypes.c_uint, P],
+    "mmsa_debug_gemm_flavour": [I],
     "mmsa_event_create": [POINTER(c_void_p)],
     "mmsa_event_record": [P, P],
     "mmsa_event_elapsed_ms": [P, P, POINTER(c_float)],
@@ -69,6 +70,8 @@ SIGNATURES = {
     "mmsa_bilinear_accum_nchw": [P, L, I, I, I, I, P, I, I, I, I, I, I, P, I, P],
     "mmsa_div_count_nchw": [P, P, I, I, L, P],
     "mmsa_argmax_nchw": [P, P, I, I, L, P],
+    "mmsa_crop_batch_nchw": [P, I, I, I, I, P, I, P, I, I, P],
+    "mmsa_slide_argmax": [P, I, I, I, I, P, P, I, I, I, I, I, P, P],
 }
 _RESTYPES = {"mmsa_last_error": c_char_p}
 
@@ -87,7 +90,7 @@ POISON_LDS = os.environ.get("MMSA_DEBUG_POISON_LDS") == "1"   # testing aid: NaN
 
 def call(name, *args):
     """Invoke an entry point; raise RuntimeError(mmsa_last_error()) on a non-zero return code."""
-    if POISON_LDS and not name.startswith(("mmsa_event", "mmsa_debug")):
+    if POISON_LDS and not name.startswith(("mmsa_event", "mmsa_debug")) and args:
         _lib.mmsa_debug_poison_lds(0x7FC07FC0, args[-1])   # the stream is the last argument of every launching entry point
     rc = getattr(_lib, name)(*args)
     if rc != 0:

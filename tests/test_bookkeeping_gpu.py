@@ -105,4 +105,8 @@ def test_rel_pos_gather_index_bit_exact_on_device(golden_dir):
     for (q, L) in ((14, 27), (64, 127), (14, 31), (20, 31), (16, 31), (32, 127)):
         tab = torch.from_numpy(g[f"rp_in_{q}_{L}"]).to(DEV)
         got = bb._rel_table(q, tab).cpu()
-        assert torch.equal(got, torch.from_numpy(g[f"rp_out_{q}_{L}"])), f"rel-pos table ({q}, {L})"
+        want = torch.from_numpy(g[f"rp_out_{q}_{L}"])
+        if L == 2 * q - 1:      # pure integer gather: bit-exact
+            assert torch.equal(got, want), f"rel-pos table ({q}, {L})"
+        else:                   # table first resized by linear interpolation (IE:568-575; fp32 on the device): same rows to rounding
+            assert (got - want).abs().max() <= 2e-6 * want.abs().max(), f"rel-pos table ({q}, {L})"

@@ -99,3 +99,45 @@ def test_muses_frame_full_size_batching_invariance():
     # the top-left window alone covers rows < 56 and columns < 640: no averaging there
     alone = inf.encode_decode(m, h, frame[:, :, :1024, :1024].contiguous())
     assert_close(batched[:, :, :56, :640], alone[:, :, :56, :640], tol=1e-6, what="singly covered region equals that window's logits")
+
+
+def test_fused_class_maps_equal_the_unfused_path(models):
+    """slide_class_map / whole_class_map (crops by one kernel, no [B, classes, H, W] canvas, resize + overlap sum + count division +
+    argmax in one pass) return the class map of slide_inference / encode_decode + argmax_map bit for bit, incl. a 2-image batch
+    and windows that overlap 1, 2 and 4 times."""
+    import mmsa.inference as inf
+    cfg, orc, horc, m, h = models
+    g = torch.Generator().manual_seed(9)
+    frame = torch.randn(2, 6, 320, 400, generator=g)
+    frame[:, 3:] = (torch.rand(2, 3, 320, 400, generator=g) < 0.05).float() * torch.rand(2, 3, 320, 400, generator=g)
+    frame = frame.to(DEV)
+    for stride, mb in (((170, 170), 3), ((256, 256), 8), ((64, 144), 5)):
+        want = inf.argmax_map(inf.slide_inference(m, h, frame, (256, 256), stride, max_batch=mb))
+        if len(inf.crop_boxes(320, 400, (256, 256), stride)) * 2 > 64:
+            continue
+        got, unc = inf.slide_class_map(m, h, frame, (256, 256), stride, max_batch=mb)
+        assert int(unc.item()) == 0
+        assert got.dtype == torch.uint8 and torch.equal(got, want), f"stride {stride}"
+    x = make_input(cfg, batch=2, seed=4).to(DEV)
+    assert torch.equal(inf.whole_class_map(m, h, x), inf.argmax_map(inf.encode_decode(m, h, x)))
+    # a window list that leaves pixels uncovered is reported (ED:220), not silently mapped to class 0
+    from mmsa import lib, ops
+    import ctypes
+    lg = torch.randn(1, 7, 16, 16, device=DEV)
+    out = torch.zeros(1, 80, 80, dtype=torch.uint8, device=DEV)
+    unc = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib.call("mmsa_slide_argmax", lg.data_ptr(), 1, 7, 16, 16, (ctypes.c_int * 3)(0, 0, 0), out.data_ptr(), 1, 80, 80, 64, 64, unc.data_ptr(), ops._stream())
+    assert int(unc.item()) == 80 * 80 - 64 * 64
+    with pytest.raises(RuntimeError, match="outside"):
+        lib.call("mmsa_slide_argmax", lg.data_ptr(), 1, 7, 16, 16, (ctypes.c_int * 3)(0, 40, 0), out.data_ptr(), 1, 80, 80, 64, 64, unc.data_ptr(), ops._stream())
+
+
+def test_crop_batch_kernel():
+    import ctypes
+    import mmsa.inference as inf
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(3, 6, 70, 90, generator=g).to(DEV)
+    chunk = [(2, (3, 5, 35, 69)), (0, (38, 26, 70, 90)), (1, (0, 0, 32, 64))]
+    got = inf._crops(img, chunk, (32, 64))
+    want = torch.stack([img[b, :, y1:y2, x1:x2] for b, (y1, x1, y2, x2) in chunk], 0)
+    assert torch.equal(got, want)

@@ -326,3 +326,45 @@ def test_dwconv7_layernorm_fused(ops, C, H, W):
     again = ops.alloc_planes(nimg * H * W, C, DEV)
     ops.dwconv7_ln(x.reshape(nimg * H * W, C).to(DEV), wt, bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, again, nimg, H, W, imgs_per_group=ipg)
     assert torch.equal(again.p, outp.p)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [
+    (16384, 1536, 384, "Pgelu"),     # ConvNeXt stage-2 pw1 (the shape the 4-wave flavour was built for)
+    (9000, 1100, 160, "P"),
+    (70000, 200, 96, "C"),
+    (5000, 300, 64, "Cres"),
+    (700, 130, 1024, "Cres"),        # deep K through the 2-slot ring
+    (33000, 130, 32, "C"),           # one k-tile per tile
+])
+def test_gemm_workgroup_flavours_agree_bitwise(ops, M, N, K, mode):
+    """The two workgroup flavours of the LDS-DMA GEMM (8 waves: 256-row ping-pong tiles, one workgroup per CU; 4 waves: 128-row
+    tiles, two workgroups per CU with a 2-slot ring) accumulate every output element over k in the same order: their results are
+    bit-identical, so which one a shape is routed to can never change a value.  Both against fp64 too."""
+    from mmsa import lib
+    a = torch.randn(M, K, generator=g(140)) * 0.5
+    w = torch.randn(N, K, generator=g(141)) / K ** 0.5
+    b = torch.randn(N, generator=g(142))
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    ref = ad.double() @ wd.double().t() + bd.double()
+    res = torch.randn(M, N, generator=g(143)).to(DEV) if mode == "Cres" else None
+    act = "gelu" if mode == "Pgelu" else "none"
+    if act == "gelu":
+        ref = F.gelu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    ap, pl = ops.split_planes(ad, kpad=K), ops.split_planes(wd)
+    got = {}
+    try:
+        for nw in (8, 4, 8, 4):
+            lib.call("mmsa_debug_gemm_flavour", nw)
+            out = torch.full((M, N), float("nan"), device=DEV) if mode[0] == "C" else None
+            outp = ops.alloc_planes(M, N, DEV) if mode[0] == "P" else None
+            ops.gemm(ap, pl, out, bias=bd, act=act, resid=res, out_planes=outp)
+            o = out if out is not None else planes_to_float(outp)
+            assert_close(o, ref.float(), tol=3e-5, what=f"flavour {nw}")
+            if nw in got:
+                assert torch.equal(got[nw], o)
+            got[nw] = o.clone()
+    finally:
+        lib.call("mmsa_debug_gemm_flavour", 0)
+    assert torch.equal(got[4], got[8]), "the 4-wave and the 8-wave flavour differ"
