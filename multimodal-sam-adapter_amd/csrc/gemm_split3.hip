@@ -288,6 +288,52 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream);
 
+// ---- tiny problems (CoordinateAttention's 1x1 convs on pooled maps, AM:187-201: M = B*(h+w) <= ~1000 rows, N or K of 8..48): a
+// 128 x 128 MFMA tile would be one or two workgroups walking K alone (64 us for M = 128, N = 48, K = 1536).  Here one wave owns
+// (row m, 8 output columns): lanes stride K with float4 loads of A and 8-byte loads of the weight planes (w = hi + lo, exact),
+// plain fp32 FMAs, a xor-shuffle reduction and the usual epilogue.  Same contract as the big kernels (fp32 A, fp32 C).
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a, int ncg) {
+  const int lane = threadIdx.x & 63;
+  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long per_b = (long)a.M * ncg;
+  const int bz = blockIdx.y;
+  if (wv >= per_b) return;
+  const int m = (int)(wv / ncg), n0 = (int)(wv - (long)m * ncg) * 8;
+  const float* A = a.A + (long)bz * a.strideA + (long)m * a.lda;
+  const unsigned short* Wp = a.Wp + (long)bz * a.strideW;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int k = lane * 4; k < a.K; k += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(A + k);
+    const int ko = ilv(k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = min(n0 + j, a.N - 1);
+      const unsigned short* wr = Wp + (long)n * 2 * a.K + ko;
+      const uint2 h = *reinterpret_cast<const uint2*>(wr), l = *reinterpret_cast<const uint2*>(wr + 32);
+      const float w0 = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+      const float w1 = __uint_as_float(h.x & 0xFFFF0000u) + __uint_as_float(l.x & 0xFFFF0000u);
+      const float w2 = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+      const float w3 = __uint_as_float(h.y & 0xFFFF0000u) + __uint_as_float(l.y & 0xFFFF0000u);
+      acc[j] = fmaf(x.x, w0, fmaf(x.y, w1, fmaf(x.z, w2, fmaf(x.w, w3, acc[j]))));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = wave_sum(acc[j]);
+  if (lane < 8 && n0 + lane < a.N) {
+    const int n = n0 + lane;
+    float v = acc[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v = lane == j ? acc[j] : v;
+    if (a.bias) v += a.bias[(long)bz * a.strideBias + n];
+    v = apply_act(v, a.act) * (a.colscale ? a.colscale[(long)bz * a.strideBias + n] * a.alpha : a.alpha);
+    if (a.resid) v += a.beta * a.resid[(long)bz * a.strideR + (long)m * a.ldr + n];
+    a.C[(long)bz * a.strideC + (long)m * a.ldc + n] = v;
+  }
+}
+
+
 // C-ABI entry: see include/mmsa.h for the contract.
 extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long lda, long strideA,
                                 const unsigned short* Wp, long strideW,
@@ -336,6 +382,15 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   // one 128-column strip with many rows and a deep K (ConvNeXt stage-0 pw2: N = 96, K = 384): the 128-row tiles of this kernel
   // balance better over the CUs than 256-row tiles (61 vs 75 us at M = 131072; at K <= 192 the 256-row kernel is faster)
   const bool narrow = N <= 128 && M >= 65536 && K >= 384;
+  static const bool no_tiny = getenv("MMSA_GEMM_NO_TINY") != nullptr;   // A/B aid
+  // routed by the problem's small dimension, NOT by the row count (rows scale with the image batch: a batch-dependent choice of
+  // kernel would make results depend on how images are batched); M <= 16384 covers 32 images of the largest pooled map
+  if (!ap && !Cp && out_mode == 0 && resid_mod <= 0 && (N <= 64 || K <= 64) && M <= 16384 && !no_tiny) {
+    const int ncg = cdiv(N, 8);
+    hipLaunchKernelGGL(gemm_tiny_kernel, dim3(cdiv((long)M * ncg, 4), batch), dim3(256), 0, stream, a, ncg);
+    MMSA_CHECK_LAUNCH("gemm_split3(tiny)");
+    return MMSA_OK;
+  }
   if (ap && M >= 128 && !force_v1 && !narrow)
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,

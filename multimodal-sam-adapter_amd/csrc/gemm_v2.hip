@@ -630,11 +630,12 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
-  // workgroup flavour: 4-wave 128-row tiles, two workgroups per CU (epilogue of one under the k-loop of the other), for the
-  // shapes whose tiles are short-lived (few k-tiles); 8-wave 256-row ping-pong tiles otherwise.  MMSA_GEMM_NW = 4 / 8 forces one
-  // (A/B timing); MMSA_GEMM_NW4_MAXK moves the threshold.
+  // workgroup flavour: 8-wave 256-row ping-pong tiles by default.  The 4-wave flavour (128-row tiles, two workgroups per CU: the
+  // epilogue of one under the k-loop of the other) measured no faster on any of the model's shapes (profiles/r02_gemm_flavours.txt:
+  // its 2-slot ring gives up more in the k-loop than the overlap returns), so it is OFF unless asked for: MMSA_GEMM_NW = 4 / 8
+  // forces one, MMSA_GEMM_NW4_MAXK = k routes shapes with K <= k to it.  Results are bit-identical either way.
   static const int nw_force = getenv("MMSA_GEMM_NW") ? atoi(getenv("MMSA_GEMM_NW")) : 0;
-  static const int nw4_maxk = getenv("MMSA_GEMM_NW4_MAXK") ? atoi(getenv("MMSA_GEMM_NW4_MAXK")) : 512;
+  static const int nw4_maxk = getenv("MMSA_GEMM_NW4_MAXK") ? atoi(getenv("MMSA_GEMM_NW4_MAXK")) : 0;
   const int nw = g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
   const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
   a.nbm = cdiv(M, bm);

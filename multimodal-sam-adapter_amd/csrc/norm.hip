@@ -7,6 +7,7 @@
 //                    nn.LayerNorm(H*W) AM:241,265; F.normalize over HW AM:100-101; avg-pool AM:159).
 //   lnhw_apply     : GFFM LayerNorm over the spatial axis + FFRM recalibration, fused apply pass.
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // RPW = rows per wave: 1 (64 lanes x NV float4 per row) or 2 (C <= 128: two rows per wave, 32 lanes each -- with one row per
@@ -19,72 +20,84 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap) {
   constexpr int LPR = 64 / RPW;                       // lanes per row
   const int lane = threadIdx.x & (LPR - 1);
-  const int row = blockIdx.x * (4 * RPW) + (threadIdx.x / LPR);
+  // A wave (or half wave) walks rows slot, slot + nslots, ... with the NEXT row's loads in flight while the current row is
+  // reduced and stored: one row per wave made every wave of the launch load, then reduce, then store in lockstep (read burst,
+  // then write burst: 2.4 TB/s on a [8192, 1024] map); streamed, loads and stores of different rows overlap.
+  const int nslots = gridDim.x * (4 * RPW);
+  int row = blockIdx.x * (4 * RPW) + (threadIdx.x / LPR);
   if (row >= rows) return;
-  // row groups (the two ConvNeXt streams stacked along the rows): group g = row / group_rows has its own weight /
-  // bias vectors (w + g * w_gstride) and writes at column offset g * y_gcol; y_wrap: output row = row % group_rows
-  const int grp = group_rows > 0 ? row / group_rows : 0;
-  w += (long)grp * w_gstride;
-  b += (long)grp * w_gstride;
-  const float* xr = x + (long)row * ldx;
-  float4 v[NV];
-  float s = 0.f;
+  float4 v[NV], vn[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + LPR * i) * 4;
-    if (c < C) {
-      v[i] = *reinterpret_cast<const float4*>(xr + c);
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    vn[i] = c < C ? *reinterpret_cast<const float4*>(x + (long)row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const float mean = (RPW == 1 ? wave_sum(s) : half_wave_sum(s)) / (float)C;
-  float q = 0.f;
+  for (; row < rows; row += nslots) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (lane + LPR * i) * 4;
-    if (c < C) {
-      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-  }
-  const float rstd = 1.0f / sqrtf((RPW == 1 ? wave_sum(q) : half_wave_sum(q)) / (float)C + eps);
-  long orow = (group_rows > 0 && y_wrap) ? row - grp * group_rows : row;
-  long ocol = (long)grp * y_gcol;
-  if (map_mode == 1) {  // 2x2 patchify: token (b,h,w) -> row (b,h/2,w/2), column block (h&1)*2+(w&1)
-    const int ww = row % map_W;
-    const int t = row / map_W;
-    const int hh = t % map_H;
-    const int bb = t / map_H;
-    orow = ((long)bb * (map_H / 2) + (hh >> 1)) * (map_W / 2) + (ww >> 1);
-    ocol += (long)(((hh & 1) << 1) | (ww & 1)) * C;
-  }
-  float* yr = y ? y + orow * ldy + ocol : nullptr;
-  float* y2r = y2 ? y2 + (long)row * ldy2 : nullptr;
-  unsigned short* pr = yp ? yp + orow * ldp : nullptr;   // ilv planes row (ocol is a multiple of 32 when patchifying)
+    for (int i = 0; i < NV; ++i) v[i] = vn[i];
+    const int nrow = row + nslots;
+    if (nrow < rows) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (lane + LPR * i) * 4;
-    if (c < C) {
-      const float4 ww = *reinterpret_cast<const float4*>(w + c);
-      const float4 bb = *reinterpret_cast<const float4*>(b + c);
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
-      o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
-      o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
-      o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
-      if (yr) *reinterpret_cast<float4*>(yr + c) = o;
-      if (pr) {
-        uint2 hh, ll;
-        split4(o, hh, ll);
-        unsigned short* q_ = pr + ilv((int)ocol + c);
-        *reinterpret_cast<uint2*>(q_) = hh;
-        *reinterpret_cast<uint2*>(q_ + 32) = ll;
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + LPR * i) * 4;
+        if (c < C) vn[i] = *reinterpret_cast<const float4*>(x + (long)nrow * ldx + c);
       }
-      if (y2r) {
-        o.x += v[i].x; o.y += v[i].y; o.z += v[i].z; o.w += v[i].w;
-        *reinterpret_cast<float4*>(y2r + c) = o;
+    }
+    // row groups (the two ConvNeXt streams stacked along the rows): group g = row / group_rows has its own weight /
+    // bias vectors (w + g * w_gstride) and writes at column offset g * y_gcol; y_wrap: output row = row % group_rows
+    const int grp = group_rows > 0 ? row / group_rows : 0;
+    const float* wg = w + (long)grp * w_gstride;
+    const float* bg = b + (long)grp * w_gstride;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);   // lanes beyond C hold zeros
+    const float mean = (RPW == 1 ? wave_sum(s) : half_wave_sum(s)) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + LPR * i) * 4;
+      if (c < C) {
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+    const float rstd = 1.0f / sqrtf((RPW == 1 ? wave_sum(q) : half_wave_sum(q)) / (float)C + eps);
+    long orow = (group_rows > 0 && y_wrap) ? row - grp * group_rows : row;
+    long ocol = (long)grp * y_gcol;
+    if (map_mode == 1) {  // 2x2 patchify: token (b,h,w) -> row (b,h/2,w/2), column block (h&1)*2+(w&1)
+      const int ww = row % map_W;
+      const int t = row / map_W;
+      const int hh = t % map_H;
+      const int bb = t / map_H;
+      orow = ((long)bb * (map_H / 2) + (hh >> 1)) * (map_W / 2) + (ww >> 1);
+      ocol += (long)(((hh & 1) << 1) | (ww & 1)) * C;
+    }
+    float* yr = y ? y + orow * ldy + ocol : nullptr;
+    float* y2r = y2 ? y2 + (long)row * ldy2 : nullptr;
+    unsigned short* pr = yp ? yp + orow * ldp : nullptr;   // ilv planes row (ocol is a multiple of 32 when patchifying)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + LPR * i) * 4;
+      if (c < C) {
+        const float4 ww = *reinterpret_cast<const float4*>(wg + c);
+        const float4 bb = *reinterpret_cast<const float4*>(bg + c);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+        o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+        o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+        o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+        if (yr) *reinterpret_cast<float4*>(yr + c) = o;
+        if (pr) {
+          uint2 hh, ll;
+          split4(o, hh, ll);
+          unsigned short* q_ = pr + ilv((int)ocol + c);
+          *reinterpret_cast<uint2*>(q_) = hh;
+          *reinterpret_cast<uint2*>(q_ + 32) = ll;
+        }
+        if (y2r) {
+          o.x += v[i].x; o.y += v[i].y; o.z += v[i].z; o.w += v[i].w;
+          *reinterpret_cast<float4*>(y2r + c) = o;
+        }
       }
     }
   }
@@ -107,7 +120,10 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
                  "layernorm_rows: bad row grouping");
   MMSA_CHECK_ARG(group_rows == 0 || map_mode == 0 || (group_rows % (map_H * map_W) == 0 && y_wrap == 0 && y_gcol == 0), "layernorm_rows: grouping with patchify needs whole images per group");
   const int rpw = C <= 128 ? 2 : 1;
-  dim3 grid(cdiv(rows, 4 * rpw)), block(256);
+  // rows per wave slot: 4 once there are enough rows to keep every CU busy that way (streamed: see the kernel); MMSA_LN_ROWS overrides (A/B timing)
+  static const int ln_rows = getenv("MMSA_LN_ROWS") ? atoi(getenv("MMSA_LN_ROWS")) : 0;
+  const int per_slot = ln_rows > 0 ? ln_rows : (rows >= 8192 ? 4 : rows >= 4096 ? 2 : 1);
+  dim3 grid(cdiv(rows, 4 * rpw * per_slot)), block(256);
 #define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap)
   if (C <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<1, 2>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap);
   else if (C <= 256) LN_LAUNCH(1);
