@@ -16,11 +16,15 @@
  *  - return 0 on success, negative on error; `mmsa_last_error()` returns a thread-local message.  Shapes,
  *    alignment and strides are validated on the host BEFORE anything is launched.
  *  - activations are fp32, token-major / NHWC: a [rows, channels] matrix with a row stride `ld*` in elements.
- *  - GEMM weights -- and the intermediate activations that feed GEMMs / attention -- are bf16 hi/lo "planes"
- *    ("split3": x = hi + lo, three MFMA products, fp32 accumulate) in the INTERLEAVED layout: row r of a [rows, K]
- *    matrix (K padded to a multiple of 32) is 2K uint16: per 32-wide k-block the 32 hi values then the 32 lo values
- *    (one 128-byte line per row per MFMA k-step).  Plane pointers are 128-byte aligned, row strides multiples of 64.
- *    `mmsa_split_planes` converts fp32; producer kernels can emit planes directly.
+ *  - GEMM weights -- and the intermediate activations that feed GEMMs / attention -- are operand "planes": row r of a
+ *    [rows, K] matrix (K padded to a multiple of 32) is 2K uint16 = one 128-byte line per 32-wide k-block (everything an MFMA
+ *    k-step needs from that row).  Plane pointers are 128-byte aligned, row strides multiples of 64.  Two formats:
+ *      MMSA_FMT_B3  bf16 hi/lo ("split3": x = hi + lo, three bf16 MFMA products, fp32 accumulate): the 32 hi values, then the 32 lo values;
+ *      MMSA_FMT_H8  fp16 hi + e5m2 cross-term bytes (x = hi + lo; hi.hi on the fp16 MFMA, both cross terms of two k-blocks on
+ *                   one block-scaled fp8 MFMA at twice the rate: same precision class, 2/3 of the matrix-pipe time): 32 fp16 hi
+ *                   values, then four 16-byte chunks, chunk g = 8 bytes e5m2(lo * 2^11) + 8 bytes e5m2(hi) of k = 8g..8g+7 for an
+ *                   ACTIVATION (A operand) row, the two halves swapped for a WEIGHT (W operand) row.  |x| is clamped to 57344.
+ *    `mmsa_split_planes` converts fp32; producer kernels emit either format directly (their `*_fmt` argument).
  */
 #ifndef MMSA_H
 #define MMSA_H
@@ -50,6 +54,9 @@ enum { MMSA_ACT_NONE = 0, MMSA_ACT_GELU = 1, MMSA_ACT_RELU = 2, MMSA_ACT_RELU6 =
 
 /* scalar type codes of the dtype-dispatched entry points (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF) */
 enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
+
+/* operand-plane formats (see Conventions) */
+enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
 
 /* --- reference native ops -----------------------------------------------------------------------------------
  * ms_deform_attn_forward (vision.cpp:14 -> ms_deform_attn.h:20-39 -> cuda/ms_deform_attn_cuda.cu:20-80).
@@ -92,16 +99,19 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * ops/modules/ms_deform_attn.py:103,107-110,129; BK:324.
  * A is EITHER fp32 (`A`, split to hi/lo while staged) OR interleaved activation planes (`Ap`, written by the
  * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
- * The result goes to fp32 `C`, to interleaved planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both. */
+ * The result goes to fp32 `C`, to planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both.
+ * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`. */
 int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      const uint16_t* Wp, long strideW,
                      const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,
                      long strideR, int resid_mod, float beta, float* C, long ldc, long strideC,
                      uint16_t* Cp, long ldcp, long strideCp, int M, int N, int K,
-                     int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, mmsa_stream_t stream);
+                     int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt,
+                     mmsa_stream_t stream);
 
-/* fp32 [rows, cols] (row stride ld) -> interleaved planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0). */
-int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes,
+/* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
+ * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows. */
+int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes, int kind,
                       mmsa_stream_t stream);
 
 /* --- attention (IE:465-501 incl. window_partition/unpartition IE:504-551 and rel-pos IE:587-623) -------------
@@ -112,7 +122,7 @@ int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const floa
 /* same with qkv [.., 2*3D], qkv_bias [2*3D] and the output [.., 2*D] as interleaved planes (strides in uint16) */
 int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const float* rp,
                           uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim,
-                          int window_size, float scale, mmsa_stream_t stream);
+                          int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */, mmsa_stream_t stream);
 
 /* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
  * get_rel_pos(...)  (IE:554-584), (KH,KW,QS) = (ws,ws,ws) for windowed blocks or (H,W,max) for global ones. */
@@ -132,7 +142,7 @@ int mmsa_relpos_bias_planes(const uint16_t* qkv_planes, long ldq, const float* R
 int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps, float* y, long ldy,
                         float* y2, long ldy2, uint16_t* y_planes, long ldp /* optional interleaved planes of y */,
                         int rows, int C, int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol,
-                        int y_wrap, mmsa_stream_t stream);
+                        int y_wrap, int plane_fmt /* MMSA_FMT_* of y_planes */, mmsa_stream_t stream);
 
 /* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
 int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C, double* out,
@@ -193,7 +203,7 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
  *     H <= 64 and a multiple of 4, head_dim 64.  No mmsa_relpos_bias pass. --- */
 int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const uint16_t* relpos_planes,
                                  uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim, float scale,
-                                 mmsa_stream_t stream);
+                                 int out_fmt /* MMSA_FMT_* of out_planes */, mmsa_stream_t stream);
 
 /* --- windowed attention with the rel-pos bias fused (Block.forward IE:382-423 on a window_size > 0 block: window_partition ->
  *     Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 -> window_unpartition).  qkv / bias / out as in
@@ -203,7 +213,8 @@ int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uin
  *     0 elsewhere (a constant of the window size).  head_dim 64, window_size <= 14.  No mmsa_relpos_bias pass. --- */
 int mmsa_window_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes,
                                  const uint16_t* relpos_planes, const uint16_t* selector, uint16_t* out_planes, long ldo, int B, int H, int W,
-                                 int heads, int head_dim, int window_size, float scale, mmsa_stream_t stream);
+                                 int heads, int head_dim, int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
+                                 mmsa_stream_t stream);
 
 /* --- Segformer decode head (segmentation/mmseg_custom/models/decode_heads/segformer_head.py:47-66; the 1x1 convs are
  *     mmsa_gemm_split3 calls).  nchw_to_planes: backbone map [B,C,HW] fp32 (image b at b*strideB) -> interleaved planes

@@ -28,6 +28,7 @@ struct AttnArgs {
   const unsigned short* qp;      // ilv planes form of qkv (PL kernels), row stride ldq (bf16 units, >= 2*3D)
   const unsigned short* bp;      // ilv planes form of qkv_bias [2*3D]
   unsigned short* op;            // ilv planes output (PL kernels), row stride ldo (>= 2*D)
+  int ofmt;                      // format of the planes output (common.h): bf16 hi/lo, or h8 for an h8 proj GEMM
   const float* rp;               // [B, heads, T, KH+KW] rel-pos bias terms (relpos kernel below)
   const unsigned short* relg;    // REL kernels: planes of a [256, 64] matrix, rows 0..2KH-2 = rel_pos_h, rows 128..128+2KW-2 = rel_pos_w
   float* out; long ldo;          // [B*T, D], channel = head*HD + c (IE:498)
@@ -455,11 +456,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       for (int d = 0; d < DT; ++d) {
         const float4 v = make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv);
         if constexpr (PL) {
-          uint2 hh, ll;
-          split4(v, hh, ll);
-          unsigned short* q_ = a.op + ((long)b * T + tq) * a.ldo + ilv(head * HD + 4 * G + 16 * d);
-          *reinterpret_cast<uint2*>(q_) = hh;
-          *reinterpret_cast<uint2*>(q_ + 32) = ll;
+          store_planes4(a.op + ((long)b * T + tq) * a.ldo, head * HD + 4 * G + 16 * d, v, a.ofmt);
         } else {
           *reinterpret_cast<float4*>(a.out + oo + 16 * d) = v;
         }
@@ -539,13 +536,14 @@ extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias,
 // planes form: qkv, qkv_bias and the output are bf16 hi/lo planes (same layouts, strides in elements)
 extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p, const float* rp,
                                      unsigned short* out_p, long ldo, int B, int H, int W,
-                                     int heads, int head_dim, int window_size, float scale, hipStream_t stream) {
+                                     int heads, int head_dim, int window_size, float scale, int out_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && rp && out_p, "attention_planes: null pointer");
+  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG((heads * head_dim) % 32 == 0, "attention_planes: embed dim must be a multiple of 32");
   AttnArgs a = {};
-  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt;
   return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, true, stream);
 }
 
@@ -553,13 +551,14 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, cons
 // of 4, head_dim 64.  relpos_planes: interleaved planes of a [256, 64] matrix, rows 0..2H-2 = rel_pos_h, 128..128+2W-2 = rel_pos_w
 extern "C" int mmsa_global_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p,
                                             const unsigned short* relpos_planes, unsigned short* out_p, long ldo, int B, int H, int W,
-                                            int heads, int head_dim, float scale, hipStream_t stream) {
+                                            int heads, int head_dim, float scale, int out_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && relpos_planes && out_p, "global_attention_planes: null pointer");
+  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "global_attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)relpos_planes) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "global_attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG(head_dim == 64 && W == 64 && H <= 64 && (H % 4) == 0, "global_attention_planes: needs head_dim 64 and a W = 64, H <= 64 (multiple of 4) grid");
   AttnArgs a = {};
-  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt;
   return attention_launch(a, B, H, W, heads, head_dim, 0, scale, true, stream);
 }
 

@@ -96,6 +96,83 @@ __device__ __forceinline__ float wave_max(float v) {
 // was the measured limiter of the two-array layout).  Element k: hi at ilv(k), lo at ilv(k) + 32.
 __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k & 31); }
 
+// ---- "h8" planes: the second operand format of the GEMM (same 128-byte-per-k-block geometry as the bf16 hi/lo planes).
+// x = hi + lo with hi = fp16(x) (11 significant bits) and lo = x - hi (|lo| <= 2^-11 |x|).  The product is
+//   a.b ~= hi_a.hi_b  +  [ q(hi_a).q(lo_b) + q(lo_a).q(hi_b) ]
+// with the first term on the fp16 MFMA (v_mfma_f32_16x16x32_f16, exact products, fp32 accumulate) and BOTH cross terms of TWO
+// k-blocks on ONE block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4: 2x the bf16 rate), whose operands q(.) are e5m2
+// roundings (3 significant bits): the cross terms are 2^-12 of the product, so rounding them to 3 bits costs 2^-16 relative --
+// the precision of the bf16 hi/lo scheme at 2/3 of its matrix-pipe time (3 bf16 MFMAs per k-block -> 1 fp16 + 1/2 fp8 at double
+// rate = 2 units).  lo is stored scaled by 2^11 (so that it sits in the normal range of e5m2 whenever x does in fp16's); the
+// MFMA's block scale (e8m0 = 127 - 11 on one operand) undoes it.  Measured end to end on the CPU oracle with every ViT-block and
+// interaction Linear in this format (tools/precision_study.py): 2-4e-5 relative on f1..f4 (bf16 hi/lo: 0.5-1e-5; gate 1e-3).
+// Row r, k-block j (128 bytes): [32 x fp16 hi][4 chunks of 16 B: chunk g = 8 lo bytes + 8 q(hi) bytes of k = 8g .. 8g+7]
+// for ACTIVATIONS (A operand); WEIGHTS store the chunk as 8 q(hi) bytes + 8 lo bytes, so that for both operands the lane's 32
+// operand bytes of the fp8 MFMA are just the chunks of two consecutive k-blocks, and byte p of A always meets byte p of W with
+// the roles (lo, q(hi)) crossed.  Values are clamped to +-57344 (the largest e5m2 / a finite fp16) before the split.
+enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
+#define MMSA_H8_MAX 57344.0f
+#define MMSA_H8_LO_SCALE 2048.0f          // 2^11
+#define MMSA_H8_MFMA_SCALE 0x74747474     // e8m0 127 - 11 in every byte: the block scale that undoes MMSA_H8_LO_SCALE
+typedef __attribute__((ext_vector_type(2))) _Float16 mmsa_h2;
+
+// two floats -> hi (2 packed fp16), lo8 / qh8 (2 e5m2 bytes each, written into the low or high half of `lo8` / `qh8`)
+template <bool UPPER>
+__device__ __forceinline__ void h8_split2(float a, float b, unsigned& hi, unsigned& lo8, unsigned& qh8) {
+  a = __builtin_amdgcn_fmed3f(a, -MMSA_H8_MAX, MMSA_H8_MAX);
+  b = __builtin_amdgcn_fmed3f(b, -MMSA_H8_MAX, MMSA_H8_MAX);
+  const mmsa_f32x2 v = {a, b};
+  const mmsa_h2 h = __builtin_convertvector(v, mmsa_h2);            // round to nearest even
+  const mmsa_f32x2 hf = __builtin_convertvector(h, mmsa_f32x2);
+  const float la = (a - hf.x) * MMSA_H8_LO_SCALE, lb = (b - hf.y) * MMSA_H8_LO_SCALE;   // exact
+  hi = __builtin_bit_cast(unsigned, h);
+  lo8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(la, lb, (int)lo8, UPPER);
+  qh8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(hf.x, hf.y, (int)qh8, UPPER);
+}
+// four floats -> 4 fp16 (8 bytes), 4 lo bytes, 4 q(hi) bytes
+__device__ __forceinline__ void h8_split4(const float4 v, uint2& hi, unsigned& lo8, unsigned& qh8) {
+  lo8 = 0u; qh8 = 0u;
+  h8_split2<false>(v.x, v.y, hi.x, lo8, qh8);
+  h8_split2<true>(v.z, v.w, hi.y, lo8, qh8);
+}
+// byte offset, inside its row, of the 4-byte group holding the lo bytes of columns c .. c+3 (c % 4 == 0) of an ACTIVATION row;
+// the q(hi) bytes sit 8 bytes further
+__host__ __device__ __forceinline__ int h8_lo_off(int c) { return ((c >> 5) << 7) + 64 + (((c & 31) >> 3) << 4) + (c & 7); }
+
+// Store 4 consecutive columns c .. c+3 (c % 4 == 0) of a planes row in either format (row = start of the row, uint16 units).
+__device__ __forceinline__ void store_planes4(unsigned short* row, int c, const float4 v, int fmt) {
+  if (fmt == MMSA_FMT_H8) {
+    uint2 hi; unsigned lo8, qh8;
+    h8_split4(v, hi, lo8, qh8);
+    *reinterpret_cast<uint2*>(row + ilv(c)) = hi;
+    unsigned char* rb = reinterpret_cast<unsigned char*>(row) + h8_lo_off(c);
+    *reinterpret_cast<unsigned*>(rb) = lo8;
+    *reinterpret_cast<unsigned*>(rb + 8) = qh8;
+  } else {
+    uint2 hh, ll;
+    split4(v, hh, ll);
+    *reinterpret_cast<uint2*>(row + ilv(c)) = hh;
+    *reinterpret_cast<uint2*>(row + ilv(c) + 32) = ll;
+  }
+}
+
+// one element (ragged edges; rare)
+__device__ __forceinline__ void store_planes1(unsigned short* row, int c, float x, int fmt) {
+  if (fmt == MMSA_FMT_H8) {
+    unsigned hi, lo8 = 0u, qh8 = 0u;
+    h8_split2<false>(x, 0.f, hi, lo8, qh8);
+    row[ilv(c)] = (unsigned short)(hi & 0xFFFFu);
+    unsigned char* rb = reinterpret_cast<unsigned char*>(row) + h8_lo_off(c & ~3) + (c & 3);
+    rb[0] = (unsigned char)(lo8 & 0xFFu);
+    rb[8] = (unsigned char)(qh8 & 0xFFu);
+  } else {
+    unsigned short hh, ll;
+    split_bf16(x, hh, ll);
+    row[ilv(c)] = hh;
+    row[ilv(c) + 32] = ll;
+  }
+}
+
 // activation codes shared by the GEMM epilogue and the conv kernels
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_HSWISH = 4, ACT_SIGMOID = 5 };
 

@@ -32,6 +32,7 @@ struct GemmArgs {
   int M, N, K;
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;   // out_mode 1: 2x2 pixel-shuffle store (conv-transpose 2x2 s2)
+  int cp_fmt;                           // format of the planes output (common.h: MMSA_FMT_B3 / MMSA_FMT_H8)
 };
 
 #define BM 128
@@ -251,13 +252,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
           o.x += a.beta * rr.x; o.y += a.beta * rr.y; o.z += a.beta * rr.z; o.w += a.beta * rr.w;
         }
         if (C) *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
-        if (Cp) {
-          uint2 hh, ll;
-          split4(o, hh, ll);
-          unsigned short* cp_ = Cp + drow * a.ldcp + ilv(dcol);
-          *reinterpret_cast<uint2*>(cp_) = hh;
-          *reinterpret_cast<uint2*>(cp_ + 32) = ll;
-        }
+        if (Cp) store_planes4(Cp + drow * a.ldcp, dcol, o, a.cp_fmt);
       } else {
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
@@ -265,12 +260,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
             float x = v[r];
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol + r];
             if (C) C[drow * a.ldc + dcol + r] = x;
-            if (Cp) {
-              unsigned short hh, ll;
-              split_bf16(x, hh, ll);
-              Cp[drow * a.ldcp + ilv(dcol + r)] = hh;
-              Cp[drow * a.ldcp + ilv(dcol + r) + 32] = ll;
-            }
+            if (Cp) store_planes1(Cp + drow * a.ldcp, dcol + r, x, a.cp_fmt);
           }
         }
       }
@@ -286,7 +276,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         float* C, long ldc, long strideC,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream);
+                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, hipStream_t stream);
 
 // ---- tiny problems (CoordinateAttention's 1x1 convs on pooled maps, AM:187-201: M = B*(h+w) <= ~1000 rows, N or K of 8..48): a
 // 128 x 128 MFMA tile would be one or two workgroups walking K alone (64 us for M = 128, N = 48, K = 1536).  Here one wave owns
@@ -342,8 +332,10 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 float* C, long ldc, long strideC,
                                 unsigned short* Cp, long ldcp, long strideCp,
                                 int M, int N, int K, int batch, int act, float alpha,
-                                int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream) {
+                                int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, hipStream_t stream) {
   const bool ap = Ap != nullptr;
+  MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && (cp_fmt == MMSA_FMT_B3 || cp_fmt == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
+  MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 operands need A planes and K %% 64 == 0 (K=%d)", K);
   MMSA_CHECK_ARG((A || Ap) && Wp && (C || Cp), "gemm_split3: null pointer");
   MMSA_CHECK_ARG(!(A && Ap), "gemm_split3: pass either fp32 A or A planes, not both");
   MMSA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_split3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -376,7 +368,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   a.C = C; a.ldc = C ? ldc : 0; a.strideC = strideC;
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
-  a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
+  a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C; a.cp_fmt = cp_fmt;
   // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 forces this one
   static const bool force_v1 = getenv("MMSA_GEMM_V1") != nullptr;
   // one 128-column strip with many rows and a deep K (ConvNeXt stage-0 pw2: N = 96, K = 384): the 128-row tiles of this kernel
@@ -391,10 +383,10 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
     MMSA_CHECK_LAUNCH("gemm_split3(tiny)");
     return MMSA_OK;
   }
-  if (ap && M >= 128 && !force_v1 && !narrow)
+  if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow)))   // h8 operands: only the LDS-DMA kernel reads them
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
-                               out_mode, ps_H, ps_W, ps_C, stream);
+                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, stream);
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
   const bool gen = out_mode != 0 || resid_mod > 0;
   if (ap) {
@@ -408,27 +400,39 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   return MMSA_OK;
 }
 
-// ---- pre-pack: fp32 [rows, cols] (row stride ld) -> ilv planes [rows, 2*cols_pad] (zero padded)
+// ---- pre-pack: fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad] (zero padded).
+// kind 0: bf16 hi/lo planes; 1: h8 activation rows (chunk = lo bytes | q(hi) bytes); 2: h8 WEIGHT rows (chunk = q(hi) | lo): common.h
 __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
-                                    unsigned short* __restrict__ out) {
+                                    unsigned short* __restrict__ out, int kind) {
   const long total = (long)rows * cols_pad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
-    unsigned short h = 0, l = 0;
-    if (c < cols) split_bf16(src[(long)r * ld + c], h, l);
-    unsigned short* o = out + (long)r * 2 * cols_pad + ilv(c);
-    o[0] = h;
-    o[32] = l;
+    const float x = c < cols ? src[(long)r * ld + c] : 0.f;
+    unsigned short* row = out + (long)r * 2 * cols_pad;
+    if (kind == 0) {
+      unsigned short h, l;
+      split_bf16(x, h, l);
+      row[ilv(c)] = h;
+      row[ilv(c) + 32] = l;
+    } else {
+      unsigned hi, lo8 = 0u, qh8 = 0u;
+      h8_split2<false>(x, 0.f, hi, lo8, qh8);
+      row[ilv(c)] = (unsigned short)(hi & 0xFFFFu);
+      unsigned char* rb = reinterpret_cast<unsigned char*>(row) + h8_lo_off(c & ~3) + (c & 3);
+      rb[kind == 2 ? 8 : 0] = (unsigned char)(lo8 & 0xFFu);
+      rb[kind == 2 ? 0 : 8] = (unsigned char)(qh8 & 0xFFu);
+    }
   }
 }
 
 extern "C" int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad,
-                                 unsigned short* out, hipStream_t stream) {
+                                 unsigned short* out, int kind, hipStream_t stream) {
   MMSA_CHECK_ARG(src && out && rows > 0 && cols > 0 && cols_pad >= cols && cols_pad % 32 == 0, "split_planes: bad args");
+  MMSA_CHECK_ARG(kind >= 0 && kind <= 2, "split_planes: kind %d (0 bf16 hi/lo, 1 h8 activation, 2 h8 weight)", kind);
   const long total = (long)rows * cols_pad;
   int blocks = cdiv(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, out);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, out, kind);
   MMSA_CHECK_LAUNCH("split_planes");
   return MMSA_OK;
 }

@@ -22,10 +22,12 @@
 //     activation rows and weight panels are re-read from that XCD's L2 (speed only, never correctness).
 #include "common.h"
 #include <stdlib.h>
+typedef __attribute__((ext_vector_type(8))) int mx_v8i;       // operand of the block-scaled fp8 MFMA (32 bytes per lane)
+typedef __attribute__((ext_vector_type(8))) _Float16 mx_h8;  // operand of the f16 MFMA
 
 struct GemmV2Args {
   const unsigned short* Ap; long lda; long strideA;    // ilv planes (common.h), lda in bf16 units (>= 2K)
-  const unsigned short* Wp; long strideW;              // ilv planes, row stride 2K
+  const unsigned short* Wp; long strideW; long ldw;    // ilv planes, row stride ldw >= 2K (bf16 units)
   const float* bias; long strideBias;
   const float* colscale;
   const float* resid; long ldr; long strideR; int resid_mod; float beta;
@@ -37,6 +39,7 @@ struct GemmV2Args {
   int nbm, nbn, ntiles;
   int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
                // that fills the CUs better: N = 384 gives 3 tiles of 128 (192 tiles on 256 CUs for the ConvNeXt pw2 GEMMs) or 4 of 96 (256 tiles)
+  int cp_fmt;  // format of the planes output Cp: MMSA_FMT_B3 (bf16 hi | lo) or MMSA_FMT_H8 (fp16 hi | e5m2 lo, q(hi): common.h), independent of the operands' format
   int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 10 = epilogue without its global stores
 };
 
@@ -74,9 +77,14 @@ extern "C" int mmsa_debug_stamps(unsigned long long* host_out) {
 // (wave tile 64 x 64 as before), 2-slot ring of 32 KiB stages, TWO workgroups per CU: the epilogue of one workgroup (VALU + stores,
 // matrix pipe idle) runs under the k-loop of the other.  For shapes whose epilogue is a large share of a tile's life (few
 // k-tiles: K <= 512, GELU / planes epilogues) that overlap is worth more than the deeper pipeline of the big tile.
-template <bool GEN, int ACT, bool PP, int NW>
+// FMT = operand format of A and W (common.h): MMSA_FMT_B3 = bf16 hi/lo planes, three bf16 MFMAs per k-tile and output tile;
+// MMSA_FMT_H8 = fp16 hi + e5m2 cross-term bytes: ONE fp16 MFMA per k-tile plus ONE block-scaled fp8 MFMA (K = 128: both cross terms
+// of two k-tiles) per PAIR of k-tiles -- 2/3 of the matrix-pipe time of the bf16 scheme at the same operand bytes; the k loop is then
+// unrolled by two (K % 64 == 0) so that the fp8 operand tuples are assembled in place by the fragment reads of the two k-tiles.
+template <bool GEN, int ACT, bool PP, int NW, int FMT>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV2Args a) {
   static_assert(NW == 8 || (NW == 4 && !PP), "4-wave workgroups run the in-phase main loop");
+  static_assert(FMT == MMSA_FMT_B3 || (PP && NW == 8), "the h8 operand format runs on the ping-pong kernel");
   constexpr bool EPI_UNROLL = ACT >= 0;
   constexpr int V2_BM = NW * 32;
   constexpr int V2_A_BYTES = V2_BM * 128;
@@ -129,11 +137,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     sa1 = ap_ + (long)min(ab_ + 8, a.M - 1) * a.lda + (dpiece ^ 32);             \
     sa2 = ap_ + (long)min(ab_ + 16, a.M - 1) * a.lda + dpiece;                   \
     sa3 = ap_ + (long)min(ab_ + 24, a.M - 1) * a.lda + (dpiece ^ 32);            \
-    sw0 = wp_ + (long)min(wb_, a.N - 1) * 2 * K + dpiece;                        \
-    sw1 = wp_ + (long)min(wb_ + 8, a.N - 1) * 2 * K + (dpiece ^ 32);             \
+    sw0 = wp_ + (long)min(wb_, a.N - 1) * a.ldw + dpiece;                        \
+    sw1 = wp_ + (long)min(wb_ + 8, a.N - 1) * a.ldw + (dpiece ^ 32);             \
     if constexpr (NW == 4) {                                                     \
-      sw2 = wp_ + (long)min(wb_ + 16, a.N - 1) * 2 * K + dpiece;                 \
-      sw3 = wp_ + (long)min(wb_ + 24, a.N - 1) * 2 * K + (dpiece ^ 32);          \
+      sw2 = wp_ + (long)min(wb_ + 16, a.N - 1) * a.ldw + dpiece;                 \
+      sw3 = wp_ + (long)min(wb_ + 24, a.N - 1) * a.ldw + (dpiece ^ 32);          \
     }                                                                            \
   } while (0)
 
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   } while (0)
 
   f32x4 acc[4][4];  // [ni][mi]
+  mx_v8i opA[4] = {}, opW[4] = {};   // h8: the fp8 operands of a k-tile pair (unused, and optimised away, for bf16 planes)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -198,14 +207,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   // the wait.  The 6 DMA instructions of iteration j+2 (ring slot (j+2)%3, last read in iteration j-1: free after the
   // barrier) are issued BETWEEN the MFMA chunks, two per chunk: an LDS-DMA costs ~100 issue cycles (M0 write, address
   // arithmetic, the instruction) which disappear under the 16-cycle passes of the MFMAs already queued.
+// MXPAR (a literal 0 / 1 defined around every expansion) = parity of the k-tile inside its pair, h8 operands only.
+#define MX_SET(dst_, src_, par_)                                                                            \
+  { const uint4 u_ = __builtin_bit_cast(uint4, src_);                                                       \
+    if ((par_) == 0) { dst_[0] = (int)u_.x; dst_[1] = (int)u_.y; dst_[2] = (int)u_.z; dst_[3] = (int)u_.w; }  \
+    else { dst_[4] = (int)u_.x; dst_[5] = (int)u_.y; dst_[6] = (int)u_.z; dst_[7] = (int)u_.w; } }
 #define MFMA_CHUNK(ni)                                                                                      \
-  if (V2_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                            \
-  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                        \
-    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
-    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);            \
-    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);            \
-  }                                                                                                         \
-  if (V2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+  if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                      \
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wh[ni]), __builtin_bit_cast(mx_h8, ah[mi]), acc[ni][mi], 0, 0, 0); \
+      if (MXPAR) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
+    }                                                                                                       \
+  } else {                                                                                                  \
+    if (V2_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                      \
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);          \
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);          \
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);          \
+    }                                                                                                       \
+    if (V2_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                          \
+  }
 #define K_STEP()                                                                                            \
   {                                                                                                         \
     if (nowait > 0) --nowait;                                                                               \
@@ -290,6 +311,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     if ((i_) == 4) GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w);                                             \
     if ((i_) == 5) GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024);                                      \
   }
+#define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } }
 #define K_STEP_PP()                                                                                         \
   {                                                                                                         \
     const bool do_pf = pf_j < total;                                                                        \
@@ -310,6 +332,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
         wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                           \
       }                                                                                                     \
     }                                                                                                       \
+    MX_FILL()                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     STAMP(1)                                                                                                \
     _Pragma("unroll") for (int pi_ = 0; pi_ < V2_PP_NR; ++pi_) PP_PIECE(pi_)                                \
@@ -350,12 +373,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   for (int tdone = 0; tdone < my_tiles; ++tdone) {
     if constexpr (PP) {
       if (grp) __builtin_amdgcn_s_barrier();
+      if constexpr (FMT == MMSA_FMT_H8) {
 #pragma unroll 1
-      for (int kt = 0; kt < nk; ++kt) K_STEP_PP()
+        for (int kt = 0; kt < nk; ++kt) {   // nk is even (checked by the launcher)
+#define MXPAR 0
+          K_STEP_PP()
+#undef MXPAR
+          ++kt;
+#define MXPAR 1
+          K_STEP_PP()
+#undef MXPAR
+        }
+      } else {
+#define MXPAR 0
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) K_STEP_PP()
+#undef MXPAR
+      }
       if (!grp) __builtin_amdgcn_s_barrier();
     } else {
+#define MXPAR 0
 #pragma unroll 1
       for (int kt = 0; kt < nk; ++kt) K_STEP()
+#undef MXPAR
     }
     const int st_cur = st == 0 ? V2_NST - 1 : st - 1;   // ring slot of the k-tile just consumed: free until the next DMA into it (issued after the next barrier)
 
@@ -461,12 +501,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             // two half-lines from two instructions).  LDS executes a wave's instructions in order: the row was fully
             // read (above) before it is overwritten here.
             uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-            if (Cp) {
-              uint2 hh, ll;
-              split4(o, hh, ll);
+            if (Cp) {   // either planes format: stage the row image, read it back 16 bytes per lane
               unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
-              *reinterpret_cast<uint2*>(srow + ilv(cl)) = hh;
-              *reinterpret_cast<uint2*>(srow + ilv(cl) + 32) = ll;
+              store_planes4(srow, cl, o, a.cp_fmt);
               pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
             }
             const int m = mb + rl;
@@ -496,12 +533,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             map_row(m, n + r, drow_, dcol, rrow);
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
             if (C) C[drow_ * a.ldc + dcol] = x;
-            if (Cp) {
-              unsigned short hh, ll;
-              split_bf16(x, hh, ll);
-              Cp[drow_ * a.ldcp + ilv(dcol)] = hh;
-              Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
-            }
+            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, a.cp_fmt);
           }
         }
         }
@@ -546,12 +578,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             // two half-lines from two instructions).  LDS executes a wave's instructions in order: the row was fully
             // read (above) before it is overwritten here.
             uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-            if (Cp) {
-              uint2 hh, ll;
-              split4(o, hh, ll);
+            if (Cp) {   // either planes format: stage the row image, read it back 16 bytes per lane
               unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
-              *reinterpret_cast<uint2*>(srow + ilv(cl)) = hh;
-              *reinterpret_cast<uint2*>(srow + ilv(cl) + 32) = ll;
+              store_planes4(srow, cl, o, a.cp_fmt);
               pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
             }
             const int m = mb + rl;
@@ -581,12 +610,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             map_row(m, n + r, drow_, dcol, rrow);
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
             if (C) C[drow_ * a.ldc + dcol] = x;
-            if (Cp) {
-              unsigned short hh, ll;
-              split_bf16(x, hh, ll);
-              Cp[drow_ * a.ldcp + ilv(dcol)] = hh;
-              Cp[drow_ * a.ldcp + ilv(dcol) + 32] = ll;
-            }
+            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, a.cp_fmt);
           }
         }
         }
@@ -613,6 +637,7 @@ extern "C" int mmsa_debug_gemm_flavour(int waves_per_workgroup) {
 }
 
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
+// fmt = format of the A and W planes, cp_fmt = format of the planes output (common.h).
 int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         const unsigned short* Wp, long strideW,
                         const float* bias, long strideBias, const float* colscale,
@@ -620,23 +645,27 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         float* C, long ldc, long strideC,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int ps_H, int ps_W, int ps_C, hipStream_t stream) {
+                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, hipStream_t stream) {
   GemmV2Args a;
   a.Ap = Ap; a.lda = lda; a.strideA = strideA;
   a.Wp = Wp; a.strideW = strideW;
+  a.ldw = 2L * K;
   a.bias = bias; a.strideBias = strideBias; a.colscale = colscale;
   a.resid = resid; a.ldr = ldr; a.strideR = strideR; a.resid_mod = resid_mod; a.beta = beta;
   a.C = C; a.ldc = C ? ldc : 0; a.strideC = strideC;
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
+  a.cp_fmt = cp_fmt;
+  const bool h8 = fmt == MMSA_FMT_H8;
+  MMSA_CHECK_ARG(!h8 || (K & 63) == 0, "gemm(v2): h8 operands need K %% 64 == 0 (K=%d)", K);
   // workgroup flavour: 8-wave 256-row ping-pong tiles by default.  The 4-wave flavour (128-row tiles, two workgroups per CU: the
   // epilogue of one under the k-loop of the other) measured no faster on any of the model's shapes (profiles/r02_gemm_flavours.txt:
   // its 2-slot ring gives up more in the k-loop than the overlap returns), so it is OFF unless asked for: MMSA_GEMM_NW = 4 / 8
-  // forces one, MMSA_GEMM_NW4_MAXK = k routes shapes with K <= k to it.  Results are bit-identical either way.
+  // forces one, MMSA_GEMM_NW4_MAXK = k routes shapes with K <= k to it.  Results are bit-identical either way.  (bf16 planes only.)
   static const int nw_force = getenv("MMSA_GEMM_NW") ? atoi(getenv("MMSA_GEMM_NW")) : 0;
   static const int nw4_maxk = getenv("MMSA_GEMM_NW4_MAXK") ? atoi(getenv("MMSA_GEMM_NW4_MAXK")) : 0;
-  const int nw = g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
+  const int nw = h8 ? 8 : g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
   const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
   a.nbm = cdiv(M, bm);
   a.bn = V2_BN;
@@ -654,9 +683,10 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (getenv("MMSA_GEMM_MAX_GRID")) g_num_cus = atoi(getenv("MMSA_GEMM_MAX_GRID"));   // experiment: leave CUs to concurrent streams
 #define V2_ATTR(GEN_, ACT_)                                                                                                   \
-  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8)); \
-  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
-  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8)); \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1)
 #undef V2_ATTR
   }
@@ -680,9 +710,10 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   static const bool pp = getenv("MMSA_GEMM_PP") ? atoi(getenv("MMSA_GEMM_PP")) != 0 : true;   // 0: every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \
   do {                                                                                                                     \
-    if (nw == 4) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 4>), dim3(grid), dim3(256), V2_LDS_BYTES(4), stream, a);     \
-    else if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);     \
-    else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);            \
+    if (h8) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);          \
+    else if (nw == 4) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>), dim3(grid), dim3(256), V2_LDS_BYTES(4), stream, a);     \
+    else if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);     \
+    else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);            \
   } while (0)
   if (gen) {
     V2_LAUNCH(true, -1);

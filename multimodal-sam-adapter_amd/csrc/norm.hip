@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b, float eps,
     float* __restrict__ y, long ldy, float* __restrict__ y2, long ldy2,
     unsigned short* __restrict__ yp, long ldp, int rows, int C,
-    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap) {
+    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap, int plane_fmt) {
   constexpr int LPR = 64 / RPW;                       // lanes per row
   const int lane = threadIdx.x & (LPR - 1);
   // A wave (or half wave) walks rows slot, slot + nslots, ... with the NEXT row's loads in flight while the current row is
@@ -26,10 +26,13 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   const int nslots = gridDim.x * (4 * RPW);
   int row = blockIdx.x * (4 * RPW) + (threadIdx.x / LPR);
   if (row >= rows) return;
-  float4 v[NV], vn[NV];
+  float4 v[NV], vn[NV], wv[NV], bv[NV];
+  int cur_grp = -1;
+  const bool pair16 = (C & 7) == 0;   // kernel-uniform
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + LPR * i) * 4;
+    wv[i] = bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     vn[i] = c < C ? *reinterpret_cast<const float4*>(x + (long)row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (; row < rows; row += nslots) {
@@ -46,8 +49,16 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     // row groups (the two ConvNeXt streams stacked along the rows): group g = row / group_rows has its own weight /
     // bias vectors (w + g * w_gstride) and writes at column offset g * y_gcol; y_wrap: output row = row % group_rows
     const int grp = group_rows > 0 ? row / group_rows : 0;
-    const float* wg = w + (long)grp * w_gstride;
-    const float* bg = b + (long)grp * w_gstride;
+    if (grp != cur_grp) {   // wave-uniform for RPW == 1; per half wave otherwise (both halves reload: harmless)
+      cur_grp = grp;
+      const float* wg = w + (long)grp * w_gstride;
+      const float* bg = b + (long)grp * w_gstride;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + LPR * i) * 4;
+        if (c < C) { wv[i] = *reinterpret_cast<const float4*>(wg + c); bv[i] = *reinterpret_cast<const float4*>(bg + c); }
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);   // lanes beyond C hold zeros
@@ -78,26 +89,43 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + LPR * i) * 4;
-      if (c < C) {
-        const float4 ww = *reinterpret_cast<const float4*>(wg + c);
-        const float4 bb = *reinterpret_cast<const float4*>(bg + c);
-        float4 o;
-        o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
-        o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
-        o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
-        o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+      const bool in = c < C;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) {
+        o.x = (v[i].x - mean) * rstd * wv[i].x + bv[i].x;
+        o.y = (v[i].y - mean) * rstd * wv[i].y + bv[i].y;
+        o.z = (v[i].z - mean) * rstd * wv[i].z + bv[i].z;
+        o.w = (v[i].w - mean) * rstd * wv[i].w + bv[i].w;
         if (yr) *reinterpret_cast<float4*>(yr + c) = o;
-        if (pr) {
-          uint2 hh, ll;
-          split4(o, hh, ll);
-          unsigned short* q_ = pr + ilv((int)ocol + c);
-          *reinterpret_cast<uint2*>(q_) = hh;
-          *reinterpret_cast<uint2*>(q_ + 32) = ll;
+      }
+      if (pr) {
+        if (pair16) {
+          // C % 8 == 0: lanes 2j / 2j+1 hold channels 8j .. 8j+7 = one 16-byte hi chunk and one 16-byte second chunk of the line
+          // (bf16 planes: the lo values; h8 planes: 8 lo bytes + 8 q(hi) bytes).  The even lane stores the hi chunk, the odd lane
+          // the other: ONE 16-byte store per lane, and a wave instruction writes whole 128-byte lines (8-byte hi / lo stores wrote
+          // every line as two half-lines from two instructions).
+          const bool odd = lane & 1;
+          uint2 mine_hi, mine_x;   // hi chunk half; second-chunk half (bf16: lo values; h8: .x = lo bytes, .y = q(hi) bytes)
+          if (plane_fmt == MMSA_FMT_H8) h8_split4(o, mine_hi, mine_x.x, mine_x.y);
+          else split4(o, mine_hi, mine_x);
+          const uint2 snd = odd ? mine_hi : mine_x;
+          uint2 rcv;
+          rcv.x = __shfl_xor(snd.x, 1, 64);
+          rcv.y = __shfl_xor(snd.y, 1, 64);
+          uint4 pk;
+          if (!odd) pk = make_uint4(mine_hi.x, mine_hi.y, rcv.x, rcv.y);
+          else if (plane_fmt == MMSA_FMT_H8) pk = make_uint4(rcv.x, mine_x.x, rcv.y, mine_x.y);
+          else pk = make_uint4(rcv.x, rcv.y, mine_x.x, mine_x.y);
+          const int c8 = (int)ocol + (c & ~7);
+          const int off = odd ? (plane_fmt == MMSA_FMT_H8 ? h8_lo_off(c8) >> 1 : ilv(c8) + 32) : ilv(c8);
+          if (in) *reinterpret_cast<uint4*>(pr + off) = pk;
+        } else if (in) {
+          store_planes4(pr, (int)ocol + c, o, plane_fmt);
         }
-        if (y2r) {
-          o.x += v[i].x; o.y += v[i].y; o.z += v[i].z; o.w += v[i].w;
-          *reinterpret_cast<float4*>(y2r + c) = o;
-        }
+      }
+      if (in && y2r) {
+        o.x += v[i].x; o.y += v[i].y; o.z += v[i].z; o.w += v[i].w;
+        *reinterpret_cast<float4*>(y2r + c) = o;
       }
     }
   }
@@ -107,7 +135,8 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
                                    float* y, long ldy, float* y2, long ldy2,
                                    unsigned short* yp, long ldp, int rows, int C,
                                    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap,
-                                   hipStream_t stream) {
+                                   int plane_fmt, hipStream_t stream) {
+  MMSA_CHECK_ARG(plane_fmt == MMSA_FMT_B3 || plane_fmt == MMSA_FMT_H8, "layernorm_rows: bad plane format %d", plane_fmt);
   MMSA_CHECK_ARG(x && w && b && (y || yp) && rows > 0 && C > 0, "layernorm_rows: bad args");
   MMSA_CHECK_ARG(!yp || map_mode == 0 || C % 32 == 0, "layernorm_rows: patchified planes need C %% 32 == 0");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy2 & 3) == 0 && (ldp & 3) == 0, "layernorm_rows: C/ld must be multiples of 4");
@@ -124,8 +153,8 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
   static const int ln_rows = getenv("MMSA_LN_ROWS") ? atoi(getenv("MMSA_LN_ROWS")) : 0;
   const int per_slot = ln_rows > 0 ? ln_rows : (rows >= 8192 ? 4 : rows >= 4096 ? 2 : 1);
   dim3 grid(cdiv(rows, 4 * rpw * per_slot)), block(256);
-#define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap)
-  if (C <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<1, 2>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap);
+#define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt)
+  if (C <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<1, 2>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt);
   else if (C <= 256) LN_LAUNCH(1);
   else if (C <= 512) LN_LAUNCH(2);
   else if (C <= 1024) LN_LAUNCH(4);

@@ -42,6 +42,7 @@ struct WAttnArgs {
   const unsigned short* relp;           // rel-pos planes [64 rows, 2*64]: rows 0..2ws-2 = rel_pos_h, 32..32+2ws-2 = rel_pos_w
   const unsigned short* sel;            // [208, 32] bf16 selector: sel[j][kh(j)] = sel[j][14 + kw(j)] = 1 for j < ws*ws, else 0
   unsigned short* op; long ldo;         // output planes [B*T, >= 2*D]
+  int ofmt;                             // their format (common.h: MMSA_FMT_B3 bf16 hi/lo, MMSA_FMT_H8 for an h8 proj GEMM)
   int B, H, W, heads, D, ws, nWw;
   int debug;                            // MMSA_WATTN_DEBUG timing ablations: 1 = stop after the barrier, 2 = no K/V DMA
   unsigned magic;                       // ceil(65536 / ws): j / ws == (j * magic) >> 16 for j < 224 (checked on the host)
@@ -294,13 +295,8 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
   if (live) {
     unsigned short* orow = a.op + ((long)b * T + tq) * a.ldo;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      uint2 hh, ll;
-      split4(make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), hh, ll);
-      unsigned short* q_ = orow + ilv(head * 64 + 16 * d + 4 * G);
-      *reinterpret_cast<uint2*>(q_) = hh;
-      *reinterpret_cast<uint2*>(q_ + 32) = ll;
-    }
+    for (int d = 0; d < 4; ++d)
+      store_planes4(orow, head * 64 + 16 * d + 4 * G, make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt);
   }
 }
 
@@ -604,13 +600,8 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       if (tq_cur >= 0) {
         unsigned short* orow = a.op + ((long)b_cur * T + tq_cur) * a.ldo;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          uint2 hh, ll;
-          split4(make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), hh, ll);
-          unsigned short* q_ = orow + ilv(head_cur * 64 + 16 * d + 4 * G);
-          *reinterpret_cast<uint2*>(q_) = hh;
-          *reinterpret_cast<uint2*>(q_ + 32) = ll;
-        }
+        for (int d = 0; d < 4; ++d)
+          store_planes4(orow, head_cur * 64 + 16 * d + 4 * G, make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt);
       }
     }
     if (!has_next) break;
@@ -623,8 +614,9 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
                                             const unsigned short* relpos_planes, const unsigned short* selector,
                                             unsigned short* out_planes, long ldo,
                                             int B, int H, int W, int heads, int head_dim, int window_size, float scale,
-                                            hipStream_t stream) {
+                                            int out_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
+  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "window_attention: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0, "window_attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64, "window_attention: head_dim %d not supported by this kernel (64)", head_dim);
   MMSA_CHECK_ARG(window_size >= 1 && window_size <= 14, "window_attention: window_size %d not supported (1..14)", window_size);
@@ -634,7 +626,7 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
                    reinterpret_cast<uintptr_t>(relpos_planes) | reinterpret_cast<uintptr_t>(selector) | reinterpret_cast<uintptr_t>(out_planes)) & 127) == 0,
                  "window_attention: planes must be 128-byte aligned");
   WAttnArgs a;
-  a.qp = qkv_planes; a.ldq = ldq; a.bp = bias_planes; a.relp = relpos_planes; a.sel = selector; a.op = out_planes; a.ldo = ldo;
+  a.qp = qkv_planes; a.ldq = ldq; a.bp = bias_planes; a.relp = relpos_planes; a.sel = selector; a.op = out_planes; a.ldo = ldo; a.ofmt = out_fmt;
   a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
   a.nWw = cdiv(W, window_size);
   static const int dbg = getenv("MMSA_WATTN_DEBUG") ? atoi(getenv("MMSA_WATTN_DEBUG")) : 0;

@@ -52,10 +52,10 @@ class Workspace:
             elif b.dtype == torch.int16:
                 b.fill_(0x7fc0)
 
-    def planes(self, name, rows, cols, zero=False):
-        """Interleaved bf16 hi/lo activation planes of a [rows, cols] matrix (cols padded to 32)."""
+    def planes(self, name, rows, cols, zero=False, fmt=ops.FMT_B3):
+        """Activation planes of a [rows, cols] matrix (cols padded to 32) in the given operand format (ops.Planes)."""
         cp = ops.pad32(cols)
-        return ops.Planes(self.get(name + ".pl", rows, 2 * cp, torch.int16, zero or cp != cols), rows, cols, cp)
+        return ops.Planes(self.get(name + ".pl", rows, 2 * cp, torch.int16, zero or cp != cols), rows, cols, cp, fmt)
 
     def nbytes(self):
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
@@ -180,16 +180,28 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             raise NotImplementedError("mmsa: the MI355X backbone implements the inference forward path only")
         return super().train(False)
 
+    # GEMM sites whose operands travel in the h8 format (ops.Planes: fp16 hi + e5m2 cross-term bytes, 2/3 of the matrix-pipe time
+    # of the bf16 hi/lo scheme; csrc/common.h has the error analysis, tools/precision_study.py the end-to-end measurement).
+    # "vit" = qkv / proj / lin1 / lin2 of the SAM ViT blocks.  `model.h8_sites = ()` or MMSA_H8=none keeps every site on bf16 hi/lo.
+    H8_DEFAULT = ("vit",)
+
+    def _h8_sites(self):
+        env = os.environ.get("MMSA_H8")
+        if env is not None:
+            return tuple(t for t in env.split(",") if t and t != "none")
+        return tuple(getattr(self, "h8_sites", self.H8_DEFAULT))
+
     # ------------------------------------------------------------------ packing (one-time weight preprocessing)
     @torch.no_grad()
     def _pack(self, dev):
         cfg = self.cfg
+        h8_sites = self._h8_sites()
         sd = {k: v.detach().to(dev, torch.float32) for k, v in self.state_dict().items() if v.dtype.is_floating_point}
-        pk = {}
+        pk = {"h8_sites": h8_sites}
         D = cfg["embed_dim"]
 
-        def planes(w2d, kpad=None):
-            return ops.split_planes(w2d.contiguous(), kpad)
+        def planes(w2d, kpad=None, fmt=ops.FMT_B3):
+            return ops.split_planes(w2d.contiguous(), kpad, fmt=fmt, weight=fmt == ops.FMT_H8)
 
         def scalar(k):
             return float(sd[k].item())
@@ -223,17 +235,21 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             out[:, :hd_true] = t
             return out
 
+        # operand format of the ViT-block GEMMs: h8 needs every contraction length (D, attention width, MLP hidden) % 64 == 0
+        hidden_ = sd["blocks.0.mlp.lin1.weight"].shape[0]
+        vfmt = ops.FMT_H8 if ("vit" in h8_sites and D % 64 == 0 and Da % 64 == 0 and hidden_ % 64 == 0) else ops.FMT_B3
+        pk["vit_fmt"] = vfmt
         for i in range(cfg["depth"]):
             b = f"blocks.{i}."
             qkv_w, qkv_bias = pad_head_rows(sd[b + "attn.qkv.weight"], 3), pad_head_rows(sd[b + "attn.qkv.bias"], 3)
             proj_w = pad_head_rows(sd[b + "attn.proj.weight"].t(), 1).t().contiguous()    # zero COLUMNS for the pad channels
             pk["blocks"].append(dict(
                 n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
-                qkv=planes(qkv_w), qkv_b=qkv_bias,
+                qkv=planes(qkv_w, fmt=vfmt), qkv_b=qkv_bias,
                 qkv_bp=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da),  # k = v of pad tokens
-                proj=planes(proj_w), proj_b=sd[b + "attn.proj.bias"],
-                lin1=planes(sd[b + "mlp.lin1.weight"]), lin1_b=sd[b + "mlp.lin1.bias"],
-                lin2=planes(sd[b + "mlp.lin2.weight"]), lin2_b=sd[b + "mlp.lin2.bias"],
+                proj=planes(proj_w, fmt=vfmt), proj_b=sd[b + "attn.proj.bias"],
+                lin1=planes(sd[b + "mlp.lin1.weight"], fmt=vfmt), lin1_b=sd[b + "mlp.lin1.bias"],
+                lin2=planes(sd[b + "mlp.lin2.weight"], fmt=vfmt), lin2_b=sd[b + "mlp.lin2.bias"],
                 rph=pad_cols(sd[b + "attn.rel_pos_h"]), rpw=pad_cols(sd[b + "attn.rel_pos_w"]),
                 ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"]))
         for blk in pk["blocks"]:   # windowed blocks with head_dim 64: rel-pos tables packed for the fused window kernel
@@ -434,7 +450,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             raise RuntimeError("mmsa: img_size must be a multiple of 32")
         dev = x.device
         x = x.contiguous().float()
-        if self._packed is None or self._packed.get("dev") != dev:
+        if self._packed is None or self._packed.get("dev") != dev or tuple(self._packed.get("h8_sites", ())) != self._h8_sites():
             self._packed = self._pack(dev)
             self._packed["dev"] = dev
         if self._ws is None or self._ws.device != dev:
@@ -565,12 +581,13 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         T = Hp * Wp
         # intermediate activations travel as bf16 hi/lo planes: split once by the producer, consumed by the
         # GEMM / attention kernels with plain 16-byte copies (same bytes as fp32, no re-splitting per column block)
-        n = ws.planes("blk_n", B * T, D)
+        vf = bp["qkv"].fmt   # operand format of this block's GEMMs: the producers below write it (qkv's own output stays bf16 hi/lo for the attention kernels)
+        n = ws.planes("blk_n", B * T, D, fmt=vf)
         ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
         qkv = ws.planes("blk_qkv", B * T, 3 * Da)
         ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
-        ao = ws.planes("blk_ao", B * T, Da)
+        ao = ws.planes("blk_ao", B * T, Da, fmt=vf)
         if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
             ops.window_attention(qkv, bp["qkv_bp"], bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
         elif relg is not None:           # global block on a 64-wide grid: flash kernel with the rel-pos terms fused
@@ -582,7 +599,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, scale)
         ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
         ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
-        h = ws.planes("blk_h", B * T, bp["lin1"].n)
+        h = ws.planes("blk_h", B * T, bp["lin1"].n, fmt=vf)
         ops.gemm(n, bp["lin1"], bias=bp["lin1_b"], act="gelu", out_planes=h)
         ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x)
 

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 2
+PACK_FORMAT = 3   # 3: planes carry their operand format (bf16 hi/lo or h8)
 
 
 def unwrap_state_dict(ck):
@@ -89,7 +89,8 @@ def convert_sam_release(state_dict):
 def _enc(o):
     if isinstance(o, ops.Planes):
         full = getattr(o, "full", None)
-        return {"__planes__": True, "p": (full if full is not None else o.p).cpu(), "n": o.n, "k": o.k, "kpad": o.kpad, "stacked": full is not None}
+        return {"__planes__": True, "p": (full if full is not None else o.p).cpu(), "n": o.n, "k": o.k, "kpad": o.kpad, "stacked": full is not None,
+                "fmt": o.fmt, "weight": o.weight}
     if isinstance(o, torch.Tensor):
         return o.cpu()
     if isinstance(o, dict):
@@ -103,10 +104,10 @@ def _dec(o, dev):
     if isinstance(o, dict) and o.get("__planes__"):
         buf = o["p"].to(dev)
         if o["stacked"]:
-            pl = ops.Planes(buf[:o["n"]], o["n"], o["k"], o["kpad"])
+            pl = ops.Planes(buf[:o["n"]], o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False))
             pl.full = buf
             return pl
-        return ops.Planes(buf, o["n"], o["k"], o["kpad"])
+        return ops.Planes(buf, o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False))
     if isinstance(o, torch.Tensor):
         return o.to(dev)
     if isinstance(o, dict):

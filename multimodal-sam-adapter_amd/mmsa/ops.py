@@ -62,15 +62,22 @@ def _mat(t, name, dtype=torch.float32):
     return _chk(t, dtype, name), t.shape[0], t.shape[1], t.stride(0)
 
 
-class Planes:
-    """Interleaved bf16 hi/lo planes (include/mmsa.h) of a matrix: ONE int16 tensor [rows, 2*kpad]; row r holds, per
-    32-wide k-block, the 32 hi values then the 32 lo values.  Used for weights [N, K] and for activations."""
+FMT_B3, FMT_H8 = 0, 1   # MMSA_FMT_* (include/mmsa.h)
 
-    def __init__(self, p, n=None, k=None, kpad=None):
+
+class Planes:
+    """Operand planes (include/mmsa.h) of a matrix: ONE int16 tensor [rows, 2*kpad]; 128 bytes per row and 32-wide k-block.
+    fmt FMT_B3: bf16 hi/lo ("split3": the 32 hi values then the 32 lo values).  fmt FMT_H8: fp16 hi + e5m2 cross-term bytes
+    (32 fp16, then four 16-byte chunks of lo / q(hi) bytes; `weight` = the chunk order of a W operand).  Used for weights
+    [N, K] and for activations; a producer writes the format of the Planes it is handed."""
+
+    def __init__(self, p, n=None, k=None, kpad=None, fmt=FMT_B3, weight=False):
         self.p = p
         self.n = p.shape[0] if n is None else n
         self.kpad = p.shape[1] // 2 if kpad is None else kpad
         self.k = self.kpad if k is None else k
+        self.fmt = fmt
+        self.weight = weight
         self.gen = None   # (cell, value): set by a producer whose buffer is reused; live() tells whether it still holds this data
 
     def stamp(self, cell):
@@ -83,13 +90,13 @@ class Planes:
 
     def rows(self, lo, hi=None):
         """Row slice (same columns)."""
-        return Planes(self.p[lo:hi], None, self.k, self.kpad)
+        return Planes(self.p[lo:hi], None, self.k, self.kpad, self.fmt, self.weight)
 
     def cols(self, lo, hi):
         """Column slice [lo, hi) of the matrix (both multiples of 32): the k-blocks are self-contained in the layout."""
         if lo % 32 or hi % 32:
             raise RuntimeError("mmsa.Planes.cols: column bounds must be multiples of 32")
-        return Planes(self.p[:, 2 * lo:2 * hi], self.n, hi - lo, hi - lo)
+        return Planes(self.p[:, 2 * lo:2 * hi], self.n, hi - lo, hi - lo, self.fmt, self.weight)
 
     def mat(self, name):
         ptr, rows, cols, ld = _mat(self.p, name, torch.int16)
@@ -102,26 +109,35 @@ def pad32(k):
     return (k + 31) // 32 * 32
 
 
-def alloc_planes(rows, cols, device, zero=False):
+def alloc_planes(rows, cols, device, zero=False, fmt=FMT_B3):
     f = torch.zeros if zero else torch.empty
-    return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols))
+    return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols), fmt)
 
 
 def planes_to_float(pl, cols=None):
     """Debug/test helper: reconstruct hi + lo as fp32 [rows, cols] (torch ops; not used on the product path)."""
     r, w = pl.p.shape
-    v = (pl.p.to(torch.int32) << 16).view(torch.float32).view(r, w // 64, 2, 32)
-    out = (v[:, :, 0] + v[:, :, 1]).reshape(r, w // 2)
+    if pl.fmt == FMT_H8:
+        blk = pl.p.contiguous().view(torch.uint8).view(r, w // 64, 128)
+        hi = blk[:, :, :64].contiguous().view(torch.float16).float()                       # [r, nb, 32]
+        ch = blk[:, :, 64:].reshape(r, w // 64, 4, 2, 8)                                    # chunk g: (lo | q(hi)) or (q(hi) | lo)
+        lo = ch[:, :, :, 1 if pl.weight else 0].contiguous().view(torch.float8_e5m2).float().reshape(r, w // 64, 32)
+        out = (hi + lo / 2048.0).reshape(r, w // 2)
+    else:
+        v = (pl.p.to(torch.int32) << 16).view(torch.float32).view(r, w // 64, 2, 32)
+        out = (v[:, :, 0] + v[:, :, 1]).reshape(r, w // 2)
     return out[:, :(pl.k if cols is None else cols)]
 
 
-def split_planes(w2d, kpad=None, out=None):
-    """fp32 [N, K] (device) -> Planes with K zero-padded to a multiple of 32."""
+def split_planes(w2d, kpad=None, out=None, fmt=FMT_B3, weight=False):
+    """fp32 [N, K] (device) -> Planes with K zero-padded to a multiple of 32.  fmt FMT_H8: `weight` selects the chunk order of a
+    GEMM W operand (q(hi) | lo) instead of an activation's (lo | q(hi))."""
     p, n, k, ld = _mat(w2d, "weight")
     kpad = kpad or pad32(k)
     if out is None:
-        out = Planes(torch.empty(n, 2 * kpad, dtype=torch.int16, device=w2d.device), n, k, kpad)
-    lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), _stream())
+        out = Planes(torch.empty(n, 2 * kpad, dtype=torch.int16, device=w2d.device), n, k, kpad, fmt, weight)
+    kind = 0 if out.fmt == FMT_B3 else (2 if out.weight else 1)
+    lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), kind, _stream())
     return out
 
 
@@ -130,11 +146,16 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
          out_planes=None, stride_cp=0):
     """out / out_planes = beta*resid + colscale*alpha*act(a @ w^T + bias).
     a: fp32 2-D view or activation Planes; w: weight Planes; out: fp32 view and/or out_planes: Planes."""
+    fmt = w.fmt
     if isinstance(a, Planes):
         pap, ma, ka, lda = a.mat("A")
         pa = None
         if ka < w.kpad:
             raise RuntimeError(f"mmsa.gemm: A planes have {ka} columns but the packed weight expects K={w.kpad}")
+        if a.fmt != w.fmt or a.weight or (w.fmt == FMT_H8 and not w.weight):
+            raise RuntimeError(f"mmsa.gemm: operand formats differ (A fmt {a.fmt}, W fmt {w.fmt} weight={w.weight})")
+    elif fmt != FMT_B3:
+        raise RuntimeError("mmsa.gemm: h8 weights need A as h8 planes")
     else:
         pa, ma, ka, lda = _mat(a, "A")
         pap = None
@@ -158,7 +179,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     lib.call("mmsa_gemm_split3", pa, pap, lda, stride_a, w.p.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
-             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], _stream())
+             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, out_planes.fmt if out_planes is not None else FMT_B3, _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
         nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)
@@ -185,7 +206,8 @@ def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None,
         pp, _, _, ldp = out_planes.mat("y planes")
     mh, mw = patchify or (0, 0)
     lib.call("mmsa_layernorm_rows", px, ldx, _chk(w), _chk(b), eps, py, ldy, p2, ld2, pp, ldp, rows, c,
-             1 if patchify else 0, mh, mw, group_rows, w_gstride, y_gcol, 1 if y_wrap else 0, _stream())
+             1 if patchify else 0, mh, mw, group_rows, w_gstride, y_gcol, 1 if y_wrap else 0,
+             out_planes.fmt if out_planes is not None else FMT_B3, _stream())
     return out if out is not None else out_planes
 
 
@@ -262,7 +284,7 @@ def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
         pq, _, _, ldq = qkv.mat("qkv")
         po, _, _, ldo = out.mat("out")
         lib.call("mmsa_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(rp),
-                 po, ldo, b, h, w, heads, hd, ws, scale, _stream())
+                 po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _stream())
     else:
         pq, _, _, ldq = _mat(qkv, "qkv")
         po, _, _, ldo = _mat(out, "out")
@@ -297,7 +319,7 @@ def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale):
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
     lib.call("mmsa_global_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relg.p, torch.int16), po, ldo,
-             b, h, w, heads, hd, scale, _stream())
+             b, h, w, heads, hd, scale, out.fmt, _stream())
     return out
 
 
@@ -323,7 +345,7 @@ def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
     lib.call("mmsa_window_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relp.p, torch.int16),
-             _chk(window_selector(ws, qkv.p.device), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, _stream())
+             _chk(window_selector(ws, qkv.p.device), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _stream())
     return out
 
 

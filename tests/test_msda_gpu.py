@@ -76,12 +76,20 @@ def test_backward_float32_border_samples(ext, golden_dir, tag):
 
 
 def test_backward_float16(ext, golden_dir):
+    """Half tensors: the kernel reads the fp16-rounded inputs, computes in fp32 and rounds each gradient once (grad_value: fp16
+    atomics).  Expected values = autograd through the oracle's core on the SAME rounded inputs (rounding sampling_loc to 11 bits
+    moves samples across pixel / border boundaries, where the location gradient is discontinuous: the fp32 golden of the
+    unrounded inputs is not the right comparison for gloc)."""
+    from oracle import ref_encoder as R  # checker only
     g = np.load(os.path.join(golden_dir, "msda_bwd.npz"))
     args, a = _bwd_case(g, "inj", torch.float16)
-    for got, key in zip(ext.ms_deform_attn_backward(*args, 64), ("gvalue", "gloc", "gaw")):
-        ref = a[key]
+    value, shapes, lsi, loc, aw, gout = [t.cpu() for t in args]
+    v32, l32, w32 = value.double().requires_grad_(True), loc.double().requires_grad_(True), aw.double().requires_grad_(True)
+    R.msda_core(v32, shapes, l32, w32).backward(gout.double())
+    for got, ref, key in zip(ext.ms_deform_attn_backward(*args, 64), (v32.grad, l32.grad, w32.grad), ("gvalue", "gloc", "gaw")):
         assert got.dtype == torch.float16
-        assert (got.cpu().float() - ref).norm() <= 2e-2 * ref.norm(), key
+        ref = ref.float()
+        assert (got.cpu().float() - ref).norm() <= 1e-2 * ref.norm(), key
 
 
 def test_autograd_function_matches_reference_gradients(ext, golden_dir):

@@ -368,3 +368,110 @@ def test_gemm_workgroup_flavours_agree_bitwise(ops, M, N, K, mode):
     finally:
         lib.call("mmsa_debug_gemm_flavour", 0)
     assert torch.equal(got[4], got[8]), "the 4-wave and the 8-wave flavour differ"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# "h8" operand planes (fp16 hi + e5m2 cross-term bytes; csrc/common.h): format, the GEMM on them, and the producers that emit them
+def _h8_emulated_product(a, w):
+    """What the kernel computes, restated with torch casts: hi.hi exactly + the two cross terms with e5m2-rounded operands."""
+    ah = a.clamp(-57344, 57344).half().float()
+    wh = w.clamp(-57344, 57344).half().float()
+    al, wl = (a - ah) * 2048, (w - wh) * 2048
+    q = lambda t: t.to(torch.float8_e5m2).float()
+    return ah.double() @ wh.double().t() + (q(ah).double() @ q(wl).double().t() + q(al).double() @ q(wh).double().t()) / 2048
+
+
+def test_split_planes_h8_roundtrip_and_layout(ops):
+    x = torch.randn(37, 50, generator=g(41)) * 3
+    for weight in (False, True):
+        p = ops.split_planes(x.to(DEV), fmt=ops.FMT_H8, weight=weight)
+        assert p.p.shape == (37, 128) and p.kpad == 64 and p.k == 50 and p.fmt == ops.FMT_H8 and p.weight == weight
+        back = ops.planes_to_float(p, cols=64).cpu()
+        assert torch.all(back[:, 50:] == 0)
+        assert ((back[:, :50] - x).abs() <= x.abs() * 2 ** -13).all()      # 11 bits of hi + 3 of lo
+        raw = p.p.cpu().view(torch.uint8).view(37, 2, 128)
+        hi = raw[:, :, :64].contiguous().view(torch.float16)                # [37, 2, 32]
+        assert torch.equal(hi[:, 0, :].float(), x[:, :32].half().float()) and torch.equal(hi[:, 1, :18].float(), x[:, 32:].half().float())
+        # chunk g of a block: 8 lo bytes + 8 q(hi) bytes (activation) / swapped (weight), k = 8g .. 8g+7
+        ch = raw[:, 0, 64:].reshape(37, 4, 2, 8)
+        lo = ch[:, :, 1 if weight else 0].contiguous().view(torch.float8_e5m2).float().reshape(37, 32)
+        qh = ch[:, :, 0 if weight else 1].contiguous().view(torch.float8_e5m2).float().reshape(37, 32)
+        xh = x[:, :32].half().float()
+        assert torch.equal(qh, xh.to(torch.float8_e5m2).float())
+        assert torch.equal(lo, ((x[:, :32] - xh) * 2048).to(torch.float8_e5m2).float())
+    # saturation instead of infinities
+    big = torch.tensor([[1e6, -1e6, 60000.0, 3.0] * 8], device=DEV)
+    assert torch.equal(ops.planes_to_float(ops.split_planes(big, fmt=ops.FMT_H8)).cpu()[0, :4], torch.tensor([57344.0, -57344.0, 57344.0, 3.0]))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 96, 64, "none"), (1000, 576, 1024, "gelu"), (4096, 1024, 768, "none"), (77, 28, 128, "relu"),
+                                       (8192, 1024, 4096, "none")])
+def test_gemm_h8_operands(ops, M, N, K, act):
+    a = torch.randn(M, K, generator=g(42)) * 1.7
+    w = torch.randn(N, K, generator=g(43)) / K ** 0.5
+    b = torch.randn(N, generator=g(44))
+    res = torch.randn(M, N, generator=g(45))
+    fact = {"none": lambda t: t, "gelu": F.gelu, "relu": F.relu}[act]
+    ref = fact(F.linear(a.double(), w.double(), b.double())).float() + res
+    ap = ops.split_planes(a.to(DEV), kpad=K, fmt=ops.FMT_H8)
+    wp = ops.split_planes(w.to(DEV), fmt=ops.FMT_H8, weight=True)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(ap, wp, out, bias=b.to(DEV), act=act, resid=res.to(DEV))
+    assert_close(out, ref, tol=5e-5, what="h8 gemm vs fp64")
+    # the kernel's own arithmetic (pins the pairing of the fp8 operand bytes: a wrong k-slot pairing is off by ~2e-4)
+    emu = fact(_h8_emulated_product(a, w) + b.double()).float() + res
+    assert_close(out, emu, tol=3e-6, what="h8 gemm vs its emulation")
+    # planes output in both formats from h8 operands, and h8 planes from bf16 hi/lo operands
+    for ofmt in (ops.FMT_B3, ops.FMT_H8):
+        outp = ops.alloc_planes(M, N, DEV, fmt=ofmt)
+        ops.gemm(ap, wp, bias=b.to(DEV), act=act, resid=res.to(DEV), out_planes=outp)
+        assert_close(planes_to_float(outp), ref, tol=1.5e-4 if ofmt == ops.FMT_H8 else 5e-5, what=f"h8 gemm planes out fmt {ofmt}")
+    outp = ops.alloc_planes(M, N, DEV, fmt=ops.FMT_H8)
+    ops.gemm(ops.split_planes(a.to(DEV), kpad=K), ops.split_planes(w.to(DEV)), bias=b.to(DEV), act=act, resid=res.to(DEV), out_planes=outp)
+    assert_close(planes_to_float(outp), ref, tol=1.5e-4, what="b3 gemm, h8 planes out")
+
+
+def test_gemm_h8_exact_on_integers_and_cross_terms(ops):
+    """Small integers are exact in fp16 (lo = 0): the result must be the exact integer product.  Then operands whose lo parts
+    carry all the signal: A = 1 + 2^-12 u (u in {-1, 0, 1}) needs the cross terms to come out right."""
+    M, N, K = 256, 128, 128
+    a = torch.randint(-8, 9, (M, K), generator=g(46)).float()
+    w = torch.randint(-8, 9, (N, K), generator=g(47)).float()
+    w[:, 0] += 100 * torch.arange(N)              # asymmetric: catches row/column swaps
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(ops.split_planes(a.to(DEV), fmt=ops.FMT_H8), ops.split_planes(w.to(DEV), fmt=ops.FMT_H8, weight=True), out)
+    assert torch.equal(out.cpu(), a @ w.t())
+    u = torch.randint(-1, 2, (M, K), generator=g(48)).float()
+    v = torch.randint(-1, 2, (N, K), generator=g(49)).float()
+    a2, w2 = 1 + u * 2 ** -12, 1 + v * 2 ** -12      # hi = 1, lo = +-2^-12: exactly representable in e5m2 after the 2^11 scaling
+    ops.gemm(ops.split_planes(a2.to(DEV), fmt=ops.FMT_H8), ops.split_planes(w2.to(DEV), fmt=ops.FMT_H8, weight=True), out)
+    exact = (K + (u.sum(1)[:, None] + v.sum(1)[None, :]) * 2 ** -12).double()      # hi.hi + both cross terms (lo.lo is dropped)
+    assert (out.cpu().double() - exact).abs().max() <= 1e-6
+
+
+def test_gemm_h8_argument_checks(ops):
+    a = ops.split_planes(torch.randn(128, 96, device=DEV), fmt=ops.FMT_H8)
+    w = ops.split_planes(torch.randn(64, 96, device=DEV), fmt=ops.FMT_H8, weight=True)
+    out = torch.empty(128, 64, device=DEV)
+    with pytest.raises(RuntimeError):     # K % 64 != 0
+        ops.gemm(a, w, out)
+    with pytest.raises(RuntimeError):     # operand formats differ
+        ops.gemm(ops.split_planes(torch.randn(128, 128, device=DEV)), ops.split_planes(torch.randn(64, 128, device=DEV), fmt=ops.FMT_H8, weight=True), out)
+    with pytest.raises(RuntimeError):     # activation-ordered planes as W
+        ops.gemm(ops.split_planes(torch.randn(128, 128, device=DEV), fmt=ops.FMT_H8), ops.split_planes(torch.randn(64, 128, device=DEV), fmt=ops.FMT_H8), out)
+
+
+@pytest.mark.parametrize("rows,C", [(96, 64), (300, 1024), (64, 96), (50, 100), (33, 1280)])
+def test_layernorm_h8_planes(ops, rows, C):
+    x = torch.randn(rows, C, generator=g(50)) * 2 + 0.3
+    w, b = torch.randn(C, generator=g(51)), torch.randn(C, generator=g(52))
+    y = F.layer_norm(x, (C,), w, b, 1e-6)
+    p = ops.alloc_planes(rows, C, DEV, zero=True, fmt=ops.FMT_H8)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out_planes=p)
+    got = planes_to_float(p).cpu()
+    assert ((got - y).abs() <= y.abs() * 2 ** -12 + 1e-5).all()
+    # bit-identical to splitting the fp32 LayerNorm output of the same kernel
+    yk = torch.empty(rows, C, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out=yk)
+    p2 = ops.split_planes(yk, fmt=ops.FMT_H8)
+    assert torch.equal(p.p[:, :2 * ops.pad32(C)].cpu().view(torch.uint8).view(rows, -1, 128)[:, :C // 32], p2.p.cpu().view(torch.uint8).view(rows, -1, 128)[:, :C // 32])

@@ -28,13 +28,15 @@ def worker():
     dev = "cuda:0"
     res = []
     for (label, M, N, K, b, act, outk, resid) in SHAPES:
-        a = ops.split_planes(torch.randn(b * M, K, device=dev), kpad=K)
-        w = ops.split_planes(torch.randn(b * N, K, device=dev) / K ** 0.5)
-        w = ops.Planes(w.p, N, K, w.kpad)
+        h8 = os.environ.get("MMSA_ABLATE_FMT") == "h8" and K % 64 == 0   # operand format (random normal data either way: the clock the chip holds depends on the data)
+        fmt = ops.FMT_H8 if h8 else ops.FMT_B3
+        a = ops.split_planes(torch.randn(b * M, K, device=dev), kpad=K, fmt=fmt)
+        w = ops.split_planes(torch.randn(b * N, K, device=dev) / K ** 0.5, fmt=fmt, weight=h8)
+        w = ops.Planes(w.p, N, K, w.kpad, fmt, h8)
         bias = torch.randn(b * N, device=dev)
         kw = {}
         if outk == "P":
-            op = ops.alloc_planes(b * M, N, dev)
+            op = ops.alloc_planes(b * M, N, dev, fmt=fmt)
             kw.update(out_planes=op, stride_cp=M * 2 * op.kpad)
         else:
             c = torch.randn(b * M, N, device=dev)
