@@ -86,7 +86,7 @@ int mmsa_ms_deform_attn_backward(const void* value, const int64_t* spatial_shape
  * loc = ref + off/(W_l,H_l), and the sampling gather.  out [N*Lq, ldo]. */
 int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                     const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
-                    uint16_t* out_planes, long ldop /* optional interleaved planes output */, int batch,
+                    uint16_t* out_planes, long ldop /* optional operand planes output */, int out_fmt /* MMSA_FMT_* */, int batch,
                     int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
                     mmsa_stream_t stream);
 
@@ -160,7 +160,7 @@ int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rs
  * gconv: weights [G][k*k][cin_g][cout_g]; replaces AM:87-88,123-124.
  * im2col_nchw: out[(b,ph,pw)][(c,kh,kw)] from NCHW input channels [c0, c0+Cin) (IE:658-663, TC:297-304). */
 int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y, long ldy,
-                     long ystrideB, uint16_t* y_planes, long ldp, long pstrideB /* optional interleaved planes */,
+                     long ystrideB, uint16_t* y_planes, long ldp, long pstrideB /* optional operand planes */, int planes_fmt /* MMSA_FMT_* */,
                      int B, int H, int W, int C, int k, int act,
                      int imgs_per_group /* > 0: image group g = b / imgs_per_group uses w + g*k*k*C, bias + g*C */, mmsa_stream_t stream);
 /* ConvNeXt block front half fused: 7x7 depthwise conv (TC:69-70,102) + LayerNorm over channels (TC:103-106, eps as given) ->

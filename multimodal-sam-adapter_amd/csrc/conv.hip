@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restrict__ x, long ldx, long xstrideB,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, long ldy, long ystrideB,
-                                                          unsigned short* __restrict__ yp, long ldp, long pstrideB,
+                                                          unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
                                                           int B, int H, int W, int C, int k, int act) {
   // one thread per (pixel, 4 channels); blockIdx.y = image row (b*H + h): 32-bit index arithmetic only
   const int c4n = C >> 2;
@@ -40,13 +40,7 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
     acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
     const long oo = (long)b * ystrideB + ((long)hh * W + ww) * ldy + c;
     if (y) *reinterpret_cast<float4*>(y + oo) = acc;
-    if (yp) {  // ilv planes
-      uint2 h2, l2;
-      split4(acc, h2, l2);
-      unsigned short* q_ = yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp + ilv(c);
-      *reinterpret_cast<uint2*>(q_) = h2;
-      *reinterpret_cast<uint2*>(q_ + 32) = l2;
-    }
+    if (yp) store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);   // operand planes, either format
   }
 }
 
@@ -125,8 +119,9 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
 }
 
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
-                                float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB,
+                                float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB, int yp_fmt,
                                 int B, int H, int W, int C, int k, int act, int imgs_per_group, hipStream_t stream) {
+  MMSA_CHECK_ARG(yp_fmt == MMSA_FMT_B3 || yp_fmt == MMSA_FMT_H8, "dwconv_nhwc: bad output plane format %d", yp_fmt);
   MMSA_CHECK_ARG(x && w && (y || yp) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
   MMSA_CHECK_ARG(imgs_per_group >= 0 && (imgs_per_group == 0 || B % imgs_per_group == 0), "dwconv_nhwc: bad image grouping");
   MMSA_CHECK_ARG(!yp || ((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0 && (pstrideB & 63) == 0), "dwconv_nhwc: bad output planes");
@@ -141,7 +136,7 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   }
   MMSA_CHECK_ARG(imgs_per_group == 0 || imgs_per_group == B, "dwconv_nhwc: image groups are implemented by the tiled 7x7 kernel only");
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
-  hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, B, H, W, C, k, act);
+  hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, k, act);
   MMSA_CHECK_LAUNCH("dwconv_nhwc");
   return MMSA_OK;
 }

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void msda_kernel(
     const float* __restrict__ raw, long ldraw,  // FUSED: [N*Lq, M*L*P*2 (offsets) + M*L*P (logits)]
     const float* __restrict__ ref,   // FUSED: [Lq,2] reference points (x,y) in [0,1]
     float* __restrict__ out, long ldo,
-    unsigned short* __restrict__ op, long ldop,
+    unsigned short* __restrict__ op, long ldop, int op_fmt,
     int N, int S, int M, int D, int L, int Lq, int P) {
   const int d4 = D >> 2;                        // lanes per (q, m) pair
   // 32-bit index arithmetic (N*Lq*M*d4 < 2^32, checked by the launcher): the four 64-bit div/mod of the first version
@@ -91,13 +91,7 @@ __global__ __launch_bounds__(256) void msda_kernel(
     }
   }
   if (out) *reinterpret_cast<float4*>(out + bq * ldo + (long)m * D + c) = acc;
-  if (op) {  // ilv planes
-    uint2 hh, ll;
-    split4(acc, hh, ll);
-    unsigned short* q_ = op + bq * ldop + ilv(m * D + c);
-    *reinterpret_cast<uint2*>(q_) = hh;
-    *reinterpret_cast<uint2*>(q_ + 32) = ll;
-  }
+  if (op) store_planes4(op + bq * ldop, m * D + c, acc, op_fmt);   // operand planes for output_proj, either format
 }
 
 
@@ -294,7 +288,7 @@ extern "C" int mmsa_ms_deform_attn_forward(const void* value, const int64_t* spa
   const int bs = msda_block(channels);
   hipLaunchKernelGGL(msda_kernel<false>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, (const float*)value, spatial_shapes,
                      level_start_index, (const float*)sampling_loc, (const float*)attn_weight, nullptr, 0L, nullptr, (float*)out,
-                     (long)num_heads * channels, nullptr, 0L, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
+                     (long)num_heads * channels, nullptr, 0L, MMSA_FMT_B3, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   MMSA_CHECK_LAUNCH("ms_deform_attn_forward");
   return MMSA_OK;
 }
@@ -345,9 +339,10 @@ extern "C" int mmsa_ms_deform_attn_backward(const void* value, const int64_t* sp
 // as produced by AM:397-431).
 extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
-                               unsigned short* out_p, long ldop,
+                               unsigned short* out_p, long ldop, int out_fmt,
                                int batch, int spatial_size, int num_heads, int channels, int num_levels,
                                int num_query, int num_point, hipStream_t stream) {
+  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "msda_fused: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && ref_points && (out || out_p), "msda_fused: null pointer");
   MMSA_CHECK_ARG(!out_p || (ldop >= 2L * num_heads * channels && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
                  "msda_fused: bad output planes");
@@ -361,7 +356,7 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
   MMSA_CHECK_ARG(threads < (1L << 31), "msda_fused: problem too large for the 32-bit index arithmetic");
   const int bs = msda_block(channels);
   hipLaunchKernelGGL(msda_kernel<true>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, value, spatial_shapes,
-                     level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, batch, spatial_size,
+                     level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, out_fmt, batch, spatial_size,
                      num_heads, channels, num_levels, num_query, num_point);
   MMSA_CHECK_LAUNCH("msda_fused");
   return MMSA_OK;

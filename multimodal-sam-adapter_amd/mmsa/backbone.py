@@ -182,8 +182,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
 
     # GEMM sites whose operands travel in the h8 format (ops.Planes: fp16 hi + e5m2 cross-term bytes, 2/3 of the matrix-pipe time
     # of the bf16 hi/lo scheme; csrc/common.h has the error analysis, tools/precision_study.py the end-to-end measurement).
-    # "vit" = qkv / proj / lin1 / lin2 of the SAM ViT blocks.  `model.h8_sites = ()` or MMSA_H8=none keeps every site on bf16 hi/lo.
-    H8_DEFAULT = ("vit",)
+    # "vit" = qkv / proj / lin1 / lin2 of the SAM ViT blocks; "inter" = the Linear layers of the injectors / extractors (MSDA
+    # projections, ConvFFN); "up" = the 2x2 transposed conv of the tail.  The TwinConvNeXt / neck GEMMs stay on bf16 hi/lo (the most
+    # error-sensitive part of the path: SURVEY appendix F).  `model.h8_sites = ()` or MMSA_H8=none keeps every site on bf16 hi/lo.
+    H8_DEFAULT = ("vit", "inter", "up")
 
     def _h8_sites(self):
         env = os.environ.get("MMSA_H8")
@@ -356,19 +358,25 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # --- interactions
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
 
+        def ifmt(w2d, site="inter"):   # operand format of one GEMM of a site group: h8 when selected and the contraction length allows it
+            return ops.FMT_H8 if (site in h8_sites and ops.pad32(w2d.shape[1]) % 64 == 0) else ops.FMT_B3
+
+        def iplanes(w2d, site="inter"):
+            return planes(w2d, fmt=ifmt(w2d, site))
+
         def pack_msda(b):
             w = torch.cat([sd[b + "sampling_offsets.weight"], sd[b + "attention_weights.weight"]], 0)
             bb = torch.cat([sd[b + "sampling_offsets.bias"], sd[b + "attention_weights.bias"]], 0)
-            return dict(oa=planes(w), oa_b=bb.contiguous(), val=planes(sd[b + "value_proj.weight"]), val_b=sd[b + "value_proj.bias"],
-                        out=planes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
+            return dict(oa=iplanes(w), oa_b=bb.contiguous(), val=iplanes(sd[b + "value_proj.weight"]), val_b=sd[b + "value_proj.bias"],
+                        out=iplanes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
 
         def pack_extractor(b):
             dw = sd[b + "ffn.dwconv.dwconv.weight"]
             return dict(qnw=sd[b + "query_norm.weight"], qnb=sd[b + "query_norm.bias"], fnw=sd[b + "feat_norm.weight"],
                         fnb=sd[b + "feat_norm.bias"], attn=pack_msda(b + "attn."),
-                        fc1=planes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
+                        fc1=iplanes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
                         dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
-                        fc2=planes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
+                        fc2=iplanes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
                         ffw=sd[b + "ffn_norm.weight"], ffb=sd[b + "ffn_norm.bias"])
 
         pk["inter"] = []
@@ -384,7 +392,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             pk["inter"].append(it)
         # --- tail: ConvTranspose2d(D,D,2,2) weight [Cin, Cout, 2, 2] -> rows (i,j,co), K = ci  (BK:55,324)
         up = sd["up.weight"]
-        pk["up"] = planes(up.permute(2, 3, 1, 0).reshape(4 * D, D))
+        pk["up"] = iplanes(up.permute(2, 3, 1, 0).reshape(4 * D, D), "up")
         pk["up_b"] = sd["up.bias"].repeat(4).contiguous()
         pk["bn"] = []
         for i in range(1, 5):
@@ -547,7 +555,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         if c1_ready is not None:
             torch.cuda.current_stream().wait_event(c1_ready)
         outs = []
-        c2p = ws.planes("up_a", B * n2, D)
+        c2p = ws.planes("up_a", B * n2, D, fmt=pk["up"].fmt)
         for bi in range(B):
             ops.split_planes(cbuf[bi * Nc:bi * Nc + n2], kpad=D, out=c2p.rows(bi * n2, (bi + 1) * n2))
         ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=n2 * 2 * D,
@@ -612,30 +620,31 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.gemm(fn, ap["val"], val, bias=ap["val_b"])
         raw = ws.get("msda_raw", B * Lq, ap["oa"].n)
         ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"])
-        samp = ws.planes("msda_s", B * Lq, dv)
+        samp = ws.planes("msda_s", B * Lq, dv, fmt=ap["out"].fmt)
         ops.msda_fused(val, ss, lsi, raw, ref, None, B, S, M, dv // M, L, Lq, Pn, out_planes=samp)
         ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale)
 
     def _injector(self, ip, x_in, x_out, c, geo, B, T, Nc):  # AM:525-542
         ws, D = self._ws, self.cfg["embed_dim"]
-        qn = ws.planes("inj_qn", B * T, D)
-        fn = ws.planes("inj_fn", B * Nc, D)
+        qn = ws.planes("inj_qn", B * T, D, fmt=ip["attn"]["oa"].fmt)
+        fn = ws.planes("inj_fn", B * Nc, D, fmt=ip["attn"]["val"].fmt)
         ops.layernorm(x_in, ip["qnw"], ip["qnb"], 1e-6, out_planes=qn)
         ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
         self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"])
 
     def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
         ws, D = self._ws, self.cfg["embed_dim"]
-        qn = ws.planes("inj_fn", B * Nc, D)
-        fn = ws.planes("inj_qn", B * T, D)
+        qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["attn"]["oa"].fmt)
+        fn = ws.planes("inj_qn", B * T, D, fmt=ep["attn"]["val"].fmt)
         ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
         ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, out_planes=fn)
         self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
+        qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["fc1"].fmt)
         ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, out_planes=qn)
         hid = ep["fc1"].n
         hp = ep["fc2"].kpad  # K of fc2 padded to a multiple of 32; pad columns stay zero
         h1 = ws.get("ffn_h1", B * Nc, hid)
-        h2f = ws.planes(f"ffn_h2_{hp}", B * Nc, hp, zero=True)
+        h2f = ws.planes(f"ffn_h2_{hp}", B * Nc, hp, zero=True, fmt=ep["fc2"].fmt)
         ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
         off = 0
         for (hh, wwd) in ((H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)):  # AM:462-470 token split 16n/4n/n

@@ -265,7 +265,8 @@ def msda_fused(value2d, spatial_shapes, level_start_index, raw, ref_points, out,
     if out_planes is not None:
         pp, _, _, ldp = out_planes.mat("out planes")
     lib.call("mmsa_msda_fused", pv, _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64), pr, ldraw,
-             _chk(ref_points), po, ldo, pp, ldp, batch, spatial, heads, d, levels, lq, points, _stream())
+             _chk(ref_points), po, ldo, pp, ldp, out_planes.fmt if out_planes is not None else FMT_B3,
+             batch, spatial, heads, d, levels, lq, points, _stream())
     return out if out is not None else out_planes
 
 
@@ -380,7 +381,8 @@ def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=N
     xs = h * wd * ldx if xstride_b is None else xstride_b
     ys = h * wd * ldo if ystride_b is None else ystride_b
     ps = h * wd * ldp if pstride_b is None else pstride_b
-    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, b, h, wd, c, k, ACT[act], imgs_per_group, _stream())
+    lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, out_planes.fmt if out_planes is not None else FMT_B3,
+             b, h, wd, c, k, ACT[act], imgs_per_group, _stream())
     return out if out is not None else out_planes
 
 
