@@ -314,13 +314,16 @@ def main():
             mj = json.load(open(mfile))
             mfma = {"gemm_family_mfma_util_pct": round(mj["gemm_family"]["mfma_util_pct"], 1), "gemm_family_mfma_tflops_counted": round(mj["gemm_family"]["mfma_tflops"], 1),
                     "whole_step_mfma_util_pct": round(mj["whole_step"]["mfma_util_pct"], 1), "whole_step_mfma_tflops_counted": round(mj["whole_step"]["mfma_tflops"], 1),
-                    "source": f"profiles/{os.path.basename(mfile)}: rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{{BF16,F32}} passes of this workload"}
-        roofline = {"bound": "mfma", "kernel": "split3 GEMM (gemm_v2_kernel + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
+                    "source": f"profiles/{os.path.basename(mfile)}: rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{{BF16,F16,F8,F32}} passes of this workload"}
+        roofline = {"bound": "mfma", "kernel": "split-operand GEMM (gemm_v2_kernel bf16 hi/lo and h8 flavours + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                     "compulsory_bytes_per_launch": round(mmsa.ops.collect_gemm_profile.bytes / max(len(prof), 1)),
                     "launches_per_step": len(prof), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
                     "kernel_ms_per_step": round(ms, 3), "mfma_counters": mfma,
-                    "note": "algorithmic 2*M*N*K FLOPs; the kernel issues 3x that on MFMA (bf16 hi/lo split for fp32-level parity)"}
+                    "h8_sites": list(model._h8_sites()),
+                    "note": "algorithmic 2*M*N*K FLOPs against the dense bf16/fp16 MFMA peak; for fp32-level parity every operand is a hi + lo pair: bf16 hi/lo "
+                            "sites issue 3 bf16 MFMAs per algorithmic product, h8 sites 1 fp16 MFMA + the two cross terms on one block-scaled fp8 MFMA at "
+                            "twice the rate (2 units)"}
 
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.config == "vitl1024":
@@ -348,7 +351,7 @@ def main():
             "metric": "images/sec encoder fwd @1024x1024 RGB+LiDAR ViT-L",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3-split MFMA (fp32 accumulate, fp32 activations)", "data": "synthetic",
+            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck, attention); fp32 accumulate, fp32 activations", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else

@@ -37,6 +37,7 @@ struct GemmV2Args {
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;
   int nbm, nbn, ntiles;
+  int tm, tn;  // tile order inside a batch: tm > 0 -> blocks of tm x tn = 32 tiles (see V2_TILE_MN), 0 -> row-major (m-tile, n-tile)
   int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
                // that fills the CUs better: N = 384 gives 3 tiles of 128 (192 tiles on 256 CUs for the ConvNeXt pw2 GEMMs) or 4 of 96 (256 tiles)
   int cp_fmt;  // format of the planes output Cp: MMSA_FMT_B3 (bf16 hi | lo) or MMSA_FMT_H8 (fp16 hi | e5m2 lo, q(hi): common.h), independent of the operands' format
@@ -123,13 +124,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   const int lds_w = wave * WROWS * 128;   // this wave's rows of the W image (2 or 4 instructions)
   const unsigned short *sa0, *sa1, *sa2, *sa3, *sw0, *sw1, *sw2 = nullptr, *sw3 = nullptr;
 
+// Tile index inside a batch -> (m-tile, n-tile).  The 32 workgroups that share an XCD (consecutive logical ids) hold 32 consecutive
+// tile indices at any time; row-major order made those one row of up to 32 n-tiles, i.e. every XCD streamed the WHOLE weight
+// matrix through its L2 per round (counted as fabric traffic: 1.66 x the compulsory bytes over the model's GEMM mix).  Blocked
+// order gives an XCD a tm x tn rectangle (8 x 4 for wide N): tm activation panels + tn weight panels per round.
+#define V2_TILE_MN(r_, mi_, ni_)                                                 \
+  do {                                                                           \
+    if (a.tm > 0) {                                                              \
+      const int blk_ = (r_) >> 5, loc_ = (r_) & 31;                              \
+      const int bpr_ = a.nbn / a.tn;                                             \
+      const int bi_ = blk_ / bpr_, bj_ = blk_ - bi_ * bpr_;                      \
+      const int lm_ = loc_ / a.tn;                                               \
+      mi_ = bi_ * a.tm + lm_;                                                    \
+      ni_ = bj_ * a.tn + (loc_ - lm_ * a.tn);                                    \
+    } else {                                                                     \
+      mi_ = (r_) / a.nbn;                                                        \
+      ni_ = (r_) - mi_ * a.nbn;                                                  \
+    }                                                                            \
+  } while (0)
 #define SET_TILE_SRC(tile_)                                                      \
   do {                                                                           \
     const int t_ = (tile_);                                                      \
     const int per_b_ = a.nbm * a.nbn;                                            \
     const int bz_ = t_ / per_b_;                                                 \
     const int r_ = t_ - bz_ * per_b_;                                            \
-    const int m0_ = (r_ / a.nbn) * V2_BM, n0_ = (r_ % a.nbn) * a.bn;             \
+    int tmi_, tni_;                                                              \
+    V2_TILE_MN(r_, tmi_, tni_);                                                  \
+    const int m0_ = tmi_ * V2_BM, n0_ = tni_ * a.bn;                             \
     const int ab_ = m0_ + wave * 32 + drow, wb_ = n0_ + wave * WROWS + drow;     \
     const unsigned short* ap_ = a.Ap + (long)bz_ * a.strideA;                    \
     const unsigned short* wp_ = a.Wp + (long)bz_ * a.strideW;                    \
@@ -408,7 +429,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       const int per_b = a.nbm * a.nbn;
       const int bz = tile / per_b;
       const int rt = tile - bz * per_b;
-      const int m0 = (rt / a.nbn) * V2_BM, n0 = (rt % a.nbn) * a.bn;
+      int tmi, tni;
+      V2_TILE_MN(rt, tmi, tni);
+      const int m0 = tmi * V2_BM, n0 = tni * a.bn;
       const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
       const float* colscale = a.colscale ? a.colscale + (long)bz * a.strideBias : nullptr;   // per-column vectors share the batch stride
       const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
@@ -703,6 +726,21 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
       a.bn = 96;
       a.nbn = nbn96;
       a.ntiles = (int)t96;
+    }
+  }
+  // blocked tile order (V2_TILE_MN): among the rectangles tm x tn = 32 that tile the (m-tile, n-tile) grid exactly, the one that
+  // makes the XCDs fetch the fewest operand bytes -- every activation panel is fetched once per block column, every weight panel
+  // once per block row: (nbn / tn) * M * K + (nbm / tm) * N * K; row-major order when none fits.  MMSA_GEMM_ROWMAJOR=1 forces
+  // row-major (A/B aid).  Results do not depend on the order.
+  static const bool rowmajor = getenv("MMSA_GEMM_ROWMAJOR") != nullptr;
+  a.tm = a.tn = 0;
+  if (!rowmajor) {
+    double best = 0.0;
+    for (int tn = 1; tn <= 32; tn <<= 1) {
+      const int tm = 32 / tn;
+      if (a.nbn % tn != 0 || a.nbm % tm != 0) continue;
+      const double cost = (double)(a.nbn / tn) * M + (double)(a.nbm / tm) * N;
+      if (a.tm == 0 || cost < best) { best = cost; a.tm = tm; a.tn = tn; }
     }
   }
   const int grid = a.ntiles < g_num_cus * wg_per_cu ? a.ntiles : g_num_cus * wg_per_cu;   // resident workgroups: one per CU (144 KiB LDS) or two (64 KiB each)

@@ -19,27 +19,35 @@ def load(sub, names):
 
 
 dur, val = load("util", ("MfmaUtil",))
-per = collections.defaultdict(lambda: {"launches": 0, "ns": 0, "util_ns": 0.0, "mfma_flop": 0.0, "ops_ns": 0})
+per = collections.defaultdict(lambda: {"launches": 0, "ns": 0, "util_ns": 0.0, "mfma_flop": 0.0, "ops_ns": 0, "by_type": collections.defaultdict(float)})
 for k, (name, ns) in dur.items():
     if k in val and "MfmaUtil" in val[k]:
         p = per[name]; p["launches"] += 1; p["ns"] += ns; p["util_ns"] += val[k]["MfmaUtil"] * ns
-dur2, val2 = load("ops", ("SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"))
+MOPS = ("SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_F8", "SQ_INSTS_VALU_MFMA_MOPS_F32")
+dur2, val2 = load("ops", MOPS)
 for k, (name, ns) in dur2.items():
     if k in val2:
         per[name]["mfma_flop"] += 512.0 * sum(val2[k].values()); per[name]["ops_ns"] += ns
+        for c, v in val2[k].items():
+            per[name]["by_type"][c.rsplit("_", 1)[1]] += 512.0 * v
 
 
 def fold(keys):
     ns = sum(per[k]["ns"] for k in keys); ons = sum(per[k]["ops_ns"] for k in keys)
     fl = sum(per[k]["mfma_flop"] for k in keys)
+    bt = collections.defaultdict(float)
+    for k in keys:
+        for c, v in per[k]["by_type"].items():
+            bt[c] += v
     return {"launches": sum(per[k]["launches"] for k in keys), "ms": ns / 1e6, "mfma_util_pct": sum(per[k]["util_ns"] for k in keys) / max(ns, 1),
-            "mfma_flop_counted": fl, "mfma_tflops": fl / max(ons, 1) / 1e3}
+            "mfma_flop_counted": fl, "mfma_tflops": fl / max(ons, 1) / 1e3, "mfma_flop_by_type": dict(bt)}
 
 
 gem = [k for k in per if "gemm" in k]
 res = {"note": "one eager step of bench.py (ViT-L 1024^2 RGB+LiDAR, batch 2, encoder + head) under rocprofv3 --pmc; kernels run serialised "
                "under counter collection, so ms is the sum of kernel durations, not the step time; util is duration-weighted MfmaUtil; "
-               "mfma_flop_counted = 512 x (MOPS_BF16 + MOPS_F32), i.e. 3 x the algorithmic flops for split3 contractions",
+               "mfma_flop_counted = 512 x (MOPS_BF16 + MOPS_F16 + MOPS_F8 + MOPS_F32): 3 x the algorithmic flops for bf16 hi/lo contractions, "
+               "1 (F16) + 2 (F8, at twice the rate) for h8 contractions",
        "whole_step": fold(list(per)), "gemm_family": fold(gem),
        "per_kernel": {k: fold([k]) for k in sorted(per, key=lambda k: -per[k]["ns"])[:25]}}
 json.dump(res, open(f"profiles/{tag}_mfma_util.json", "w"), indent=1)

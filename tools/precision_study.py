@@ -54,6 +54,8 @@ def patch(model, pred, mode):
 GROUPS = {
     "vit": lambda n: n.startswith("blocks."),
     "vit+inter": lambda n: n.startswith("blocks.") or n.startswith("interactions."),
+    "cnx": lambda n: n.startswith("spm.twin_conv."),
+    "all-linear": lambda n: True,
 }
 
 if __name__ == "__main__":
@@ -64,8 +66,11 @@ if __name__ == "__main__":
     x = make_input(cfg)
     with torch.no_grad():
         ref, _ = base(x)
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(GROUPS)
     for grp, pred in GROUPS.items():
-        for mode in ("split3", "h16x8_e5m2", "h16x8_e5m2t", "h16x8_e4m3", "h16"):
+        if grp not in only:
+            continue
+        for mode in ("split3", "h16x8_e5m2", "h16x8_e5m2t"):
             m = R.OracleEncoder(**cfg["kwargs"]); m.load_state_dict(sd); m.eval()
             n = patch(m, pred, mode)
             with torch.no_grad():
