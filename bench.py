@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed graph-vs-eager / golden-probe checks")
     ap.add_argument("--default-init", action="store_true", help="A/B aid: default-init weights instead of the seeded live generator")
     ap.add_argument("--no-head", action="store_true", help="time the encoder forward only (no decode head, no all-gather)")
+    ap.add_argument("--chains", type=int, default=int(os.environ.get("MMSA_CHAINS", "2")),
+                    help="the step's batch as this many independent sub-batch chains on concurrent HIP streams (mmsa.Chains); 1 = one chain")
     return ap.parse_args()
 
 
@@ -226,12 +228,32 @@ def main():
             dt = float(t.item())
         return dt
 
-    replay, local_out, graphed = capture(local_step)
-    graph_feats = feats[0]                 # the four output maps the captured graph writes (fixed addresses)
+    nch = a.chains if (a.chains > 1 and a.batch % a.chains == 0 and not a.no_graph) else 1
+    chains = None
+    if nch > 1:
+        # the batch as `nch` concurrent chains (mmsa/chains.py): same kernels, same results, the GEMM phases of the chains overlap
+        for _ in range(max(a.warmup, 1)):
+            local_out = local_step()       # also the eager reference of the verification below
+        torch.cuda.synchronize()
+        chains = mmsa.Chains(model, head, n=nch).capture(x)
+        replay, graphed = chains.replay, True
+        replay()
+        torch.cuda.synchronize()
+        if head is not None:
+            local_out = chains.logits
+        graph_feats = None                 # per-chain maps: chains.feats
+    else:
+        replay, local_out, graphed = capture(local_step)
+        graph_feats = feats[0]                 # the four output maps the captured graph writes (fixed addresses)
     gathered = [None]
 
     def run():
-        replay()
+        if chains is not None:
+            # single rank: the chains free-run through the K timed steps (no cross-chain join per step; the closing synchronize
+            # covers them); with the all-gather of a multi-rank run the step joins its chains first
+            chains.replay(join=head is not None and use_dist)
+        else:
+            replay()
         if head is not None and use_dist:   # the pipeline's only exchange step; outside the graph (RCCL owns its stream)
             gathered[0] = allgather_logits(local_out)
 
@@ -247,13 +269,20 @@ def main():
         verified = {}
         replay()
         torch.cuda.synchronize()
-        got_out = local_out.clone()
-        got_f = [f.clone() for f in graph_feats]
+        got_out = local_out.clone() if head is not None else None
         if graphed:
-            e_out = local_step()
+            e_out = local_step()           # eager, ONE chain over the whole batch, full grids
             torch.cuda.synchronize()
-            same = bool(torch.equal(e_out, got_out)) and all(bool(torch.equal(u, v)) for u, v in zip(feats[0], got_f))
+            same = True
+            if head is not None:
+                same = bool(torch.equal(e_out, got_out))
+            for k in range(4):             # map by map: f1 alone is 268 MB per image
+                gk = graph_feats[k] if chains is None else torch.cat([chains.feats[c][k] for c in range(nch)], 0)
+                same = same and bool(torch.equal(feats[0][k], gk))
+                del gk
             verified["graph_replay_equals_eager_bitwise"] = same
+            if nch > 1:
+                verified["chains"] = f"{nch} concurrent chains of {a.batch // nch} image(s) == one eager chain of {a.batch}, bit for bit"
             if not same:
                 raise SystemExit("[bench] the HIP-graph replay does not reproduce the eager step bit for bit")
         gfile = os.path.join(ROOT, "tests", "golden", f"model_{a.config}.npz")
@@ -266,8 +295,8 @@ def main():
                 replay()
                 torch.cuda.synchronize()
                 worst = 0.0
-                for i, f in enumerate(graph_feats):
-                    f0 = f[0]
+                for i in range(4):
+                    f0 = (graph_feats[i] if chains is None else chains.feats[0][i])[0]
                     pi = probe_index(f0.numel(), 2048, seed=100 + i).to(dev)
                     got = f0.flatten()[pi].double().cpu()
                     ref = torch.from_numpy(g[f"f{i+1}_probe"]).double()
@@ -284,7 +313,11 @@ def main():
 
     encoder_only = None
     if head is not None and world == 1:
-        ereplay, _, _ = capture(encoder_step)
+        if nch > 1:
+            ech = mmsa.Chains(model, None, n=nch).capture(x)
+            ereplay = lambda: ech.replay(join=False)   # noqa: E731
+        else:
+            ereplay, _, _ = capture(encoder_step)
         edt = timed(ereplay)
         encoder_only = {"value": round(a.batch * a.steps / edt, 3), "unit": "images/s", "ms_per_step": round(edt / a.steps * 1e3, 3)}
 
@@ -358,6 +391,7 @@ def main():
                                 "encoder forward + SegformerHead logits [B,25,H/4,W/4] + all-gather of logits across ranks",
                        "weights": "default init" if a.default_init else "seeded live generator (tests/weights.py), every parameter / buffer non-trivial",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graphed),
+                       "chains_per_gpu": nch,
                        "collective": ("one RCCL all_gather_into_tensor of the logits per step" if (head is not None and use_dist)
                                       else "none (single rank)" if head is not None else "none (encoder only)")},
             "verified": verified,

@@ -100,14 +100,16 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * A is EITHER fp32 (`A`, split to hi/lo while staged) OR interleaved activation planes (`Ap`, written by the
  * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
  * The result goes to fp32 `C`, to planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both.
- * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`. */
+ * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`.
+ * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
+ * its share of the CUs); 0 = all CUs.  Results do not depend on it. */
 int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      const uint16_t* Wp, long strideW,
                      const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,
                      long strideR, int resid_mod, float beta, float* C, long ldc, long strideC,
                      uint16_t* Cp, long ldcp, long strideCp, int M, int N, int K,
                      int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt,
-                     mmsa_stream_t stream);
+                     int max_grid, mmsa_stream_t stream);
 
 /* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
  * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows. */

@@ -276,7 +276,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         float* C, long ldc, long strideC,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, hipStream_t stream);
+                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream);
 
 // ---- tiny problems (CoordinateAttention's 1x1 convs on pooled maps, AM:187-201: M = B*(h+w) <= ~1000 rows, N or K of 8..48): a
 // 128 x 128 MFMA tile would be one or two workgroups walking K alone (64 us for M = 128, N = 48, K = 1536).  Here one wave owns
@@ -332,7 +332,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 float* C, long ldc, long strideC,
                                 unsigned short* Cp, long ldcp, long strideCp,
                                 int M, int N, int K, int batch, int act, float alpha,
-                                int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, hipStream_t stream) {
+                                int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
   const bool ap = Ap != nullptr;
   MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && (cp_fmt == MMSA_FMT_B3 || cp_fmt == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
   MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 operands need A planes and K %% 64 == 0 (K=%d)", K);
@@ -386,7 +386,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow)))   // h8 operands: only the LDS-DMA kernel reads them
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
-                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, stream);
+                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream);
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
   const bool gen = out_mode != 0 || resid_mod > 0;
   if (ap) {

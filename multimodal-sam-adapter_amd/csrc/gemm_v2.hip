@@ -668,7 +668,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         float* C, long ldc, long strideC,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, hipStream_t stream) {
+                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
   GemmV2Args a;
   a.Ap = Ap; a.lda = lda; a.strideA = strideA;
   a.Wp = Wp; a.strideW = strideW;
@@ -713,13 +713,17 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1)
 #undef V2_ATTR
   }
+  // max_grid > 0: at most that many persistent workgroups -- a caller that runs independent chains on concurrent streams gives each
+  // GEMM its share of the CUs, so that the kernels of two chains are resident together (one 144 KiB workgroup fits a CU).  The tile
+  // shape below is chosen for THAT many CUs (the value of an output element does not depend on the shape of its tile).
+  const int cus = (max_grid > 0 && max_grid < g_num_cus) ? max_grid : g_num_cus;
   // 96-column tiles when they occupy the CUs better: rounds(tiles) x relative tile cost (0.75) against rounds of 128-column tiles.
   // fp32 output only (the planes epilogue writes whole 64-column strips) and no pixel-shuffle / broadcast-residual store.
   if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96) {
     static const bool no96 = getenv("MMSA_GEMM_NO96") != nullptr;   // A/B aid
     const int nbn96 = cdiv(N, 96);
     const long t96 = (long)a.nbm * nbn96 * batch;
-    const int slots = g_num_cus * wg_per_cu;
+    const int slots = cus * wg_per_cu;
     const double c128 = (double)cdiv(a.ntiles, slots), c96 = 0.75 * (double)cdiv(t96, slots);
     // same number of column tiles -> nothing to gain from narrower ones (ragged last tile aside)
     if (!no96 && c96 < c128 - 1e-9) {
@@ -743,7 +747,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
       if (a.tm == 0 || cost < best) { best = cost; a.tm = tm; a.tn = tn; }
     }
   }
-  const int grid = a.ntiles < g_num_cus * wg_per_cu ? a.ntiles : g_num_cus * wg_per_cu;   // resident workgroups: one per CU (144 KiB LDS) or two (64 KiB each)
+  const int grid = a.ntiles < cus * wg_per_cu ? a.ntiles : cus * wg_per_cu;   // resident workgroups: one per CU (144 KiB LDS) or two (64 KiB each)
   const bool gen = out_mode != 0 || resid_mod > 0;
   static const bool pp = getenv("MMSA_GEMM_PP") ? atoi(getenv("MMSA_GEMM_PP")) != 0 : true;   // 0: every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \

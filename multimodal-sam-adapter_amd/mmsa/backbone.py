@@ -8,6 +8,7 @@ activation checkpointing are identities, SyncBatchNorm uses running statistics.
 All arithmetic is done by hand-written HIP kernels through the C ABI (mmsa.ops); torch allocates device buffers
 and provides the stream.  Activations are fp32, token-major (NHWC) end to end; only the four outputs are written
 NCHW by the fused tail kernel.  There is no CPU / PyTorch fallback."""
+import contextlib
 import math
 
 import os
@@ -72,6 +73,16 @@ class _Tagged:
 
     def planes(self, name, *a, **k):
         return self.ws.planes(self.tag + name, *a, **k)
+
+    @property
+    def device(self):
+        return self.ws.device
+
+    def poison(self):
+        return self.ws.poison()
+
+    def nbytes(self):
+        return self.ws.nbytes()
 
 
 class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
@@ -192,6 +203,20 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         if env is not None:
             return tuple(t for t in env.split(",") if t and t != "none")
         return tuple(getattr(self, "h8_sites", self.H8_DEFAULT))
+
+    @contextlib.contextmanager
+    def chain(self, index):
+        """Everything forward() does inside this context uses chain `index`'s private scratch buffers (a tagged view of the
+        workspace), so that several sub-batches can be in flight on concurrent streams with ONE set of packed weights
+        (mmsa.chains).  Results are those of a plain forward()."""
+        base = self._ws
+        if base is None:
+            raise RuntimeError("mmsa: run one forward() before opening a chain (workspace not created yet)")
+        self._ws = _Tagged(base, f"chain{index}_")
+        try:
+            yield self
+        finally:
+            self._ws = base
 
     # ------------------------------------------------------------------ packing (one-time weight preprocessing)
     @torch.no_grad()
@@ -564,9 +589,11 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # token-major as interleaved planes and attached to the returned tensor (`_mmsa_planes`), so that mmsa.SegformerHead
         # feeds its first 1x1 convs without the NCHW -> planes transposition of 0.7 GB per step
         emit = bool(getattr(self, "emit_planes", False)) and D % 32 == 0
-        if not hasattr(self, "_planes_gen"):
-            self._planes_gen = [0]
-        self._planes_gen[0] += 1     # the f*_out planes of earlier calls are overwritten below: their holders see live() == False
+        ctag = getattr(self._ws, "tag", "")   # "" or the chain's workspace tag (mmsa.chains): every chain has its own output planes
+        if not hasattr(self, "_planes_gens"):
+            self._planes_gens = {}
+        pgen = self._planes_gens.setdefault(ctag, [0])
+        pgen[0] += 1     # the f*_out planes of earlier calls (of this chain) are overwritten below: their holders see live() == False
         outs = []
         for k, (src, cs, (hh, wwd)) in enumerate(((c1, (H // 4) * (W // 4) * D, (H // 4, W // 4)), (cbuf, Nc * D, (H // 8, W // 8)),
                                                   (cbuf[n2:], Nc * D, (Hp, Wp)), (cbuf[n2 + n3:], Nc * D, (H // 32, W // 32)))):
@@ -574,7 +601,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             fpl = ws.planes(f"f{k + 1}_out", B * hh * wwd, D) if emit else None
             ops.tail_fuse(src, cs, xs[k + 1], *pk["bn"][k], f, B, hh, wwd, Hp, Wp, out_planes=fpl)
             if emit:
-                f._mmsa_planes = fpl.stamp(self._planes_gen)
+                f._mmsa_planes = fpl.stamp(pgen)
             outs.append(f)
         f1, f2, f3, f4 = outs
         return [f1, f2, f3, f4]
@@ -670,9 +697,12 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         main = torch.cuda.current_stream()
         multi = getattr(self, "multistream", True)
         if multi:
-            if getattr(self, "_side", None) is None or len(self._side) < 4 or self._side[0].device != x.device:
-                self._side = [torch.cuda.Stream(device=x.device) for _ in range(4)]
-            s_neck = self._side[0:4]
+            if not hasattr(self, "_sides"):
+                self._sides = {}
+            skey = (getattr(self._ws, "tag", ""), x.device)   # concurrent chains (mmsa.chains) fork onto their own side streams
+            if skey not in self._sides:
+                self._sides[skey] = [torch.cuda.Stream(device=x.device) for _ in range(4)]
+            s_neck = self._sides[skey]
         else:   # profiling aid: everything on the current stream
             s_neck = [main] * 4
         # --- TwinConvNeXt (TC:445-476): the rgb and the auxiliary stream are ONE chain of batched kernels (batch index =

@@ -111,6 +111,7 @@ class SegformerHead(nn.Module):
         return pk
 
     def _buf(self, name, shape, dtype=torch.float32, dev=None):
+        name = getattr(self, "buf_tag", "") + name     # mmsa.chains: one set of scratch buffers per concurrent chain
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
             t = torch.zeros(shape, dtype=dtype, device=dev)

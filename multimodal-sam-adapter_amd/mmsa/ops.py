@@ -12,6 +12,7 @@ ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
 # When set to a list, every gemm() launch is bracketed by HIP events recorded on the launch stream and
 # (flops, start, stop) is appended; bench.py uses this for the roofline of the dominant kernel.
 GEMM_PROFILE = None
+GEMM_MAX_GRID = 0    # > 0: cap on the persistent workgroups of every gemm() launch (mmsa.chains gives each concurrent chain its share of the CUs)
 GEMM_SHAPES = None   # optional parallel list of (m, n, k, batch, act, has_resid, outputs) per profiled launch (tools/gemm_shapes.py)
 
 
@@ -179,7 +180,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     lib.call("mmsa_gemm_split3", pa, pap, lda, stride_a, w.p.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
-             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, out_planes.fmt if out_planes is not None else FMT_B3, _stream())
+             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, out_planes.fmt if out_planes is not None else FMT_B3, GEMM_MAX_GRID, _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
         nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)

@@ -141,3 +141,36 @@ def test_crop_batch_kernel():
     got = inf._crops(img, chunk, (32, 64))
     want = torch.stack([img[b, :, y1:y2, x1:x2] for b, (y1, x1, y2, x2) in chunk], 0)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("nch", [2, 3])
+def test_concurrent_chains_equal_one_chain_bit_for_bit(models, nch):
+    """mmsa.Chains: the batch as `nch` sub-batches on concurrent streams (own HIP graphs, private scratch buffers, shared packed
+    weights, GEMM grids capped to a share of the CUs) returns, per chain, the bits of a plain forward + head of that sub-batch, replay
+    after replay and for new input contents (bench.py checks the whole ViT-L batch of 2 against one chain of 2 the same way)."""
+    import mmsa
+    cfg, _, _, m, h = models
+    x = make_input(cfg, batch=2 * nch, seed=31).to(DEV)
+    ch = mmsa.Chains(m, h, n=nch).capture(x)
+    for rep in range(3):
+        if rep == 2:
+            x.copy_(make_input(cfg, batch=2 * nch, seed=32).to(DEV))     # the graphs read the caller's buffer
+        logits = ch.replay()
+        torch.cuda.synchronize()
+        for c in range(nch):      # chain c == a plain forward + head of its own slice
+            fs, _ = m(x[2 * c:2 * c + 2])
+            ref = h(fs)
+            torch.cuda.synchronize()
+            assert torch.equal(logits[2 * c:2 * c + 2], ref)
+            for k in range(4):
+                assert torch.equal(ch.feats[c][k], fs[k])
+    assert mmsa.ops.GEMM_MAX_GRID == 0 and getattr(h, "buf_tag", "") == ""      # nothing left switched on
+    enc = mmsa.Chains(m, None, n=nch).capture(x)                               # encoder-only chains
+    feats = enc.replay()
+    torch.cuda.synchronize()
+    for c in range(nch):
+        fs, _ = m(x[2 * c:2 * c + 2])
+        for k in range(4):
+            assert torch.equal(feats[c][k], fs[k])
+    with pytest.raises(RuntimeError):
+        mmsa.Chains(m, None, n=nch).capture(x[:nch + 1])
