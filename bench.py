@@ -248,12 +248,7 @@ def main():
     gathered = [None]
 
     def run():
-        if chains is not None:
-            # single rank: the chains free-run through the K timed steps (no cross-chain join per step; the closing synchronize
-            # covers them); with the all-gather of a multi-rank run the step joins its chains first
-            chains.replay(join=head is not None and use_dist)
-        else:
-            replay()
+        replay()                            # chains: both sub-batch chains of the step, joined into this stream (a step ends before the next starts)
         if head is not None and use_dist:   # the pipeline's only exchange step; outside the graph (RCCL owns its stream)
             gathered[0] = allgather_logits(local_out)
 
@@ -314,8 +309,7 @@ def main():
     encoder_only = None
     if head is not None and world == 1:
         if nch > 1:
-            ech = mmsa.Chains(model, None, n=nch).capture(x)
-            ereplay = lambda: ech.replay(join=False)   # noqa: E731
+            ereplay = mmsa.Chains(model, None, n=nch).capture(x).replay
         else:
             ereplay, _, _ = capture(encoder_step)
         edt = timed(ereplay)

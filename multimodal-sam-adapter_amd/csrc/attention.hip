@@ -450,17 +450,18 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     const int tq = tq_sub[sub];
-    if (tq >= 0) {
+    if constexpr (PL) {
+      // lanes G / G ^ 1 of a query row (lane ^ 16) hold 8 consecutive channels: whole-line stores through the pair exchange (common.h)
+      unsigned short* orow = a.op + ((long)b * T + (tq >= 0 ? tq : 0)) * a.ldo;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        store_planes8_pair<16>(orow, head * HD + 16 * d + 8 * (G >> 1),
+                               make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv), a.ofmt, G & 1, tq >= 0);
+    } else if (tq >= 0) {
       const long oo = ((long)b * T + tq) * a.ldo + head * HD + 4 * G;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const float4 v = make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv);
-        if constexpr (PL) {
-          store_planes4(a.op + ((long)b * T + tq) * a.ldo, head * HD + 4 * G + 16 * d, v, a.ofmt);
-        } else {
-          *reinterpret_cast<float4*>(a.out + oo + 16 * d) = v;
-        }
-      }
+      for (int d = 0; d < DT; ++d)
+        *reinterpret_cast<float4*>(a.out + oo + 16 * d) = make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv);
     }
   }
 }

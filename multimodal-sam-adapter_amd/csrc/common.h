@@ -156,6 +156,28 @@ __device__ __forceinline__ void store_planes4(unsigned short* row, int c, const 
   }
 }
 
+// The same for a PAIR of lanes (lane ^ XOR) that hold columns c8 .. c8+3 (the `odd == false` lane) and c8+4 .. c8+7 (`odd == true`),
+// c8 % 8 == 0: the pair's 8 columns are one 16-byte hi chunk and one 16-byte second chunk of the line, so after exchanging halves the
+// even lane stores the hi chunk and the odd lane the other one -- ONE 16-byte store per lane, and a wave instruction writes whole
+// 128-byte lines (8- and 4-byte stores write every line as several partial-line requests).  Both lanes of a pair must be active and
+// agree on `do_store`.
+template <int XOR>
+__device__ __forceinline__ void store_planes8_pair(unsigned short* row, int c8, const float4 v, int fmt, bool odd, bool do_store) {
+  uint2 mine_hi, mine_x;   // hi chunk half; second-chunk half (bf16: lo values; h8: .x = lo bytes, .y = q(hi) bytes)
+  if (fmt == MMSA_FMT_H8) h8_split4(v, mine_hi, mine_x.x, mine_x.y);
+  else split4(v, mine_hi, mine_x);
+  const uint2 snd = odd ? mine_hi : mine_x;
+  uint2 rcv;
+  rcv.x = __shfl_xor(snd.x, XOR, 64);
+  rcv.y = __shfl_xor(snd.y, XOR, 64);
+  uint4 pk;
+  if (!odd) pk = make_uint4(mine_hi.x, mine_hi.y, rcv.x, rcv.y);
+  else if (fmt == MMSA_FMT_H8) pk = make_uint4(rcv.x, mine_x.x, rcv.y, mine_x.y);
+  else pk = make_uint4(rcv.x, rcv.y, mine_x.x, mine_x.y);
+  const int off = odd ? (fmt == MMSA_FMT_H8 ? h8_lo_off(c8) >> 1 : ilv(c8) + 32) : ilv(c8);
+  if (do_store) *reinterpret_cast<uint4*>(row + off) = pk;
+}
+
 // one element (ragged edges; rare)
 __device__ __forceinline__ void store_planes1(unsigned short* row, int c, float x, int fmt) {
   if (fmt == MMSA_FMT_H8) {

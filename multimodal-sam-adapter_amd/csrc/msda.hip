@@ -91,7 +91,11 @@ __global__ __launch_bounds__(256) void msda_kernel(
     }
   }
   if (out) *reinterpret_cast<float4*>(out + bq * ldo + (long)m * D + c) = acc;
-  if (op) store_planes4(op + bq * ldop, m * D + c, acc, op_fmt);   // operand planes for output_proj, either format
+  if (op) {   // operand planes for output_proj, either format
+    // D % 8 == 0: threads 2j / 2j+1 of a (query, head) group hold 8 consecutive channels: whole-line stores through the lane-pair exchange
+    if ((D & 7) == 0) store_planes8_pair<1>(op + bq * ldop, m * D + (c & ~7), acc, op_fmt, (c >> 2) & 1, true);
+    else store_planes4(op + bq * ldop, m * D + c, acc, op_fmt);
+  }
 }
 
 

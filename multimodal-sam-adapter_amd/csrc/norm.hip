@@ -100,25 +100,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       }
       if (pr) {
         if (pair16) {
-          // C % 8 == 0: lanes 2j / 2j+1 hold channels 8j .. 8j+7 = one 16-byte hi chunk and one 16-byte second chunk of the line
-          // (bf16 planes: the lo values; h8 planes: 8 lo bytes + 8 q(hi) bytes).  The even lane stores the hi chunk, the odd lane
-          // the other: ONE 16-byte store per lane, and a wave instruction writes whole 128-byte lines (8-byte hi / lo stores wrote
-          // every line as two half-lines from two instructions).
-          const bool odd = lane & 1;
-          uint2 mine_hi, mine_x;   // hi chunk half; second-chunk half (bf16: lo values; h8: .x = lo bytes, .y = q(hi) bytes)
-          if (plane_fmt == MMSA_FMT_H8) h8_split4(o, mine_hi, mine_x.x, mine_x.y);
-          else split4(o, mine_hi, mine_x);
-          const uint2 snd = odd ? mine_hi : mine_x;
-          uint2 rcv;
-          rcv.x = __shfl_xor(snd.x, 1, 64);
-          rcv.y = __shfl_xor(snd.y, 1, 64);
-          uint4 pk;
-          if (!odd) pk = make_uint4(mine_hi.x, mine_hi.y, rcv.x, rcv.y);
-          else if (plane_fmt == MMSA_FMT_H8) pk = make_uint4(rcv.x, mine_x.x, rcv.y, mine_x.y);
-          else pk = make_uint4(rcv.x, rcv.y, mine_x.x, mine_x.y);
-          const int c8 = (int)ocol + (c & ~7);
-          const int off = odd ? (plane_fmt == MMSA_FMT_H8 ? h8_lo_off(c8) >> 1 : ilv(c8) + 32) : ilv(c8);
-          if (in) *reinterpret_cast<uint4*>(pr + off) = pk;
+          // C % 8 == 0: lanes 2j / 2j+1 hold channels 8j .. 8j+7: whole-line stores through the lane-pair exchange (common.h)
+          store_planes8_pair<1>(pr, (int)ocol + (c & ~7), o, plane_fmt, lane & 1, in);
         } else if (in) {
           store_planes4(pr, (int)ocol + c, o, plane_fmt);
         }

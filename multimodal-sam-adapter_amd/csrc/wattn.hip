@@ -292,11 +292,11 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
   psum += __shfl_xor(psum, 32, 64);
   const float inv = 1.0f / psum;
   // ---- O[q][16d + 4G .. +3] / sum -> out planes row token(q), columns head*64 + ...  (window_unpartition + crop: IE:534-551)
-  if (live) {
-    unsigned short* orow = a.op + ((long)b * T + tq) * a.ldo;
+  {   // lanes G / G ^ 1 of a query row (lane ^ 16) hold 8 consecutive channels: whole-line stores through the pair exchange (common.h)
+    unsigned short* orow = a.op + ((long)b * T + (live ? tq : 0)) * a.ldo;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
-      store_planes4(orow, head * 64 + 16 * d + 4 * G, make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt);
+      store_planes8_pair<16>(orow, head * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, live);
   }
 }
 
@@ -597,11 +597,11 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       psum += __shfl_xor(psum, 16, 64);
       psum += __shfl_xor(psum, 32, 64);
       const float inv = 1.0f / psum;
-      if (tq_cur >= 0) {
-        unsigned short* orow = a.op + ((long)b_cur * T + tq_cur) * a.ldo;
+      {   // lanes G / G ^ 1 of a query row (lane ^ 16) hold 8 consecutive channels: whole-line stores through the pair exchange (common.h)
+        unsigned short* orow = a.op + ((long)b_cur * T + (tq_cur >= 0 ? tq_cur : 0)) * a.ldo;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
-          store_planes4(orow, head_cur * 64 + 16 * d + 4 * G, make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt);
+          store_planes8_pair<16>(orow, head_cur * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, tq_cur >= 0);
       }
     }
     if (!has_next) break;

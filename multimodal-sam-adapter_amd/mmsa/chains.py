@@ -3,9 +3,10 @@
 Why.  Images are independent in the eval-mode forward, and every GEMM of the path is ONE persistent grid whose
 workgroups all reach their epilogue at the same moment: the chip alternates between k loops (matrix pipe busy, memory idle) and
 epilogues (a store burst at HBM speed, matrix pipe idle) -- DESIGN.md section 4.1.  Two chains that each own half of the CUs
-(`ops.GEMM_MAX_GRID`) run those phases against each other.  Measured on one MI355X, ViT-L 1024^2, batch 2 (tools/split_batch_bench.py):
-one chain of 2 images 36.8 ms, two chains of 1 image 35.4 ms; the results are bit-identical (the kernels' arithmetic does not depend
-on the batch size or on the grid).
+(`ops.GEMM_MAX_GRID`) run those phases against each other.  Measured on one MI355X, ViT-L 1024^2, batch 2 (tools/chains_bench.py,
+bench.py --chains 1 / 2 on the same box): one chain of 2 images 37.3-37.5 ms, two chains of 1 image 35.7-36.4 ms (encoder only), 38.8
+against 37.3 ms with the head; the results are bit-identical (the kernels' arithmetic does not depend on the batch size or on the
+grid).  Forcing a phase offset between the chains (0-18 ms) changes nothing measurable: they drift apart by themselves.
 
 How.  Each chain is its own HIP graph, captured on its own origin stream (a capture that forks side streams may only join them
 into its origin stream on ROCm 7.2, so the chains cannot be branches of one graph); the chains share the packed weights and use
@@ -82,8 +83,8 @@ class Chains:
     def replay(self, join=True):
         """Enqueue one pass over the batch: every chain starts behind the current stream's work.  join=True: the current stream then
         waits for all chains (the outputs are ready for whatever it does next).  join=False: the chains free-run -- consecutive
-        replays queue up per chain, nothing orders chain A's pass k against chain B's, so the chains drift out of phase (which is where
-        the gain comes from: DESIGN.md section 4.1); call join() before reading the outputs."""
+        replays queue up per chain and nothing orders chain A's pass k against chain B's (measured within 1 % of the joined form);
+        call join() before reading the outputs."""
         main = torch.cuda.current_stream(self.x.device)
         start = torch.cuda.Event()
         start.record(main)

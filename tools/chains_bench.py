@@ -43,3 +43,15 @@ ch = mmsa.Chains(m, None, n=nch).capture(x)
 t2 = timeit(lambda: ch.replay(join=False))
 t3 = timeit(lambda: ch.replay(join=True))
 print(f"one chain x batch {B}: {t1:.2f} ms | {nch} chains free-running: {t2:.2f} ms | joined per pass: {t3:.2f} ms", flush=True)
+# free-running with a forced phase offset: chain 1 starts `off` ms late (one spin kernel), 40 passes so that the tail amortises
+for off in (0.0, 6.0, 12.0, 18.0):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if off > 0:
+        with torch.cuda.stream(ch.streams[1]):
+            torch.cuda._sleep(int(off * 1e-3 * 100e6))     # s_memrealtime ticks at 100 MHz
+    for _ in range(40):
+        ch.replay(join=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    print(f"  offset {off:4.1f} ms: {dt / 40:.2f} ms per pass over 40 passes ({(dt - off) / 40:.2f} without the offset itself)", flush=True)
