@@ -486,7 +486,54 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       // cache two CUs share, and ran at instruction-fetch speed: ~45 of the kernel's ~200 us at K = 1024 with
       // only ~13 us of that being the stores themselves (MMSA_GEMM_DEBUG 1 / 10 / 2 ablations).
       const int act = ACT >= 0 ? ACT : a.act;
-      if constexpr (EPI_UNROLL) {
+      // Planes-only outputs (lin1, qkv, the ConvNeXt pw1s: no fp32 copy, no residual, plain row mapping): bias / activation / scale are
+      // applied in the NATIVE accumulator layout (lane = row l15, columns 16 ni + 4g .. +3) and the split values go straight into the
+      // LDS line image, which is read back 16 bytes per lane for whole-line stores: ONE LDS round trip per sub-tile instead of two
+      // (transpose to rows, then re-stage as lines), and the four sub-tiles' LDS traffic and arithmetic are free to overlap -- a wave's
+      // LDS instructions execute in order, so sub-tile mi + 1 may overwrite the staging rows as soon as mi's read-backs are ISSUED.
+      bool direct = false;
+      if constexpr (EPI_UNROLL && !GEN) direct = fast && Cp && !C && !resid && ni4 && a.debug == 0 && (((uintptr_t)bias | (uintptr_t)colscale) & 15) == 0;
+      if constexpr (EPI_UNROLL && !GEN) {
+        if (direct) {
+          float4 bn_[4], cn_[4];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int ci = nb_ + ni * 16 + 4 * g;     // fast: the whole 64-column strip is inside N
+            bn_[ni] = bias ? *reinterpret_cast<const float4*>(bias + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            cn_[ni] = colscale ? *reinterpret_cast<const float4*>(colscale + ci) : make_float4(1.f, 1.f, 1.f, 1.f);
+            cn_[ni].x *= a.alpha; cn_[ni].y *= a.alpha; cn_[ni].z *= a.alpha; cn_[ni].w *= a.alpha;
+          }
+          unsigned short* wrow = reinterpret_cast<unsigned short*>(stg + l15 * 68);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const int mb = m0 + wm * 64 + mi * 16;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              float4 o = make_float4(acc[ni][mi][0] + bn_[ni].x, acc[ni][mi][1] + bn_[ni].y, acc[ni][mi][2] + bn_[ni].z, acc[ni][mi][3] + bn_[ni].w);
+              acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              if (act != ACT_NONE) {
+                if (act == ACT_GELU) o = gelu4(o);
+                else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
+              }
+              o.x *= cn_[ni].x; o.y *= cn_[ni].y; o.z *= cn_[ni].z; o.w *= cn_[ni].w;
+              store_planes4(wrow, ni * 16 + 4 * g, o, a.cp_fmt);
+            }
+            uint4 pk[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              pk[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(stg + (rl0 + 4 * i) * 68) + 8 * (lane & 15));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int m = mb + rl0 + 4 * i;
+              if (m < a.M) *reinterpret_cast<uint4*>(Cp + (long)m * a.ldcp + ilv(n & ~63) + 8 * (lane & 15)) = pk[i];
+            }
+          }
+        }
+      }
+      // (fp32-only outputs stored straight from the accumulator layout -- 16 rows x 64 bytes per instruction, no LDS transpose --
+      // measured time-neutral against the transposed whole-row stores on every shape and on the step, same box: not kept.)
+      if (direct) {
+      } else if constexpr (EPI_UNROLL) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
         const int mb = m0 + wm * 64 + mi * 16;
