@@ -389,16 +389,33 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         def iplanes(w2d, site="inter"):
             return planes(w2d, fmt=ifmt(w2d, site))
 
-        def pack_msda(b):
+        # Injector i normalises the adapter tokens c with its feat_norm, extractor i normalises the SAME c (the injector only
+        # updates x) with its query_norm: two LayerNorm passes over the largest token matrix of the path (Nc = 21504 rows per
+        # image).  LN(c; w, b) W^T + bias = chat (W * w)^T + (W b + bias) with chat = (c - mean) * rstd, so the affine parts are folded
+        # into the two projections' weights here and ONE pass computes chat for both (`share_c_norm`; MMSA_SHARE_CNORM=0 keeps two).
+        share_c = os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(self, "share_c_norm", True))
+        pk["share_c_norm"] = share_c
+        pk["ln_one"], pk["ln_zero"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+
+        def fold_ln(w2d, bias, lnw, lnb):      # -> weight and bias of the projection applied to the un-affine normalised tokens
+            return (w2d * lnw[None, :]).contiguous(), (bias + w2d @ lnb).contiguous()
+
+        def pack_msda(b, fold_val=None, fold_oa=None):
             w = torch.cat([sd[b + "sampling_offsets.weight"], sd[b + "attention_weights.weight"]], 0)
             bb = torch.cat([sd[b + "sampling_offsets.bias"], sd[b + "attention_weights.bias"]], 0)
-            return dict(oa=iplanes(w), oa_b=bb.contiguous(), val=iplanes(sd[b + "value_proj.weight"]), val_b=sd[b + "value_proj.bias"],
+            wv, bv_ = sd[b + "value_proj.weight"], sd[b + "value_proj.bias"]
+            if fold_oa is not None:
+                w, bb = fold_ln(w, bb, *fold_oa)
+            if fold_val is not None:
+                wv, bv_ = fold_ln(wv, bv_, *fold_val)
+            return dict(oa=iplanes(w), oa_b=bb.contiguous(), val=iplanes(wv), val_b=bv_,
                         out=iplanes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
 
-        def pack_extractor(b):
+        def pack_extractor(b, fold_c=False):
             dw = sd[b + "ffn.dwconv.dwconv.weight"]
             return dict(qnw=sd[b + "query_norm.weight"], qnb=sd[b + "query_norm.bias"], fnw=sd[b + "feat_norm.weight"],
-                        fnb=sd[b + "feat_norm.bias"], attn=pack_msda(b + "attn."),
+                        fnb=sd[b + "feat_norm.bias"], fold_c=fold_c,
+                        attn=pack_msda(b + "attn.", fold_oa=(sd[b + "query_norm.weight"], sd[b + "query_norm.bias"]) if fold_c else None),
                         fc1=iplanes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
                         dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
                         fc2=iplanes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
@@ -410,8 +427,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             b = f"interactions.{i}."
             it = dict(inj=dict(gamma=sd[b + "injector.gamma"], qnw=sd[b + "injector.query_norm.weight"],
                                qnb=sd[b + "injector.query_norm.bias"], fnw=sd[b + "injector.feat_norm.weight"],
-                               fnb=sd[b + "injector.feat_norm.bias"], attn=pack_msda(b + "injector.attn.")),
-                      ext=[pack_extractor(b + "extractor.")])
+                               fnb=sd[b + "injector.feat_norm.bias"], fold_c=share_c,
+                               attn=pack_msda(b + "injector.attn.", fold_val=(sd[b + "injector.feat_norm.weight"], sd[b + "injector.feat_norm.bias"]) if share_c else None)),
+                      ext=[pack_extractor(b + "extractor.", fold_c=share_c)])
             if i == n_int - 1:
                 it["ext"] += [pack_extractor(b + "extra_extractors.0."), pack_extractor(b + "extra_extractors.1.")]
             pk["inter"].append(it)
@@ -656,14 +674,19 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         qn = ws.planes("inj_qn", B * T, D, fmt=ip["attn"]["oa"].fmt)
         fn = ws.planes("inj_fn", B * Nc, D, fmt=ip["attn"]["val"].fmt)
         ops.layernorm(x_in, ip["qnw"], ip["qnb"], 1e-6, out_planes=qn)
-        ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
+        if ip["fold_c"]:   # chat = (c - mean) * rstd: feat_norm's affine part lives in value_proj's packed weight; the extractor reuses `fn`
+            pk = self._packed
+            ops.layernorm(c, pk["ln_one"], pk["ln_zero"], 1e-6, out_planes=fn)
+        else:
+            ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
         self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"])
 
     def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
         ws, D = self._ws, self.cfg["embed_dim"]
         qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["attn"]["oa"].fmt)
         fn = ws.planes("inj_qn", B * T, D, fmt=ep["attn"]["val"].fmt)
-        ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
+        if not ep["fold_c"]:   # else: `inj_fn` still holds chat of this very c, written by the interaction's injector (nothing in between touches c or the buffer)
+            ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
         ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, out_planes=fn)
         self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
         qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["fc1"].fmt)

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 3   # 3: planes carry their operand format (bf16 hi/lo or h8)
+PACK_FORMAT = 4   # 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm)
 
 
 def unwrap_state_dict(ck):
