@@ -371,9 +371,9 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C; a.cp_fmt = cp_fmt;
   // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 forces this one
   static const bool force_v1 = getenv("MMSA_GEMM_V1") != nullptr;
-  // one 128-column strip with many rows and a deep K (ConvNeXt stage-0 pw2: N = 96, K = 384): the 128-row tiles of this kernel
-  // balance better over the CUs than 256-row tiles (61 vs 75 us at M = 131072; at K <= 192 the 256-row kernel is faster)
-  const bool narrow = N <= 128 && M >= 65536 && K >= 384;
+  // (round 1 routed one-strip shapes with many rows and a deep K -- ConvNeXt stage-0 pw2: N = 96, K = 384 -- to the 128-row tiles of
+  // this kernel; with the blocked tile order and the 96-column tiles of the LDS-DMA kernel that shape is 18 % faster there: 152 -> 125 us)
+  const bool narrow = false;
   static const bool no_tiny = getenv("MMSA_GEMM_NO_TINY") != nullptr;   // A/B aid
   // routed by the problem's small dimension, NOT by the row count (rows scale with the image batch: a batch-dependent choice of
   // kernel would make results depend on how images are batched); M <= 16384 covers 32 images of the largest pooled map
