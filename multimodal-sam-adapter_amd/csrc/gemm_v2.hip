@@ -36,6 +36,7 @@ struct GemmV2Args {
   int M, N, K;
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;
+  int ps_sw, ps_sh;   // log2 of ps_W / ps_H when they are powers of two (the pixel-shuffle row mapping then needs no integer division), else -1
   int nbm, nbn, ntiles;
   int tm, tn;  // tile order inside a batch: tm > 0 -> blocks of tm x tn = 32 tiles (see V2_TILE_MN), 0 -> row-major (m-tile, n-tile)
   int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
@@ -462,16 +463,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
         cv[r] = colscale ? colscale[ci] * a.alpha : a.alpha;
       }
       // row mapping (destination row / column, residual row); identity unless GEN
+      // pixel-shuffle store: the (i, j) quadrant of this lane's own columns is fixed for the tile -- one division per tile, not per row
+      int ij_n = 0, dcol_n = n;
+      if constexpr (GEN) { if (a.out_mode == 1) { ij_n = n / a.ps_C; dcol_n = n - ij_n * a.ps_C; } }
       auto map_row = [&](int m, int nn, long& drow_, int& dcol, long& rrow) {
         drow_ = m; dcol = nn; rrow = m;
         if constexpr (GEN) {
           if (a.out_mode == 1) {
-            const int ij = nn / a.ps_C;
-            dcol = nn - ij * a.ps_C;
-            const int w_ = m % a.ps_W;
-            const int t_ = m / a.ps_W;
-            const int h_ = t_ % a.ps_H;
-            const int b_ = t_ / a.ps_H;
+            int ij = ij_n;
+            dcol = dcol_n;
+            if (nn != n) { ij = nn / a.ps_C; dcol = nn - ij * a.ps_C; }
+            int w_, h_, b_;
+            if (a.ps_sw >= 0 && a.ps_sh >= 0) {   // power-of-two grids (every shipped config): shifts and masks
+              w_ = m & (a.ps_W - 1);
+              const int t_ = m >> a.ps_sw;
+              h_ = t_ & (a.ps_H - 1);
+              b_ = t_ >> a.ps_sh;
+            } else {
+              w_ = m % a.ps_W;
+              const int t_ = m / a.ps_W;
+              h_ = t_ % a.ps_H;
+              b_ = t_ / a.ps_H;
+            }
             drow_ = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
           }
           rrow = a.resid_mod > 0 ? (long)((int)drow_ % a.resid_mod) : drow_;
@@ -726,6 +739,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C;
+  auto log2_exact = [](int v) { int s_ = -1; if (v > 0 && (v & (v - 1)) == 0) { s_ = 0; while ((1 << s_) < v) ++s_; } return s_; };
+  a.ps_sw = log2_exact(ps_W); a.ps_sh = log2_exact(ps_H);
   a.cp_fmt = cp_fmt;
   const bool h8 = fmt == MMSA_FMT_H8;
   MMSA_CHECK_ARG(!h8 || (K & 63) == 0, "gemm(v2): h8 operands need K %% 64 == 0 (K=%d)", K);
@@ -757,7 +772,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
-    V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1)
+    V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1) V2_ATTR(true, ACT_NONE)
 #undef V2_ATTR
   }
   // max_grid > 0: at most that many persistent workgroups -- a caller that runs independent chains on concurrent streams gives each
@@ -805,7 +820,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);            \
   } while (0)
   if (gen) {
-    V2_LAUNCH(true, -1);
+    if (act == ACT_NONE) V2_LAUNCH(true, ACT_NONE);   // the up-conv / pos-embed GEMMs: unrolled epilogue
+    else V2_LAUNCH(true, -1);
   } else {
     switch (act) {
       case ACT_NONE: V2_LAUNCH(false, ACT_NONE); break;
