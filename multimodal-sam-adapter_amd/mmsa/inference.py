@@ -180,3 +180,44 @@ def argmax_map(seg_logit):
     out = torch.empty(B, H, W, dtype=torch.uint8, device=seg_logit.device)
     lib.call("mmsa_argmax_nchw", seg_logit.data_ptr(), out.data_ptr(), B, C, H * W, ops._stream())
     return out
+
+
+class SlideRunner:
+    """Throughput form of slide_class_map for a fixed frame geometry: the frame's windows are cut by one kernel, go through the
+    encoder + head as `chains` concurrent sub-batches (mmsa.Chains: one HIP graph per chain, shared packed weights) and one kernel
+    (mmsa_slide_argmax) turns the head-resolution logits into the class map.  Same class map as slide_inference + argmax_map, bit
+    for bit.  `frame` is the static [B, 6, H, W] buffer the runner reads on every run()."""
+
+    def __init__(self, backbone, head, frame, crop_size, stride, chains=2):
+        import ctypes
+        from .chains import Chains
+        _check(frame)
+        _pair(backbone, head)
+        self.frame = frame.contiguous()
+        B, _, H, W = self.frame.shape
+        self.crop_size = tuple(crop_size)
+        boxes = crop_boxes(H, W, crop_size, stride)
+        self.jobs = [(b, box) for box in boxes for b in range(B)]      # the accumulation order of slide_inference
+        n = len(self.jobs)
+        if n > 64:
+            raise RuntimeError("mmsa.SlideRunner: at most 64 windows per frame batch")
+        if n % chains:
+            chains = 1
+        with torch.cuda.device(self.frame.device):
+            self.crops = _crops(self.frame, self.jobs, self.crop_size)          # also the static input buffer of the chains
+            self.chains = Chains(backbone, head, n=chains).capture(self.crops)
+            self.tab = (ctypes.c_int * (3 * n))(*[v for b, (y1, x1, _, _) in self.jobs for v in (b, y1, x1)])
+            self.out = torch.empty(B, H, W, dtype=torch.uint8, device=self.frame.device)
+            self.unc = torch.zeros(1, dtype=torch.int32, device=self.frame.device)
+
+    @torch.no_grad()
+    def run(self):
+        """-> (class map uint8 [B, H, W], uncovered-pixel flag); asynchronous on the current stream."""
+        with torch.cuda.device(self.frame.device):
+            _crops(self.frame, self.jobs, self.crop_size, out=self.crops)
+            lg = self.chains.replay()
+            B, H, W = self.out.shape
+            self.unc.zero_()
+            lib.call("mmsa_slide_argmax", lg.data_ptr(), len(self.jobs), lg.shape[1], lg.shape[2], lg.shape[3], self.tab, self.out.data_ptr(),
+                     B, H, W, self.crop_size[0], self.crop_size[1], self.unc.data_ptr(), ops._stream())
+        return self.out, self.unc

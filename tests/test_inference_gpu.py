@@ -174,3 +174,20 @@ def test_concurrent_chains_equal_one_chain_bit_for_bit(models, nch):
             assert torch.equal(feats[c][k], fs[k])
     with pytest.raises(RuntimeError):
         mmsa.Chains(m, None, n=nch).capture(x[:nch + 1])
+
+
+def test_slide_runner_equals_slide_inference(models):
+    """mmsa.inference.SlideRunner (windows as concurrent chains, HIP graphs) == slide_inference + argmax_map, bit for bit, run after run."""
+    import mmsa.inference as inf
+    cfg, _, _, m, h = models
+    g = torch.Generator().manual_seed(77)
+    frame = torch.randn(1, 6, 300, 420, generator=g).to(DEV)        # 256-pixel windows, stride 160: 1 x 3 = ... windows (even count needed for 2 chains)
+    boxes = inf.crop_boxes(300, 420, (256, 256), (160, 160))
+    sr = inf.SlideRunner(m, h, frame, (256, 256), (160, 160), chains=2)
+    for rep in range(3):
+        if rep == 2:
+            frame.copy_(torch.randn(1, 6, 300, 420, generator=g).to(DEV))
+        cm, unc = sr.run()
+        torch.cuda.synchronize()
+        want = inf.argmax_map(inf.slide_inference(m, h, frame, (256, 256), (160, 160), max_batch=len(boxes)))
+        assert int(unc.item()) == 0 and torch.equal(cm, want)

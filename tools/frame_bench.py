@@ -72,6 +72,20 @@ def main():
         out["fused_hip_graph"] = {"ms_per_frame": dt * 1e3, "frames_per_s": 1 / dt, "crops_per_s": 6 / dt, "verified": "replayed class map == slide_inference + argmax_map, bit for bit"}
     except Exception as e:  # noqa: BLE001
         out["fused_hip_graph"] = {"error": f"{type(e).__name__}: {e}"}
+    try:   # throughput form: the six windows as two concurrent chains of three (mmsa.inference.SlideRunner)
+        sr = inf.SlideRunner(m, h, frame, (1024, 1024), (640, 640), chains=2)
+        for _ in range(2):
+            rcm, runc = sr.run()
+        torch.cuda.synchronize()
+        assert int(runc.item()) == 0 and torch.equal(rcm, want), "SlideRunner class map differs"
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            sr.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out["two_chains_hip_graphs"] = {"ms_per_frame": dt * 1e3, "frames_per_s": 1 / dt, "crops_per_s": 6 / dt, "verified": "class map == slide_inference + argmax_map, bit for bit"}
+    except Exception as e:  # noqa: BLE001
+        out["two_chains_hip_graphs"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps({"workload": "MUSES frame 1080x1920 -> 6 crops 1024^2, ViT-L RGB+LiDAR, encoder+head+slide+argmax; weights: seeded live generator",
                       "class_map": [int(cls.shape[1]), int(cls.shape[2])], **out}))
 
