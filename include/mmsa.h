@@ -111,6 +111,14 @@ int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt,
                      int max_grid, mmsa_stream_t stream);
 
+/* ConvNeXt pointwise pair of the narrow stages as ONE kernel (TC:107-132): x[b] <- x[b] + gamma[b] * (GELU(A[b] W1[b]^T + b1[b]) W2[b]^T
+ * + b2[b]); A = LayerNorm output as bf16 hi/lo planes [M, C] (row stride lda, batch stride strideA, uint16 units), W1 [4C, C] and
+ * W2 [C, 4C] bf16 hi/lo planes per batch, b1 [batch, 4C], b2 / gamma [batch, C], x fp32 [M, C] (row stride ldx) updated in place.
+ * C = 96 (the narrowest ConvNeXt stage); the 4C-wide hidden tensor stays in LDS.  max_grid as in mmsa_gemm_split3. */
+int mmsa_convnext_mlp_fused(const uint16_t* Ap, long lda, long strideA, const uint16_t* W1p, long strideW1, const uint16_t* W2p,
+                            long strideW2, const float* b1, const float* b2, const float* gamma, float* x, long ldx, long strideX,
+                            int M, int C, int batch, int max_grid, mmsa_stream_t stream);
+
 /* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
  * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows. */
 int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes, int kind,

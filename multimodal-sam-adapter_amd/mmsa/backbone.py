@@ -794,12 +794,19 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             # one-kernel depthwise conv + LayerNorm (csrc/conv_ln.hip): 42.6 vs 31 + 26 us at C = 384, but step-neutral (its
             # 122-KiB workgroups push the overlapping neck streams off the CUs: see its header) -- off unless asked for
             fused = ops.dwconv7_ln_supported(c) and getattr(self, "fuse_dwconv_ln", False)
+            # narrow stages (C = 96 / 192): the pointwise pair as ONE kernel that keeps the 4C hidden tensor in LDS (csrc/mlp_fused.hip)
+            fuse_mlp = ops.convnext_mlp_fused_supported(c) and bool(getattr(self, "fuse_convnext_mlp", True)) and os.environ.get("MMSA_FUSE_MLP", "1") != "0"
             for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
                 if fused:   # depthwise conv + LayerNorm in one kernel: the conv output never goes to memory
                     ops.dwconv7_ln(cur, blk["dw"], blk["dw_b"], blk["nw"], blk["nb"], 1e-6, n, 2 * B, hh, wwd, imgs_per_group=B)
                 else:
                     ops.dwconv(cur, blk["dw"], blk["dw_b"], d, 2 * B, hh, wwd, 7, imgs_per_group=B)
                     ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n, group_rows=P, w_gstride=c)
+                if fuse_mlp:
+                    ops.convnext_mlp_fused(n, blk["pw1"], blk["pw2"], blk["pw1_b"], blk["pw2_b"], blk["gamma"], cur, P, batch=2,
+                                           stride_a=P * 2 * n.kpad, stride_w1=blk["pw1"].n * 2 * blk["pw1"].kpad,
+                                           stride_w2=blk["pw2"].n * 2 * blk["pw2"].kpad, stride_x=P * c)
+                    continue
                 ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf, batch=2, m=P, stride_a=P * 2 * n.kpad,
                          stride_w=blk["pw1"].n * 2 * blk["pw1"].kpad, stride_bias=4 * c, stride_cp=P * 2 * hbuf.kpad)
                 ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur, batch=2, m=P,

@@ -192,6 +192,22 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     return out if out is not None else out_planes
 
 
+def convnext_mlp_fused(a, w1, w2, b1, b2, gamma, x, m, batch=1, stride_a=0, stride_w1=0, stride_w2=0, stride_x=0):
+    """x[b] <- x[b] + gamma[b] * (gelu(a[b] @ w1[b].T + b1[b]) @ w2[b].T + b2[b]) in place (one kernel; C = 96).
+    a: bf16 hi/lo activation Planes; w1 [4C, C], w2 [C, 4C]: bf16 hi/lo weight Planes (first batch; batch strides in uint16 units)."""
+    pa, _, _, lda = a.mat("A")
+    px, _, c, ldx = _mat(x, "x")
+    if a.fmt != FMT_B3 or w1.fmt != FMT_B3 or w2.fmt != FMT_B3:
+        raise RuntimeError("mmsa.convnext_mlp_fused: bf16 hi/lo planes expected")
+    lib.call("mmsa_convnext_mlp_fused", pa, lda, stride_a, w1.p.data_ptr(), stride_w1, w2.p.data_ptr(), stride_w2, _chk(b1), _chk(b2),
+             _chk(gamma), px, ldx, stride_x, m, c, batch, GEMM_MAX_GRID, _stream())
+    return x
+
+
+def convnext_mlp_fused_supported(c):
+    return c == 96
+
+
 def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None, group_rows=0, w_gstride=0, y_gcol=0, y_wrap=False):
     """Row LayerNorm.  group_rows > 0: stacked row groups with their own weights (w, b of shape [groups, C]); group g writes
     at column offset g * y_gcol, and at row (row % group_rows) when y_wrap."""

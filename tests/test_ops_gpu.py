@@ -450,3 +450,38 @@ def test_gconv3_on_the_matrix_pipe(ops, cg, H, W):
     again = torch.empty_like(out)
     ops.gconv(x.permute(0, 2, 3, 1).reshape(-1, cg * groups).contiguous().to(DEV), w, None, again, B, H, W, groups, cg, cg, 3)
     assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("C,M", [(96, 1000), (96, 128), (96, 70000), (96, 33)])
+def test_convnext_mlp_fused(C, M):
+    """mmsa_convnext_mlp_fused (TC:107-132 pointwise_conv1 -> GELU -> pointwise_conv2 -> gamma -> + residual, two batched streams)
+    against fp64 torch and against the two separate GEMM launches it replaces."""
+    import mmsa
+    ops = mmsa.ops
+    g = torch.Generator().manual_seed(90 + C)
+    b = 2
+    a = torch.randn(b * M, C, generator=g)
+    w1 = torch.randn(b * 4 * C, C, generator=g) / C ** 0.5
+    w2 = torch.randn(b * C, 4 * C, generator=g) / (4 * C) ** 0.5
+    b1, b2, gam = torch.randn(b * 4 * C, generator=g), torch.randn(b * C, generator=g), torch.randn(b * C, generator=g)
+    x0 = torch.randn(b * M, C, generator=g)
+    ref = torch.empty_like(x0)
+    for s in range(b):
+        h = F.gelu(a[s * M:(s + 1) * M].double() @ w1[s * 4 * C:(s + 1) * 4 * C].double().t() + b1[s * 4 * C:(s + 1) * 4 * C].double())
+        y = h @ w2[s * C:(s + 1) * C].double().t() + b2[s * C:(s + 1) * C].double()
+        ref[s * M:(s + 1) * M] = (x0[s * M:(s + 1) * M].double() + gam[s * C:(s + 1) * C].double() * y).float()
+    ap = ops.split_planes(a.to(DEV), kpad=ops.pad32(C))
+    w1p = ops.split_planes(w1.to(DEV)); w1p = ops.Planes(w1p.p, 4 * C, C, w1p.kpad)
+    w2p = ops.split_planes(w2.to(DEV)); w2p = ops.Planes(w2p.p, C, 4 * C, w2p.kpad)
+    x = x0.to(DEV).clone()
+    ops.convnext_mlp_fused(ap, w1p, w2p, b1.to(DEV), b2.to(DEV), gam.to(DEV), x, M, batch=b, stride_a=M * 2 * ap.kpad,
+                           stride_w1=4 * C * 2 * w1p.kpad, stride_w2=C * 2 * w2p.kpad, stride_x=M * C)
+    assert_close(x, ref, tol=3e-5, what="fused ConvNeXt MLP vs fp64")
+    # the pair of launches it replaces
+    hb = ops.alloc_planes(b * M, 4 * C, DEV)
+    x2 = x0.to(DEV).clone()
+    ops.gemm(ap, w1p, bias=b1.to(DEV), act="gelu", out_planes=hb, batch=b, m=M, stride_a=M * 2 * ap.kpad, stride_w=4 * C * 2 * w1p.kpad,
+             stride_bias=4 * C, stride_cp=M * 2 * hb.kpad)
+    ops.gemm(hb, w2p, x2, bias=b2.to(DEV), colscale=gam.to(DEV), resid=x2, batch=b, m=M, stride_a=M * 2 * hb.kpad, stride_w=C * 2 * w2p.kpad,
+             stride_bias=C, stride_r=M * C, stride_c=M * C)
+    assert_close(x, x2, tol=5e-6, what="fused vs the two GEMM launches")
