@@ -199,8 +199,17 @@ def convnext_mlp_fused(a, w1, w2, b1, b2, gamma, x, m, batch=1, stride_a=0, stri
     px, _, c, ldx = _mat(x, "x")
     if a.fmt != FMT_B3 or w1.fmt != FMT_B3 or w2.fmt != FMT_B3:
         raise RuntimeError("mmsa.convnext_mlp_fused: bf16 hi/lo planes expected")
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = _event(), _event()
+        lib.call("mmsa_event_record", e0, _stream())
     lib.call("mmsa_convnext_mlp_fused", pa, lda, stride_a, w1.p.data_ptr(), stride_w1, w2.p.data_ptr(), stride_w2, _chk(b1), _chk(b2),
              _chk(gamma), px, ldx, stride_x, m, c, batch, GEMM_MAX_GRID, _stream())
+    if prof is not None:      # both contractions of the pair count towards the GEMM family (bench.py roofline)
+        lib.call("mmsa_event_record", e1, _stream())
+        prof.append((2.0 * 2.0 * m * c * 4 * c * batch, e0, e1, 4.0 * batch * (m * c * 3 + 2 * 4 * c * c)))
+        if GEMM_SHAPES is not None:
+            GEMM_SHAPES.append((m, c, 4 * c, batch, "gelu", True, "C", "fused-pair"))
     return x
 
 

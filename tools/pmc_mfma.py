@@ -43,7 +43,7 @@ def fold(keys):
             "mfma_flop_counted": fl, "mfma_tflops": fl / max(ons, 1) / 1e3, "mfma_flop_by_type": dict(bt)}
 
 
-gem = [k for k in per if "gemm" in k]
+gem = [k for k in per if "gemm" in k or "mlp_fused" in k]   # the contraction kernels
 res = {"note": "one eager step of bench.py (ViT-L 1024^2 RGB+LiDAR, batch 2, encoder + head) under rocprofv3 --pmc; kernels run serialised "
                "under counter collection, so ms is the sum of kernel durations, not the step time; util is duration-weighted MfmaUtil; "
                "mfma_flop_counted = 512 x (MOPS_BF16 + MOPS_F16 + MOPS_F8 + MOPS_F32): 3 x the algorithmic flops for bf16 hi/lo contractions, "

@@ -12,7 +12,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"].split("(")[0]
             agg[k] += float(r["Counter_Value"]); n[k] += 1
     out[c] = {k: {"launches": n[k], "sum_kb": agg[k]} for k in agg}
-gem = [k for k in out["FETCH_SIZE"] if "gemm" in k]
+gem = [k for k in out["FETCH_SIZE"] if "gemm" in k or "mlp_fused" in k]
 launches = sum(out["FETCH_SIZE"][k]["launches"] for k in gem)
 fetch_kb = sum(out["FETCH_SIZE"][k]["sum_kb"] for k in gem)
 write_kb = sum(out["WRITE_SIZE"].get(k, {"sum_kb": 0})["sum_kb"] for k in gem)
