@@ -287,6 +287,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 tw = blk["rpw"] if blk["rpw"].shape[0] == L else _linear_resize_rows(blk["rpw"], L)
                 blk["relp"] = ops.window_relpos_planes(th, tw, wsz)
         # --- TwinConvNeXt
+        def cfmt(w2d):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path):
+            # h8 operands for the pointwise convs whose two contraction lengths (C and 4C) are multiples of 64 and that do not run on the fused stage-0 kernel
+            c_ = min(w2d.shape)
+            return ops.FMT_H8 if ("cnx" in h8_sites and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_)) else ops.FMT_B3
         t = "spm.twin_conv."
         pk["twin"] = {}
         for s in ("x", "y"):
@@ -304,8 +308,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                     dw = sd[b + "depthwise_conv.weight"]  # [C,1,7,7] -> tap-major [49, C]
                     blks.append(dict(dw=dw.reshape(dw.shape[0], 49).t().contiguous(), dw_b=sd[b + "depthwise_conv.bias"],
                                      nw=sd[b + "norm.weight"], nb=sd[b + "norm.bias"],
-                                     pw1=planes(sd[b + "pointwise_conv1.weight"]), pw1_b=sd[b + "pointwise_conv1.bias"],
-                                     pw2=planes(sd[b + "pointwise_conv2.weight"]), pw2_b=sd[b + "pointwise_conv2.bias"],
+                                     pw1=planes(sd[b + "pointwise_conv1.weight"], fmt=cfmt(sd[b + "pointwise_conv1.weight"])), pw1_b=sd[b + "pointwise_conv1.bias"],
+                                     pw2=planes(sd[b + "pointwise_conv2.weight"], fmt=cfmt(sd[b + "pointwise_conv2.weight"])), pw2_b=sd[b + "pointwise_conv2.bias"],
                                      gamma=sd[b + "gamma"]))
                 st["stages"].append(blks)
                 st["out_norm"].append((sd[t + f"norm_{s}{i}.weight"], sd[t + f"norm_{s}{i}.bias"]))
@@ -315,7 +319,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         def stack2(fx, fy):
             if isinstance(fx, ops.Planes):
                 buf = torch.cat([fx.p, fy.p], 0).contiguous()
-                pl = ops.Planes(buf[:fx.n], fx.n, fx.k, fx.kpad)
+                pl = ops.Planes(buf[:fx.n], fx.n, fx.k, fx.kpad, fx.fmt, fx.weight)
                 pl.full = buf           # keeps the second batch alive; batch stride = n * 2 * kpad elements
                 return pl
             return torch.stack([fx, fy], 0).contiguous()
@@ -789,8 +793,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 ops.gemm(pa, ds["w"], cur, bias=ds["b"], batch=2, m=P, stride_a=P * 2 * pa.kpad, stride_w=ds["w"].n * 2 * ds["w"].kpad,
                          stride_bias=c, stride_c=P * c)
             d = ws.get(t + "tmp", 2 * P, c)
-            n = ws.planes(t + "n", 2 * P, c)
-            hbuf = ws.planes(t + "h", 2 * P, 4 * c)
+            wf = st["stages"][i][0]["pw1"].fmt          # operand format of this stage's pointwise convs (bf16 hi/lo unless "cnx" is an h8 site)
+            n = ws.planes(t + "n", 2 * P, c, fmt=wf)
+            hbuf = ws.planes(t + "h", 2 * P, 4 * c, fmt=wf)
             # one-kernel depthwise conv + LayerNorm (csrc/conv_ln.hip): 42.6 vs 31 + 26 us at C = 384, but step-neutral (its
             # 122-KiB workgroups push the overlapping neck streams off the CUs: see its header) -- off unless asked for
             fused = ops.dwconv7_ln_supported(c) and getattr(self, "fuse_dwconv_ln", False)
