@@ -809,7 +809,12 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
       if (a.tm == 0 || cost < best) { best = cost; a.tm = tm; a.tn = tn; }
     }
   }
-  const int grid = a.ntiles < cus * wg_per_cu ? a.ntiles : cus * wg_per_cu;   // resident workgroups: one per CU (144 KiB LDS) or two (64 KiB each)
+  // resident workgroups: one per CU (144 KiB LDS) or two (64 KiB each) -- and no more of them than the number of rounds needs: with
+  // 168 tiles on 128 CUs two rounds are needed either way, 84 workgroups of 2 tiles finish when 128 workgroups (40 with 2 tiles, 88
+  // with 1) do, and leave 44 CUs to whatever runs on the other streams (the concurrent chain, the neck levels)
+  const int slots_ = cus * wg_per_cu;
+  const int rounds_ = cdiv(a.ntiles, slots_);
+  const int grid = cdiv(a.ntiles, rounds_);
   const bool gen = out_mode != 0 || resid_mod > 0;
   static const bool pp = getenv("MMSA_GEMM_PP") ? atoi(getenv("MMSA_GEMM_PP")) != 0 : true;   // 0: every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \

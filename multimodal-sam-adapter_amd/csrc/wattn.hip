@@ -655,7 +655,8 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
     hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
   } else {
     const int nitems = nWin * heads * B;
-    const int grid = nitems < num_cus ? nitems : num_cus;
+    const int rounds = cdiv(nitems, num_cus);
+    const int grid = cdiv(nitems, rounds);   // the fewest workgroups that still finish in `rounds` items each: the other CUs stay free for concurrent streams
     hipLaunchKernelGGL(wattn_persist_kernel, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
   }
   MMSA_CHECK_LAUNCH("window_attention");
