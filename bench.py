@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-head", action="store_true", help="time the encoder forward only (no decode head, no all-gather)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("MMSA_CHAINS", "2")),
                     help="the step's batch as this many independent sub-batch chains on concurrent HIP streams (mmsa.Chains); 1 = one chain")
+    ap.add_argument("--force-chains", action="store_true", help="skip the untimed probe that falls back to one chain when the chains are slower on this machine")
     return ap.parse_args()
 
 
@@ -248,7 +249,32 @@ def main():
                 print(f"[bench] concurrent chains unavailable ({type(e).__name__}: {e}); one chain", file=sys.stderr)
             torch.cuda.synchronize()
             chains, nch = None, 1
-    if chains is None:
+    chain_probe = None
+    if chains is not None and not a.force_chains:
+        # The overlap of the chains depends on how the runtime maps their streams onto hardware queues (another queue
+        # count costs 25-30 %).  Untimed probe: a few replays of both forms; the timed region runs the faster one.
+        one_replay, one_out, one_graphed = capture(local_step)
+        one_feats = feats[0]
+
+        def probe(fn, n=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        t_ch, t_one = probe(chains.replay), probe(one_replay)
+        if use_dist:     # every rank must take the same decision
+            tt = torch.tensor([t_ch, t_one], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_ch, t_one = float(tt[0]), float(tt[1])
+        chain_probe = {"chains_ms": round(t_ch, 3), "one_chain_ms": round(t_one, 3)}
+        if t_one < t_ch:
+            chains, nch = None, 1
+            replay, local_out, graphed, graph_feats = one_replay, one_out, one_graphed, one_feats
+    elif chains is None:
         replay, local_out, graphed = capture(local_step)
         graph_feats = feats[0]                 # the four output maps the captured graph writes (fixed addresses)
     gathered = [None]
@@ -391,7 +417,7 @@ def main():
                                 "encoder forward + SegformerHead logits [B,25,H/4,W/4] + all-gather of logits across ranks",
                        "weights": "default init" if a.default_init else "seeded live generator (tests/weights.py), every parameter / buffer non-trivial",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graphed),
-                       "chains_per_gpu": nch,
+                       "chains_per_gpu": nch, "chains_probe_ms": chain_probe,
                        "collective": ("one RCCL all_gather_into_tensor of the logits per step" if (head is not None and use_dist)
                                       else "none (single rank)" if head is not None else "none (encoder only)")},
             "verified": verified,
