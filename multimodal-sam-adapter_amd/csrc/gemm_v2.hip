@@ -42,7 +42,7 @@ struct GemmV2Args {
   int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
                // that fills the CUs better: N = 384 gives 3 tiles of 128 (192 tiles on 256 CUs for the ConvNeXt pw2 GEMMs) or 4 of 96 (256 tiles)
   int cp_fmt;  // format of the planes output Cp: MMSA_FMT_B3 (bf16 hi | lo) or MMSA_FMT_H8 (fp16 hi | e5m2 lo, q(hi): common.h), independent of the operands' format
-  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 10 = epilogue without its global stores
+  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
 };
 
 #define V2_BN 128
@@ -50,6 +50,9 @@ struct GemmV2Args {
 #define V2_W_BYTES (V2_BN * 128)                        // 16 KiB
 // per workgroup flavour (template parameter NW of the kernel): rows per tile 256 / 128, A stage 32 / 16 KiB, ring 3 x 48 / 2 x 32 KiB
 #define V2_LDS_BYTES(NW_) (((NW_) == 8 ? 3 : 2) * ((NW_) * 32 * 128 + V2_W_BYTES))
+#ifndef V2_FAST_STEPS
+#define V2_FAST_STEPS 1   // 0: every k-tile runs the general step (A/B timing; the ablation build -DV2_KABL needs it)
+#endif
 #ifndef V2_SETPRIO
 #define V2_SETPRIO 0   // s_setprio(1) around the MFMA chunks: measured no effect on this kernel (same-box A/B)
 #endif
@@ -67,12 +70,14 @@ struct GemmV2Args {
 // the MFMA pipe.  With every wave in phase (PP = false) the whole CU first reads LDS (~1000 cycles, MFMA idle) and then
 // computes (1536 cycles, LDS idle): MfmaUtil 36-42 %.
 #ifdef V2_STAMP   // timing experiment build only (tools/build_variant.sh -DV2_STAMP): cycle stamps of workgroup 0, k-tiles 8..11
-__device__ unsigned long long g_v2_stamps[8 * 4 * 10];
+__device__ unsigned long long g_v2_stamps[8 * 4 * 10 + 4];   // + {memtime, memrealtime} at start and end of workgroup 0
 extern "C" int mmsa_debug_stamps(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v2_stamps), sizeof(unsigned long long) * 8 * 4 * 10);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v2_stamps), sizeof(unsigned long long) * (8 * 4 * 10 + 4));
 }
 #define STAMP(i_) if (stamp_on) tt[i_] = __builtin_readcyclecounter();
+#define CLK_SAMPLE(o_) if (blockIdx.x == 0 && threadIdx.x == 0) { g_v2_stamps[320 + (o_)] = __builtin_readcyclecounter(); g_v2_stamps[321 + (o_)] = __builtin_amdgcn_s_memrealtime(); }
 #else
+#define CLK_SAMPLE(o_)
 #define STAMP(i_)
 #endif
 // NW = waves per workgroup.  8: the 256 x 128 tile, 3-slot ring, one workgroup per CU (ping-pong main loop).  4: a 128 x 128 tile
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   }
   const int my_tiles = (a.ntiles - rb + G - 1) / G;   // tiles rb, rb+G, ...
   if (my_tiles <= 0) return;
+  CLK_SAMPLE(0)
   const int total = my_tiles * nk;
 
   // ---- DMA: one instruction = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7); the 16-byte piece fetched
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       sw2 = wp_ + (long)min(wb_ + 16, a.N - 1) * a.ldw + dpiece;                 \
       sw3 = wp_ + (long)min(wb_ + 24, a.N - 1) * a.ldw + (dpiece ^ 32);          \
     }                                                                            \
+    if (a.debug == 4 || a.debug == 5) sa1 = sa2 = sa3 = sw0 = sw1 = sa0;   /* timing experiment: L1-resident operand stream */ \
   } while (0)
 
 #define ISSUE_DMA(kt_, st_)                                                       \
@@ -334,21 +341,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     if ((i_) == 5) GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024);                                      \
   }
 #define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } }
+// k-loop ablation build (tools/build_variant.sh -DV2_KABL, timing only, results are garbage): MMSA_GEMM_DEBUG = 64 + a bit mask of what
+// to leave out -- 1 the MFMAs, 2 the fragment reads, 4 the LDS-DMA, 8 the barriers inside the k loop; all without the epilogue.
+#ifdef V2_KABL
+#define KABL(x_) (a.debug >= 64 && ((a.debug >> ((x_) - 6)) & 1))
+#define KABL_INIT() _Pragma("unroll") for (int i = 0; i < 4; ++i) { ah[i] = al[i] = wh[i] = wl[i] = __builtin_bit_cast(bf16x8, make_uint4(lane + i, 0x3c003c00u, lane, 0x3c003c00u)); }
+#else
+#define KABL(x_) false
+#define KABL_INIT()
+#endif
 #define K_STEP_PP()                                                                                         \
   {                                                                                                         \
-    const bool do_pf = pf_j < total;                                                                        \
+    const bool do_pf = pf_j < total && !KABL(8);                                                            \
     const bool last_k = kt == nk - 1;                                                                       \
     STAMP_DECL()                                                                                            \
     STAMP(0)                                                                                                \
     unsigned char* pfb = smem + pf_st * V2_STAGE;                                                           \
-    const int pko = pf_kt * 64;                                                                             \
+    const int pko = a.debug >= 3 && a.debug <= 5 ? 0 : pf_kt * 64;                                          \
     const unsigned char* base = smem + st * V2_STAGE;                                                       \
     bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+    KABL_INIT()                                                                                             \
+    if (!KABL(7)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
       ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);                             \
       al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
     }                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+    if (!KABL(7)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
       if (i < 3 || ni4) {                                                                                   \
         wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                           \
         wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                           \
@@ -364,13 +381,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     STAMP(3)                                                                                                \
     if (grp && !last_k) PP_WAIT(V2_PP_NR)                                                                   \
     STAMP(4)                                                                                                \
-    __builtin_amdgcn_s_barrier();                                                                           \
+    if (!KABL(9)) __builtin_amdgcn_s_barrier();                                                             \
     STAMP(5)                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (!KABL(6)) {                                                                                         \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
     MFMA_CHUNK(2)                                                                                           \
     if (ni4) { MFMA_CHUNK(3) }                                                                              \
+    }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (do_pf) {                                                                                            \
       pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                   \
@@ -385,9 +404,57 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     if (last_k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
     else if (!grp) PP_WAIT(6)                                                                               \
     STAMP(7)                                                                                                \
-    __builtin_amdgcn_s_barrier();                                                                           \
+    if (!KABL(9)) __builtin_amdgcn_s_barrier();                                                             \
     STAMP(8)                                                                                                \
     STAMP_STORE()                                                                                           \
+    st = st == 2 ? 0 : st + 1;                                                                              \
+    ++j;                                                                                                    \
+  }
+
+// Steady-state k-tile of the ping-pong loop: the same step with every case distinction of K_STEP_PP resolved -- the prefetch cursor
+// stays inside the current output tile (kt + 2 < nk), no wait is skipped (kt >= 2) and no drain is due, so the step is straight-line
+// code between its two barriers.  K_STEP_PP spends ~10 scalar branches per step on those cases, and a wave's taken branches sit on
+// the critical path between two barriers (the partner group cannot start its phase before this one arrives).  Both groups execute
+// both counted waits: the one a group does not need is already satisfied.  NI4_ = four n-tiles per wave (literal).
+#define K_STEP_PP_FAST(NI4_)                                                                                \
+  {                                                                                                         \
+    unsigned char* pfb = smem + pf_st * V2_STAGE;                                                           \
+    const int pko = pf_kt * 64;                                                                             \
+    const unsigned char* base = smem + st * V2_STAGE;                                                       \
+    bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);                             \
+      al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
+    }                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      if (i < 3 || NI4_) {                                                                                  \
+        wh[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_hi);                           \
+        wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                           \
+      }                                                                                                     \
+    }                                                                                                       \
+    MX_FILL()                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    GLDS16(sa0 + pko, pfb + lds_a);                                                                         \
+    GLDS16(sa1 + pko, pfb + lds_a + 1024);                                                                  \
+    GLDS16(sa2 + pko, pfb + lds_a + 2048);                                                                  \
+    GLDS16(sa3 + pko, pfb + lds_a + 3072);                                                                  \
+    GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w);                                                            \
+    GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                        \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    MFMA_CHUNK(0)                                                                                           \
+    MFMA_CHUNK(1)                                                                                           \
+    MFMA_CHUNK(2)                                                                                           \
+    if (NI4_) { MFMA_CHUNK(3) }                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                     \
+    ++pf_j;                                                                                                 \
+    ++pf_kt;                                                                                                \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                        \
+    __builtin_amdgcn_s_barrier();                                                                           \
     st = st == 2 ? 0 : st + 1;                                                                              \
     ++j;                                                                                                    \
   }
@@ -395,9 +462,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   for (int tdone = 0; tdone < my_tiles; ++tdone) {
     if constexpr (PP) {
       if (grp) __builtin_amdgcn_s_barrier();
-      if constexpr (FMT == MMSA_FMT_H8) {
+      // k-tiles 0, 1 (a wait may be skipped after an epilogue) and nk-2, nk-1 (the prefetch cursor moves to the next output tile, the
+      // last one drains) run the general step, everything between them the straight-line one.
+      const bool fast_ok = V2_FAST_STEPS && nk >= 6 && (a.debug < 3 || a.debug == 10) && (FMT != MMSA_FMT_H8 || ni4);   // h8: a second copy of the loop for 96-column tiles costs registers (spills)
+      const int kt_a = fast_ok ? 2 : nk, kt_b = fast_ok ? nk - 2 : nk;
+      if constexpr (FMT == MMSA_FMT_H8) {   // nk is even (checked by the launcher): the fp8 operand tuples are filled by a PAIR of k-tiles
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {   // nk is even (checked by the launcher)
+        for (int kt = 0; kt < kt_a; ++kt) {
+#define MXPAR 0
+          K_STEP_PP()
+#undef MXPAR
+          ++kt;
+#define MXPAR 1
+          K_STEP_PP()
+#undef MXPAR
+        }
+#pragma unroll 1
+        for (int kt = kt_a; kt < kt_b; kt += 2) {
+#define MXPAR 0
+          K_STEP_PP_FAST(true)
+#undef MXPAR
+#define MXPAR 1
+          K_STEP_PP_FAST(true)
+#undef MXPAR
+        }
+        if (fast_ok) {   // the straight-line steps left the prefetch cursor at k-tile nk of this output tile: move it to the next one
+          pf_kt = 0;
+          pf_tile += G;
+          if (pf_j < total) SET_TILE_SRC(pf_tile);
+        }
+#pragma unroll 1
+        for (int kt = kt_b; kt < nk; ++kt) {
 #define MXPAR 0
           K_STEP_PP()
 #undef MXPAR
@@ -409,7 +504,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       } else {
 #define MXPAR 0
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) K_STEP_PP()
+        for (int kt = 0; kt < kt_a; ++kt) K_STEP_PP()
+        if (ni4) {
+#pragma unroll 1
+          for (int kt = kt_a; kt < kt_b; ++kt) K_STEP_PP_FAST(true)
+        } else {
+#pragma unroll 1
+          for (int kt = kt_a; kt < kt_b; ++kt) K_STEP_PP_FAST(false)
+        }
+        if (fast_ok) {   // the straight-line steps left the prefetch cursor at k-tile nk of this output tile: move it to the next one
+          pf_kt = 0;
+          pf_tile += G;
+          if (pf_j < total) SET_TILE_SRC(pf_tile);
+        }
+#pragma unroll 1
+        for (int kt = kt_b; kt < nk; ++kt) K_STEP_PP()
 #undef MXPAR
       }
       if (!grp) __builtin_amdgcn_s_barrier();
@@ -421,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     }
     const int st_cur = st == 0 ? V2_NST - 1 : st - 1;   // ring slot of the k-tile just consumed: free until the next DMA into it (issued after the next barrier)
 
-    if (a.debug == 2) { tile += G; continue; }
+    if (a.debug == 2 || a.debug == 5 || a.debug >= 64) { tile += G; continue; }
     // ---- tile boundary.  MFMA layout: lane holds C[m = ..+l15][n = ..+4g .. +3].  Each wave transposes 16 x 64
     // sub-tiles through the ring slot it has just finished computing from, so that residual loads and output stores
     // are FULL 256-byte row segments (4 rows per wave-instruction).  After the transpose a lane owns the SAME 4
@@ -705,8 +814,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     }
     tile += G;
   }
+  CLK_SAMPLE(2)
 #undef K_STEP
 #undef K_STEP_PP
+#undef K_STEP_PP_FAST
 #undef PP_WAIT
 #undef PP_PIECE
 #undef MFMA_CHUNK

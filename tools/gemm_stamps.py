@@ -9,13 +9,15 @@ import mmsa  # noqa: E402
 from mmsa import lib  # noqa: E402
 ops = mmsa.ops
 M, N, K = (int(v) for v in sys.argv[2:5])
-a = ops.split_planes(torch.randn(M, K, device="cuda:0"), kpad=K)
-w = ops.split_planes(torch.randn(N, K, device="cuda:0") / K ** 0.5)
+h8 = os.environ.get("MMSA_ABLATE_FMT") == "h8"
+fmt = ops.FMT_H8 if h8 else ops.FMT_B3
+a = ops.split_planes(torch.randn(M, K, device="cuda:0"), kpad=K, fmt=fmt)
+w = ops.split_planes(torch.randn(N, K, device="cuda:0") / K ** 0.5, fmt=fmt, weight=h8)
 out = torch.empty(M, N, device="cuda:0")
 for _ in range(5):
     ops.gemm(a, w, out=out)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 320)()
+buf = (ctypes.c_ulonglong * 324)()
 h = lib.handle() if hasattr(lib, "handle") else lib._lib
 rc = h.mmsa_debug_stamps(buf)
 names = ["start", "reads issued", "dma issued", "lgkm0", "vm wait", "barrier1", "mfma issued", "vm wait", "barrier2"]
@@ -24,3 +26,5 @@ for wv in range(8):
     for s in range(4):
         b = [(buf[(wv * 4 + s) * 10 + q] - t0) for q in range(9)]
         print(f"wave {wv} grp {wv >> 2} kt {8 + s}: start {b[0]:6d} | " + " ".join(f"{names[q + 1]} +{b[q + 1] - b[q]:4d}" for q in range(8)) + f" | step {b[8] - b[0]}")
+cyc, real = buf[322] - buf[320], buf[323] - buf[321]
+print(f"workgroup 0: {cyc} shader cycles in {real} ticks of the 100 MHz counter = {real / 100:.1f} us -> average shader clock {cyc / real * 0.1:.3f} GHz" if real else "no clock sample")
