@@ -50,6 +50,12 @@ struct GemmV2Args {
 #define V2_W_BYTES (V2_BN * 128)                        // 16 KiB
 // per workgroup flavour (template parameter NW of the kernel): rows per tile 256 / 128, A stage 32 / 16 KiB, ring 3 x 48 / 2 x 32 KiB
 #define V2_LDS_BYTES(NW_) (((NW_) == 8 ? 3 : 2) * ((NW_) * 32 * 128 + V2_W_BYTES))
+#ifndef V2_FP8_FIRST
+#define V2_FP8_FIRST 1   // 0: fp8 and fp16 MFMAs interleaved per output tile (A/B timing)
+#endif
+#ifndef V2_EXP_NO_FP8
+#define V2_EXP_NO_FP8 0   // timing experiment: leave the fp8 cross-term MFMAs out (wrong results)
+#endif
 #ifndef V2_FAST_STEPS
 #define V2_FAST_STEPS 1   // 0: every k-tile runs the general step (A/B timing; the ablation build -DV2_KABL needs it)
 #endif
@@ -129,7 +135,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   const int dpiece = ((lane & 7) ^ (drow >> 1)) * 8;         // even 8-row groups; odd groups use dpiece ^ 32
   const int lds_a = wave * 32 * 128;   // this wave's 32 rows of the A image (4 instructions x 8 rows)
   const int lds_w = wave * WROWS * 128;   // this wave's rows of the W image (2 or 4 instructions)
-  const unsigned short *sa0, *sa1, *sa2, *sa3, *sw0, *sw1, *sw2 = nullptr, *sw3 = nullptr;
+  // DMA source of piece i = wave-uniform base of the output tile's first row (SGPR pair) + a 32-bit per-lane byte offset: the
+  // `global_load_lds ... v_off, s[base]` form -- one scalar add per k-tile and operand instead of a 64-bit vector add per piece.
+  const unsigned char *gA, *gW;
+  unsigned oa0, oa1, oa2, oa3, ow0, ow1, ow2 = 0, ow3 = 0;
+#define SA(i_, ko_) reinterpret_cast<const unsigned short*>(gA + (long)(ko_) * 2 + (unsigned long)oa##i_)
+#define SW(i_, ko_) reinterpret_cast<const unsigned short*>(gW + (long)(ko_) * 2 + (unsigned long)ow##i_)
 
 // Tile index inside a batch -> (m-tile, n-tile).  The 32 workgroups that share an XCD (consecutive logical ids) hold 32 consecutive
 // tile indices at any time; row-major order made those one row of up to 32 n-tiles, i.e. every XCD streamed the WHOLE weight
@@ -159,34 +170,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     V2_TILE_MN(r_, tmi_, tni_);                                                  \
     const int m0_ = tmi_ * V2_BM, n0_ = tni_ * a.bn;                             \
     const int ab_ = m0_ + wave * 32 + drow, wb_ = n0_ + wave * WROWS + drow;     \
-    const unsigned short* ap_ = a.Ap + (long)bz_ * a.strideA;                    \
-    const unsigned short* wp_ = a.Wp + (long)bz_ * a.strideW;                    \
-    sa0 = ap_ + (long)min(ab_, a.M - 1) * a.lda + dpiece;                        \
-    sa1 = ap_ + (long)min(ab_ + 8, a.M - 1) * a.lda + (dpiece ^ 32);             \
-    sa2 = ap_ + (long)min(ab_ + 16, a.M - 1) * a.lda + dpiece;                   \
-    sa3 = ap_ + (long)min(ab_ + 24, a.M - 1) * a.lda + (dpiece ^ 32);            \
-    sw0 = wp_ + (long)min(wb_, a.N - 1) * a.ldw + dpiece;                        \
-    sw1 = wp_ + (long)min(wb_ + 8, a.N - 1) * a.ldw + (dpiece ^ 32);             \
+    gA = reinterpret_cast<const unsigned char*>(a.Ap + (long)bz_ * a.strideA + (long)m0_ * a.lda);  \
+    gW = reinterpret_cast<const unsigned char*>(a.Wp + (long)bz_ * a.strideW + (long)n0_ * a.ldw);  \
+    oa0 = (unsigned)((min(ab_, a.M - 1) - m0_) * (int)a.lda + dpiece) * 2u;           \
+    oa1 = (unsigned)((min(ab_ + 8, a.M - 1) - m0_) * (int)a.lda + (dpiece ^ 32)) * 2u;  \
+    oa2 = (unsigned)((min(ab_ + 16, a.M - 1) - m0_) * (int)a.lda + dpiece) * 2u;      \
+    oa3 = (unsigned)((min(ab_ + 24, a.M - 1) - m0_) * (int)a.lda + (dpiece ^ 32)) * 2u; \
+    ow0 = (unsigned)((min(wb_, a.N - 1) - n0_) * (int)a.ldw + dpiece) * 2u;           \
+    ow1 = (unsigned)((min(wb_ + 8, a.N - 1) - n0_) * (int)a.ldw + (dpiece ^ 32)) * 2u;  \
     if constexpr (NW == 4) {                                                     \
-      sw2 = wp_ + (long)min(wb_ + 16, a.N - 1) * a.ldw + dpiece;                 \
-      sw3 = wp_ + (long)min(wb_ + 24, a.N - 1) * a.ldw + (dpiece ^ 32);          \
+      ow2 = (unsigned)((min(wb_ + 16, a.N - 1) - n0_) * (int)a.ldw + dpiece) * 2u;    \
+      ow3 = (unsigned)((min(wb_ + 24, a.N - 1) - n0_) * (int)a.ldw + (dpiece ^ 32)) * 2u; \
     }                                                                            \
-    if (a.debug == 4 || a.debug == 5) sa1 = sa2 = sa3 = sw0 = sw1 = sa0;   /* timing experiment: L1-resident operand stream */ \
+    if (a.debug == 4 || a.debug == 5) { oa1 = oa2 = oa3 = oa0; gW = gA; ow0 = ow1 = oa0; }   /* timing experiment: L1-resident operand stream */ \
   } while (0)
 
 #define ISSUE_DMA(kt_, st_)                                                       \
   do {                                                                            \
     unsigned char* sb_ = smem + (st_) * V2_STAGE;                                 \
     const int ko_ = a.debug == 3 ? 0 : (kt_) * 64;   /* debug 3: timing experiment, re-read k-tile 0 */ \
-    GLDS16(sa0 + ko_, sb_ + lds_a);                                               \
-    GLDS16(sa1 + ko_, sb_ + lds_a + 1024);                                        \
-    GLDS16(sa2 + ko_, sb_ + lds_a + 2048);                                        \
-    GLDS16(sa3 + ko_, sb_ + lds_a + 3072);                                        \
-    GLDS16(sw0 + ko_, sb_ + V2_A_BYTES + lds_w);                                  \
-    GLDS16(sw1 + ko_, sb_ + V2_A_BYTES + lds_w + 1024);                           \
+    GLDS16(SA(0, ko_), sb_ + lds_a);                                               \
+    GLDS16(SA(1, ko_), sb_ + lds_a + 1024);                                        \
+    GLDS16(SA(2, ko_), sb_ + lds_a + 2048);                                        \
+    GLDS16(SA(3, ko_), sb_ + lds_a + 3072);                                        \
+    GLDS16(SW(0, ko_), sb_ + V2_A_BYTES + lds_w);                                  \
+    GLDS16(SW(1, ko_), sb_ + V2_A_BYTES + lds_w + 1024);                           \
     if constexpr (NW == 4) {                                                      \
-      GLDS16(sw2 + ko_, sb_ + V2_A_BYTES + lds_w + 2048);                         \
-      GLDS16(sw3 + ko_, sb_ + V2_A_BYTES + lds_w + 3072);                         \
+      GLDS16(SW(2, ko_), sb_ + V2_A_BYTES + lds_w + 2048);                         \
+      GLDS16(SW(3, ko_), sb_ + V2_A_BYTES + lds_w + 3072);                         \
     }                                                                             \
   } while (0)
 
@@ -241,11 +252,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   { const uint4 u_ = __builtin_bit_cast(uint4, src_);                                                       \
     if ((par_) == 0) { dst_[0] = (int)u_.x; dst_[1] = (int)u_.y; dst_[2] = (int)u_.z; dst_[3] = (int)u_.w; }  \
     else { dst_[4] = (int)u_.x; dst_[5] = (int)u_.y; dst_[6] = (int)u_.z; dst_[7] = (int)u_.w; } }
+// h8, second k-tile of a pair: the 16 block-scaled fp8 MFMAs (cross terms of both k-tiles) go FIRST, the fp16 MFMAs last.  MFMAs are
+// queued: a wave reaches the barrier that ends its matrix phase with its last MFMAs still waiting for the pipe, and its next read
+// phase overwrites the fp8 operand tuples -- every fragment read of that phase then stalls until the queued fp8 MFMAs have read
+// them (interval stamps: the read phase after an fp8 burst took 1150-1400 cycles, the other one 600).  With the fp16 MFMAs at the
+// tail the registers still in use are the hi fragments of the finished k-tile, which the next read phase does not touch.
+#define MFMA_FP8_ALL(NI4_)                                                                                  \
+  if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
+    if (MXPAR && V2_FP8_FIRST && !V2_EXP_NO_FP8) {                                                          \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                      \
+        if (ni < 3 || (NI4_)) {                                                                             \
+          _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
+        }                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }                                                                                                       \
+  }
 #define MFMA_CHUNK(ni)                                                                                      \
   if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                      \
       acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wh[ni]), __builtin_bit_cast(mx_h8, ah[mi]), acc[ni][mi], 0, 0, 0); \
-      if (MXPAR) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
+      if (MXPAR && !V2_FP8_FIRST && !V2_EXP_NO_FP8) acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
     }                                                                                                       \
   } else {                                                                                                  \
     if (V2_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                          \
@@ -280,16 +307,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     MFMA_CHUNK(0)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (do_pf) { GLDS16(sa0 + pko, pfb + lds_a); GLDS16(sa1 + pko, pfb + lds_a + 1024); }                   \
+    if (do_pf) { GLDS16(SA(0, pko), pfb + lds_a); GLDS16(SA(1, pko), pfb + lds_a + 1024); }                   \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     MFMA_CHUNK(1)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (do_pf) { GLDS16(sa2 + pko, pfb + lds_a + 2048); GLDS16(sa3 + pko, pfb + lds_a + 3072); }            \
+    if (do_pf) { GLDS16(SA(2, pko), pfb + lds_a + 2048); GLDS16(SA(3, pko), pfb + lds_a + 3072); }            \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     MFMA_CHUNK(2)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (do_pf) { GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w); GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024); } \
-    if constexpr (NW == 4) { if (do_pf) { GLDS16(sw2 + pko, pfb + V2_A_BYTES + lds_w + 2048); GLDS16(sw3 + pko, pfb + V2_A_BYTES + lds_w + 3072); } } \
+    if (do_pf) { GLDS16(SW(0, pko), pfb + V2_A_BYTES + lds_w); GLDS16(SW(1, pko), pfb + V2_A_BYTES + lds_w + 1024); } \
+    if constexpr (NW == 4) { if (do_pf) { GLDS16(SW(2, pko), pfb + V2_A_BYTES + lds_w + 2048); GLDS16(SW(3, pko), pfb + V2_A_BYTES + lds_w + 3072); } } \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (ni4) { MFMA_CHUNK(3) }                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -333,12 +360,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   }
 #define PP_PIECE(i_)                                                                                        \
   if (do_pf) {                                                                                              \
-    if ((i_) == 0) GLDS16(sa0 + pko, pfb + lds_a);                                                          \
-    if ((i_) == 1) GLDS16(sa1 + pko, pfb + lds_a + 1024);                                                   \
-    if ((i_) == 2) GLDS16(sa2 + pko, pfb + lds_a + 2048);                                                   \
-    if ((i_) == 3) GLDS16(sa3 + pko, pfb + lds_a + 3072);                                                   \
-    if ((i_) == 4) GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w);                                             \
-    if ((i_) == 5) GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024);                                      \
+    if ((i_) == 0) GLDS16(SA(0, pko), pfb + lds_a);                                                          \
+    if ((i_) == 1) GLDS16(SA(1, pko), pfb + lds_a + 1024);                                                   \
+    if ((i_) == 2) GLDS16(SA(2, pko), pfb + lds_a + 2048);                                                   \
+    if ((i_) == 3) GLDS16(SA(3, pko), pfb + lds_a + 3072);                                                   \
+    if ((i_) == 4) GLDS16(SW(0, pko), pfb + V2_A_BYTES + lds_w);                                             \
+    if ((i_) == 5) GLDS16(SW(1, pko), pfb + V2_A_BYTES + lds_w + 1024);                                      \
   }
 #define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } }
 // k-loop ablation build (tools/build_variant.sh -DV2_KABL, timing only, results are garbage): MMSA_GEMM_DEBUG = 64 + a bit mask of what
@@ -346,9 +373,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 #ifdef V2_KABL
 #define KABL(x_) (a.debug >= 64 && ((a.debug >> ((x_) - 6)) & 1))
 #define KABL_INIT() _Pragma("unroll") for (int i = 0; i < 4; ++i) { ah[i] = al[i] = wh[i] = wl[i] = __builtin_bit_cast(bf16x8, make_uint4(lane + i, 0x3c003c00u, lane, 0x3c003c00u)); }
+#define KABL_UNDEF() _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(ah[i]), "=v"(al[i]), "=v"(wh[i]), "=v"(wl[i])); }   /* fragments = whatever the registers hold */
 #else
 #define KABL(x_) false
 #define KABL_INIT()
+#define KABL_UNDEF()
 #endif
 #define K_STEP_PP()                                                                                         \
   {                                                                                                         \
@@ -385,6 +414,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     STAMP(5)                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (!KABL(6)) {                                                                                         \
+    MFMA_FP8_ALL(ni4)                                                                                       \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
     MFMA_CHUNK(2)                                                                                           \
@@ -422,6 +452,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     const int pko = pf_kt * 64;                                                                             \
     const unsigned char* base = smem + st * V2_STAGE;                                                       \
     bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
+    if (KABL(7)) { KABL_UNDEF() } else {                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
       ah[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_hi);                             \
       al[i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 2048 + frag_lo);                             \
@@ -432,39 +463,57 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
         wl[i] = *reinterpret_cast<const bf16x8*>(base + fw + i * 2048 + frag_lo);                           \
       }                                                                                                     \
     }                                                                                                       \
+    }                                                                                                       \
     MX_FILL()                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    GLDS16(sa0 + pko, pfb + lds_a);                                                                         \
-    GLDS16(sa1 + pko, pfb + lds_a + 1024);                                                                  \
-    GLDS16(sa2 + pko, pfb + lds_a + 2048);                                                                  \
-    GLDS16(sa3 + pko, pfb + lds_a + 3072);                                                                  \
-    GLDS16(sw0 + pko, pfb + V2_A_BYTES + lds_w);                                                            \
-    GLDS16(sw1 + pko, pfb + V2_A_BYTES + lds_w + 1024);                                                     \
+    if (!KABL(8)) {                                                                                         \
+    GLDS16(SA(0, pko), pfb + lds_a);                                                                        \
+    GLDS16(SA(1, pko), pfb + lds_a + 1024);                                                                 \
+    GLDS16(SA(2, pko), pfb + lds_a + 2048);                                                                 \
+    GLDS16(SA(3, pko), pfb + lds_a + 3072);                                                                 \
+    GLDS16(SW(0, pko), pfb + V2_A_BYTES + lds_w);                                                           \
+    GLDS16(SW(1, pko), pfb + V2_A_BYTES + lds_w + 1024);                                                    \
+    }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                        \
     __builtin_amdgcn_s_barrier();                                                                           \
+    ISTAMP(0)                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (!KABL(6)) {                                                                                         \
+    MFMA_FP8_ALL(NI4_)                                                                                      \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
     MFMA_CHUNK(2)                                                                                           \
     if (NI4_) { MFMA_CHUNK(3) }                                                                             \
+    }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     pf_st = pf_st == 2 ? 0 : pf_st + 1;                                                                     \
     ++pf_j;                                                                                                 \
     ++pf_kt;                                                                                                \
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                        \
     __builtin_amdgcn_s_barrier();                                                                           \
+    ISTAMP(1)                                                                                               \
     st = st == 2 ? 0 : st + 1;                                                                              \
     ++j;                                                                                                    \
   }
+// interval stamps (-DV2_STAMP): the shader clock right after each barrier of the straight-line steps kt = 8..15 of workgroup 0's first
+// tile, waves 0 (group 0) and 4 (group 1), stored by lane 0
+#ifdef V2_STAMP
+#ifndef V2_ISTAMP_KT0
+#define V2_ISTAMP_KT0 8
+#endif
+#define ISTAMP(h_) if (blockIdx.x == 0 && tdone == 0 && kt >= V2_ISTAMP_KT0 && kt < V2_ISTAMP_KT0 + 8 && (wave & 3) == 0 && lane == 0) g_v2_stamps[grp * 16 + (kt + MXPAR - V2_ISTAMP_KT0) * 2 + (h_)] = __builtin_readcyclecounter();
+#else
+#define ISTAMP(h_)
+#endif
 
   for (int tdone = 0; tdone < my_tiles; ++tdone) {
     if constexpr (PP) {
       if (grp) __builtin_amdgcn_s_barrier();
       // k-tiles 0, 1 (a wait may be skipped after an epilogue) and nk-2, nk-1 (the prefetch cursor moves to the next output tile, the
       // last one drains) run the general step, everything between them the straight-line one.
-      const bool fast_ok = V2_FAST_STEPS && nk >= 6 && (a.debug < 3 || a.debug == 10) && (FMT != MMSA_FMT_H8 || ni4);   // h8: a second copy of the loop for 96-column tiles costs registers (spills)
+      const bool fast_ok = V2_FAST_STEPS && nk >= 6 && (a.debug < 3 || a.debug == 10 || a.debug >= 64) && (FMT != MMSA_FMT_H8 || ni4);   // h8: a second copy of the loop for 96-column tiles costs registers (spills)
       const int kt_a = fast_ok ? 2 : nk, kt_b = fast_ok ? nk - 2 : nk;
       if constexpr (FMT == MMSA_FMT_H8) {   // nk is even (checked by the launcher): the fp8 operand tuples are filled by a PAIR of k-tiles
 #pragma unroll 1
@@ -821,6 +870,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 #undef PP_WAIT
 #undef PP_PIECE
 #undef MFMA_CHUNK
+#undef MFMA_FP8_ALL
 }
 
 static int g_num_cus = 0;

@@ -20,6 +20,15 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 324)()
 h = lib.handle() if hasattr(lib, "handle") else lib._lib
 rc = h.mmsa_debug_stamps(buf)
+if os.environ.get("MMSA_ISTAMP"):   # interval stamps of the straight-line steps: clock after each barrier, waves 0 and 4
+    t0 = min(buf[i] for i in range(32) if buf[i])
+    for grp in range(2):
+        ts = [buf[grp * 16 + i] - t0 for i in range(16)]
+        print(f"group {grp}: barrier exits " + " ".join(f"{t:6d}" for t in ts))
+        print(f"         intervals      " + " ".join(f"{b - a:6d}" for a, b in zip(ts, ts[1:])) + "   (even = after the read phase's barrier -> MFMA phase, odd = MFMA phase's barrier -> read phase)")
+    cyc, real = buf[322] - buf[320], buf[323] - buf[321]
+    print(f"workgroup 0: {cyc} shader cycles in {real / 100:.1f} us -> average shader clock {cyc / real * 0.1:.3f} GHz")
+    sys.exit(0)
 names = ["start", "reads issued", "dma issued", "lgkm0", "vm wait", "barrier1", "mfma issued", "vm wait", "barrier2"]
 t0 = min(buf[(wv * 4) * 10] for wv in range(8))
 for wv in range(8):
