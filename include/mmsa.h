@@ -100,7 +100,9 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * A is EITHER fp32 (`A`, split to hi/lo while staged) OR interleaved activation planes (`Ap`, written by the
  * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
  * The result goes to fp32 `C`, to planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both.
- * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`.
+ * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`:
+ * bits 0..7 MMSA_FMT_*, bits 8.. = split / 32 -- columns >= split (a multiple of 32; 0 = none) are written as MMSA_FMT_H8 planes
+ * whatever the base format (the qkv projection: q and k bf16 hi/lo, v with an fp16 hi part for the attention kernels' v_fmt = 1).
  * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
  * its share of the CUs); 0 = all CUs.  Results do not depend on it. */
 int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
@@ -132,7 +134,10 @@ int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const floa
 /* same with qkv [.., 2*3D], qkv_bias [2*3D] and the output [.., 2*D] as interleaved planes (strides in uint16) */
 int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const float* rp,
                           uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim,
-                          int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */, mmsa_stream_t stream);
+                          int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
+                          int v_fmt /* 0: v columns of qkv_planes / bias_planes are bf16 hi/lo planes; 1: h8 planes (fp16 hi, as the qkv GEMM
+                                       writes them with cp_fmt = MMSA_FMT_B3 | (2D/32) << 8): P V runs on the fp16 MFMA with P rounded to fp16 */,
+                          mmsa_stream_t stream);
 
 /* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
  * get_rel_pos(...)  (IE:554-584), (KH,KW,QS) = (ws,ws,ws) for windowed blocks or (H,W,max) for global ones. */
@@ -213,7 +218,7 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
  *     H <= 64 and a multiple of 4, head_dim 64.  No mmsa_relpos_bias pass. --- */
 int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const uint16_t* relpos_planes,
                                  uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim, float scale,
-                                 int out_fmt /* MMSA_FMT_* of out_planes */, mmsa_stream_t stream);
+                                 int out_fmt /* MMSA_FMT_* of out_planes */, int v_fmt /* as mmsa_attention_planes */, mmsa_stream_t stream);
 
 /* --- windowed attention with the rel-pos bias fused (Block.forward IE:382-423 on a window_size > 0 block: window_partition ->
  *     Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 -> window_unpartition).  qkv / bias / out as in
@@ -224,7 +229,7 @@ int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uin
 int mmsa_window_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes,
                                  const uint16_t* relpos_planes, const uint16_t* selector, uint16_t* out_planes, long ldo, int B, int H, int W,
                                  int heads, int head_dim, int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
-                                 mmsa_stream_t stream);
+                                 int v_fmt /* as mmsa_attention_planes */, mmsa_stream_t stream);
 
 /* --- Segformer decode head (segmentation/mmseg_custom/models/decode_heads/segformer_head.py:47-66; the 1x1 convs are
  *     mmsa_gemm_split3 calls).  nchw_to_planes: backbone map [B,C,HW] fp32 (image b at b*strideB) -> interleaved planes

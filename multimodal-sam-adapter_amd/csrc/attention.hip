@@ -29,6 +29,7 @@ struct AttnArgs {
   const unsigned short* bp;      // ilv planes form of qkv_bias [2*3D]
   unsigned short* op;            // ilv planes output (PL kernels), row stride ldo (>= 2*D)
   int ofmt;                      // format of the planes output (common.h): bf16 hi/lo, or h8 for an h8 proj GEMM
+  int vf;                        // PL kernels: 1 = the v columns of qp / bp are h8 planes (fp16 hi): P V on the fp16 MFMA (VF kernels)
   const float* rp;               // [B, heads, T, KH+KW] rel-pos bias terms (relpos kernel below)
   const unsigned short* relg;    // REL kernels: planes of a [256, 64] matrix, rows 0..2KH-2 = rel_pos_h, rows 128..128+2KW-2 = rel_pos_w
   float* out; long ldo;          // [B*T, D], channel = head*HD + c (IE:498)
@@ -44,8 +45,14 @@ struct AttnArgs {
 
 // REL (with PL, FB, HD = 64): the rel-pos terms are computed in the kernel's prologue (MFMA, like wattn.hip) instead of being
 // read from the prepass output
-template <int HD, bool PL, bool FB, bool REL = false>
+// VF (with PL): the v columns of the qkv planes carry an fp16 hi part (h8 planes: the qkv GEMM writes them that way, common.h
+// MMSA_CP_SPLIT) and P V runs as ONE fp16 MFMA per product with P rounded to fp16 -- instead of three bf16 MFMAs on hi/lo pairs of
+// both.  P <= 1 has 11 significant bits in fp16 and its rounding errors average out over the keys; measured on the CPU oracle
+// (ViT-B 512^2, every attention block): 2.9e-5 relative on f1..f4 against 1.2e-4 for a bf16 P.  Q K^T stays on
+// bf16 hi/lo pairs: the scores are exponentiated.
+template <int HD, bool PL, bool FB, bool REL = false, bool VF = false>
 __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(AttnArgs a) {
+  static_assert(!VF || PL, "the fp16 P V path reads planes");
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
   constexpr int DT = HD / 16;            // output d tiles
@@ -246,12 +253,12 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
           rkh[i] = *reinterpret_cast<const uint4*>(kr_);                                     \
           rkl[i] = *reinterpret_cast<const uint4*>(kr_ + 32);                                \
           rvh[i] = *reinterpret_cast<const uint4*>(vr_);                                     \
-          rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);                                \
+          if constexpr (!VF) rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);             \
         } else if (tk_ == -1) {                                                              \
           rkh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c));                    \
           rkl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c) + 32);               \
           rvh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c));                    \
-          rvl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c) + 32);               \
+          if constexpr (!VF) rvl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c) + 32); \
         } else {                                                                             \
           rkh[i] = make_uint4(0u, 0u, 0u, 0u); rkl[i] = rkh[i]; rvh[i] = rkh[i]; rvl[i] = rkh[i]; \
         }                                                                                    \
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         *reinterpret_cast<uint4*>(Klo + ko) = rkl[i];                                        \
         const int vo = skey * VSTR + c * 2;                                                  \
         *reinterpret_cast<uint4*>(Vhi + vo) = rvh[i];                                        \
-        *reinterpret_cast<uint4*>(Vlo + vo) = rvl[i];                                        \
+        if constexpr (!VF) *reinterpret_cast<uint4*>(Vlo + vo) = rvl[i];                     \
       }                                                                                      \
     } else {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
@@ -404,7 +411,8 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
           const float p0 = __builtin_amdgcn_exp2f(s[sub][t][r] - m_sub);
           const float p1 = __builtin_amdgcn_exp2f(s[sub][t][r + 1] - m_sub);
           psum += p0 + p1;
-          split2(p0, p1, hp[u], lp[u]);
+          if constexpr (VF) { hp[u] = pack_f16(p0, p1); lp[u] = 0u; }
+          else split2(p0, p1, hp[u], lp[u]);
         }
         ph[sub][s2] = __builtin_bit_cast(bf16x8, hh);
         pl[sub][s2] = __builtin_bit_cast(bf16x8, ll);
@@ -428,15 +436,21 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         const int voff = row0 * VSTR + (16 * d + 4 * (l15 & 3)) * 2;
         const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
         const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + 16 * VSTR));
-        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
-        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + 16 * VSTR));
         const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (VF) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-          o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[sub][s2], o[sub][d], 0, 0, 0);
-          o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[sub][s2], o[sub][d], 0, 0, 0);
-          o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[sub][s2], o[sub][d], 0, 0, 0);
+          for (int sub = 0; sub < 2; ++sub)
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph[sub][s2]), o[sub][d], 0, 0, 0);
+        } else {
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + 16 * VSTR));
+          const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[sub][s2], o[sub][d], 0, 0, 0);
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[sub][s2], o[sub][d], 0, 0, 0);
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[sub][s2], o[sub][d], 0, 0, 0);
+          }
         }
       }
     }
@@ -506,19 +520,30 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, PL_, FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((attn_kernel<HD_, PL_, FB_>), grid, dim3(256), smem, stream, a);                                    \
   } while (0)
+#define ATTN_LAUNCH_VF(HD_, FB_)                                                                                           \
+  do {                                                                                                                     \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, true, FB_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((attn_kernel<HD_, true, FB_, false, true>), grid, dim3(256), smem, stream, a);                      \
+  } while (0)
+  MMSA_CHECK_ARG(a.vf == 0 || (a.vf == 1 && planes), "attention: v_fmt %d (0 = bf16 hi/lo planes, 1 = h8 planes for the v columns)", a.vf);
   if (head_dim == 64) {
     if (planes && a.relg) {
       MMSA_CHECK_ARG(fb && H <= 64 && 128 * a.KWs * (int)sizeof(float) <= 2 * 8 * 64 * 16 + 2 * 64 * VSTR, "attention: the fused rel-pos path needs a W = 64, H <= 64 global grid");
-      hipLaunchKernelGGL((attn_kernel<64, true, true, true>), grid, dim3(256), smem, stream, a);
-    } else if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
+      if (a.vf) hipLaunchKernelGGL((attn_kernel<64, true, true, true, true>), grid, dim3(256), smem, stream, a);
+      else hipLaunchKernelGGL((attn_kernel<64, true, true, true>), grid, dim3(256), smem, stream, a);
+    } else if (planes && a.vf) { if (fb) ATTN_LAUNCH_VF(64, true); else ATTN_LAUNCH_VF(64, false); }
+    else if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }
     else { if (fb) ATTN_LAUNCH(64, false, true); else ATTN_LAUNCH(64, false, false); }
   } else if (head_dim == 96) {
-    if (planes) { if (fb) ATTN_LAUNCH(96, true, true); else ATTN_LAUNCH(96, true, false); }
+    if (planes && a.vf) { if (fb) ATTN_LAUNCH_VF(96, true); else ATTN_LAUNCH_VF(96, false); }
+    else if (planes) { if (fb) ATTN_LAUNCH(96, true, true); else ATTN_LAUNCH(96, true, false); }
     else { if (fb) ATTN_LAUNCH(96, false, true); else ATTN_LAUNCH(96, false, false); }
   } else {
-    if (planes) { if (fb) ATTN_LAUNCH(32, true, true); else ATTN_LAUNCH(32, true, false); }
+    if (planes && a.vf) { if (fb) ATTN_LAUNCH_VF(32, true); else ATTN_LAUNCH_VF(32, false); }
+    else if (planes) { if (fb) ATTN_LAUNCH(32, true, true); else ATTN_LAUNCH(32, true, false); }
     else { if (fb) ATTN_LAUNCH(32, false, true); else ATTN_LAUNCH(32, false, false); }
   }
+#undef ATTN_LAUNCH_VF
 #undef ATTN_LAUNCH
   MMSA_CHECK_LAUNCH("attention");
   return MMSA_OK;
@@ -537,14 +562,14 @@ extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias,
 // planes form: qkv, qkv_bias and the output are bf16 hi/lo planes (same layouts, strides in elements)
 extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p, const float* rp,
                                      unsigned short* out_p, long ldo, int B, int H, int W,
-                                     int heads, int head_dim, int window_size, float scale, int out_fmt, hipStream_t stream) {
+                                     int heads, int head_dim, int window_size, float scale, int out_fmt, int v_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && rp && out_p, "attention_planes: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG((heads * head_dim) % 32 == 0, "attention_planes: embed dim must be a multiple of 32");
   AttnArgs a = {};
-  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt; a.vf = v_fmt;
   return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, true, stream);
 }
 
@@ -552,14 +577,14 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, cons
 // of 4, head_dim 64.  relpos_planes: interleaved planes of a [256, 64] matrix, rows 0..2H-2 = rel_pos_h, 128..128+2W-2 = rel_pos_w
 extern "C" int mmsa_global_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p,
                                             const unsigned short* relpos_planes, unsigned short* out_p, long ldo, int B, int H, int W,
-                                            int heads, int head_dim, float scale, int out_fmt, hipStream_t stream) {
+                                            int heads, int head_dim, float scale, int out_fmt, int v_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && relpos_planes && out_p, "global_attention_planes: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "global_attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)relpos_planes) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "global_attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG(head_dim == 64 && W == 64 && H <= 64 && (H % 4) == 0, "global_attention_planes: needs head_dim 64 and a W = 64, H <= 64 (multiple of 4) grid");
   AttnArgs a = {};
-  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt; a.vf = v_fmt;
   return attention_launch(a, B, H, W, heads, head_dim, 0, scale, true, stream);
 }
 

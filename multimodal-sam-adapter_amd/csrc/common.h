@@ -111,10 +111,22 @@ __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k
 // operand bytes of the fp8 MFMA are just the chunks of two consecutive k-blocks, and byte p of A always meets byte p of W with
 // the roles (lo, q(hi)) crossed.  Values are clamped to +-57344 (the largest e5m2 / a finite fp16) before the split.
 enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
+// Output-plane format argument of the GEMM (`cp_fmt`): bits 0..7 = format of the columns below the split, bits 8.. = split / 32;
+// columns >= split (a multiple of 32, 0 = no split) are written as MMSA_FMT_H8.  The qkv projection writes q and k as bf16 hi/lo
+// planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: DESIGN.md 4.1).
+#define MMSA_CP_BASE(f_) ((f_) & 0xff)
+#define MMSA_CP_SPLIT(f_) (((f_) >> 8) * 32)
+#define MMSA_CP_AT(f_, col_) ((MMSA_CP_SPLIT(f_) > 0 && (col_) >= MMSA_CP_SPLIT(f_)) ? MMSA_FMT_H8 : MMSA_CP_BASE(f_))
 #define MMSA_H8_MAX 57344.0f
 #define MMSA_H8_LO_SCALE 2048.0f          // 2^11
 #define MMSA_H8_MFMA_SCALE 0x74747474     // e8m0 127 - 11 in every byte: the block scale that undoes MMSA_H8_LO_SCALE
 typedef __attribute__((ext_vector_type(2))) _Float16 mmsa_h2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // operand of v_mfma_f32_16x16x32_f16
+// two floats -> 2 packed fp16, round to nearest even (softmax probabilities of the attention kernels' fp16 P V)
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const mmsa_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mmsa_h2));
+}
 
 // two floats -> hi (2 packed fp16), lo8 / qh8 (2 e5m2 bytes each, written into the low or high half of `lo8` / `qh8`)
 template <bool UPPER>

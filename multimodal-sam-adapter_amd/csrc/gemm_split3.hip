@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
           o.x += a.beta * rr.x; o.y += a.beta * rr.y; o.z += a.beta * rr.z; o.w += a.beta * rr.w;
         }
         if (C) *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
-        if (Cp) store_planes4(Cp + drow * a.ldcp, dcol, o, a.cp_fmt);
+        if (Cp) store_planes4(Cp + drow * a.ldcp, dcol, o, MMSA_CP_AT(a.cp_fmt, dcol));
       } else {
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
             float x = v[r];
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol + r];
             if (C) C[drow * a.ldc + dcol + r] = x;
-            if (Cp) store_planes1(Cp + drow * a.ldcp, dcol + r, x, a.cp_fmt);
+            if (Cp) store_planes1(Cp + drow * a.ldcp, dcol + r, x, MMSA_CP_AT(a.cp_fmt, dcol + r));
           }
         }
       }
@@ -334,7 +334,8 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 int M, int N, int K, int batch, int act, float alpha,
                                 int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
   const bool ap = Ap != nullptr;
-  MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && (cp_fmt == MMSA_FMT_B3 || cp_fmt == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
+  MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && cp_fmt >= 0 && (MMSA_CP_BASE(cp_fmt) == MMSA_FMT_B3 || MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
+  MMSA_CHECK_ARG(MMSA_CP_SPLIT(cp_fmt) == 0 || (out_mode == 0 && MMSA_CP_SPLIT(cp_fmt) < N), "gemm_split3: the output-format split %d needs a plain [M, N] planes output with N=%d beyond it", MMSA_CP_SPLIT(cp_fmt), N);
   MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 operands need A planes and K %% 64 == 0 (K=%d)", K);
   MMSA_CHECK_ARG((A || Ap) && Wp && (C || Cp), "gemm_split3: null pointer");
   MMSA_CHECK_ARG(!(A && Ap), "gemm_split3: pass either fp32 A or A planes, not both");

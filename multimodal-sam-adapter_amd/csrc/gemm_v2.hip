@@ -607,6 +607,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       }
       float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
       const int nb_ = n0 + wn * swid;
+      const int cp_base = MMSA_CP_BASE(a.cp_fmt);
+      const bool cp_split = MMSA_CP_SPLIT(a.cp_fmt) != 0;   // kernel-uniform: columns >= the split leave as h8 planes (common.h)
       const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
       const int cl = (lane & 15) * 4;
       const bool lane_ok = cl < swid;        // 96-column tiles: the lanes of the (skipped) fourth n-tile only keep the loads in bounds
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
                 else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
               }
               o.x *= cn_[ni].x; o.y *= cn_[ni].y; o.z *= cn_[ni].z; o.w *= cn_[ni].w;
-              store_planes4(wrow, ni * 16 + 4 * g, o, a.cp_fmt);
+              store_planes4(wrow, ni * 16 + 4 * g, o, cp_split ? MMSA_CP_AT(a.cp_fmt, nb_ + ni * 16 + 4 * g) : cp_base);
             }
             uint4 pk[4];
 #pragma unroll
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             uint4 pk = make_uint4(0u, 0u, 0u, 0u);
             if (Cp) {   // either planes format: stage the row image, read it back 16 bytes per lane
               unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
-              store_planes4(srow, cl, o, a.cp_fmt);
+              store_planes4(srow, cl, o, cp_split ? MMSA_CP_AT(a.cp_fmt, nb_ + cl) : cp_base);
               pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
             }
             const int m = mb + rl;
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             map_row(m, n + r, drow_, dcol, rrow);
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
             if (C) C[drow_ * a.ldc + dcol] = x;
-            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, a.cp_fmt);
+            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, MMSA_CP_AT(a.cp_fmt, dcol));
           }
         }
         }
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             uint4 pk = make_uint4(0u, 0u, 0u, 0u);
             if (Cp) {   // either planes format: stage the row image, read it back 16 bytes per lane
               unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
-              store_planes4(srow, cl, o, a.cp_fmt);
+              store_planes4(srow, cl, o, cp_split ? MMSA_CP_AT(a.cp_fmt, nb_ + cl) : cp_base);
               pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
             }
             const int m = mb + rl;
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
             map_row(m, n + r, drow_, dcol, rrow);
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
             if (C) C[drow_ * a.ldc + dcol] = x;
-            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, a.cp_fmt);
+            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, MMSA_CP_AT(a.cp_fmt, dcol));
           }
         }
         }

@@ -315,6 +315,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
 #define WP_R_BYTES (2 * 64 * 128)        // rel-pos table image: [ks][64 rows] of 128 B (GEMM LDS image)
 #define WP_LDS (WA_K_BYTES + 2 * WP_V_BYTES + WA_E_BYTES + WP_R_BYTES + WA_WAVES * WA_B_BYTES)
 
+// VF: the v columns of the qkv planes are h8 planes (fp16 hi) and P V is one fp16 MFMA per product with P rounded to fp16
+// (attention.hip, attn_kernel: same scheme, same error study); the V lo image is then neither transferred nor read.
+template <bool VF>
 __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs a, int nWin, int nitems) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       const int c = slot ^ (((key >> 1) & 3) << 1);                                                           \
       const unsigned short* vsrc = row + 2 * (colv_ + 32 * (c >> 2)) + (c & 3) * 8;                           \
       GLDS16(vsrc, Vhi + (16 * wave + 8 * half) * 128);                                                       \
-      GLDS16(vsrc + 32, Vlo + (16 * wave + 8 * half) * 128);                                                  \
+      if constexpr (!VF) GLDS16(vsrc + 32, Vlo + (16 * wave + 8 * half) * 128);                               \
     }                                                                                                         \
   }
 #define WP_LOAD_Q()                                                                                           \
@@ -566,12 +569,22 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
             }
           }
         }
-        uint4 hh, ll;
-        split2(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
-        split2(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
+        uint4 hh, ll = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (VF) {
+          hh.x = pack_f16(s[2 * g][0], s[2 * g][1]);
+          hh.y = pack_f16(s[2 * g][2], s[2 * g][3]);
+        } else {
+          split2(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
+          split2(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
+        }
         if (2 * g + 1 < 13) {
-          split2(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
-          split2(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
+          if constexpr (VF) {
+            hh.z = pack_f16(s[2 * g + 1][0], s[2 * g + 1][1]);
+            hh.w = pack_f16(s[2 * g + 1][2], s[2 * g + 1][3]);
+          } else {
+            split2(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
+            split2(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
+          }
         } else {
           hh.z = hh.w = ll.z = ll.w = 0u;   // keys 208..223 do not exist
         }
@@ -584,13 +597,17 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
           const int voff = row0 * 128 + ((d ^ sw) << 5) + 8 * (l15 & 3);
           const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
           const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + second));
-          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
-          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + second));
           const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-          const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d], 0, 0, 0);
-          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d], 0, 0, 0);
-          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d], 0, 0, 0);
+          if constexpr (VF) {
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph), o[d], 0, 0, 0);
+          } else {
+            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
+            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + second));
+            const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -614,9 +631,10 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
                                             const unsigned short* relpos_planes, const unsigned short* selector,
                                             unsigned short* out_planes, long ldo,
                                             int B, int H, int W, int heads, int head_dim, int window_size, float scale,
-                                            int out_fmt, hipStream_t stream) {
+                                            int out_fmt, int v_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "window_attention: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(v_fmt == 0 || v_fmt == 1, "window_attention: v_fmt %d (0 = bf16 hi/lo planes, 1 = h8 planes for the v columns)", v_fmt);
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0, "window_attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64, "window_attention: head_dim %d not supported by this kernel (64)", head_dim);
   MMSA_CHECK_ARG(window_size >= 1 && window_size <= 14, "window_attention: window_size %d not supported (1..14)", window_size);
@@ -642,7 +660,8 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
   static int num_cus = 256;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
-    (void)hipFuncSetAttribute((const void*)wattn_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+    (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+    (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -650,14 +669,15 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
     attr_set = true;
   }
   const int nWin = cdiv(H, window_size) * a.nWw;
-  if (v1) {
+  if (v1 && !v_fmt) {
     dim3 grid(nWin, heads, B);
     hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
   } else {
     const int nitems = nWin * heads * B;
     const int rounds = cdiv(nitems, num_cus);
     const int grid = cdiv(nitems, rounds);   // the fewest workgroups that still finish in `rounds` items each: the other CUs stay free for concurrent streams
-    hipLaunchKernelGGL(wattn_persist_kernel, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
+    if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
+    else hipLaunchKernelGGL(wattn_persist_kernel<false>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
   }
   MMSA_CHECK_LAUNCH("window_attention");
   return MMSA_OK;

@@ -196,7 +196,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # "vit" = qkv / proj / lin1 / lin2 of the SAM ViT blocks; "inter" = the Linear layers of the injectors / extractors (MSDA
     # projections, ConvFFN); "up" = the 2x2 transposed conv of the tail.  The TwinConvNeXt / neck GEMMs stay on bf16 hi/lo (the most
     # error-sensitive part of the path: SURVEY appendix F).  `model.h8_sites = ()` or MMSA_H8=none keeps every site on bf16 hi/lo.
-    H8_DEFAULT = ("vit", "inter", "up")
+    # "attnv" = the attention kernels run P V on the fp16 MFMA: the v third of the qkv planes (GEMM output and bias rows) is h8-encoded
+    # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study); Q K^T stays on bf16 hi/lo.
+    H8_DEFAULT = ("vit", "inter", "up", "attnv")
 
     def _h8_sites(self):
         env = os.environ.get("MMSA_H8")
@@ -273,7 +275,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             pk["blocks"].append(dict(
                 n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
                 qkv=planes(qkv_w, fmt=vfmt), qkv_b=qkv_bias,
-                qkv_bp=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da),  # k = v of pad tokens
+                # k = v of pad tokens; with the fp16 P V of the attention kernels (the "attnv" site, a default; MMSA_H8 without it: bf16 hi/lo pairs) the v third
+                # of the qkv planes -- these bias rows and the qkv GEMM's output -- is h8-encoded (ops.Planes.split)
+                qkv_bp=(ops.split_planes_qkv(qkv_bias.reshape(1, -1).contiguous(), Da) if ("attnv" in h8_sites and Da % 32 == 0)
+                        else ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da)),
                 proj=planes(proj_w, fmt=vfmt), proj_b=sd[b + "attn.proj.bias"],
                 lin1=planes(sd[b + "mlp.lin1.weight"], fmt=vfmt), lin1_b=sd[b + "mlp.lin1.bias"],
                 lin2=planes(sd[b + "mlp.lin2.weight"], fmt=vfmt), lin2_b=sd[b + "mlp.lin2.bias"],
@@ -642,6 +647,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         n = ws.planes("blk_n", B * T, D, fmt=vf)
         ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
         qkv = ws.planes("blk_qkv", B * T, 3 * Da)
+        qkv.split = bp["qkv_bp"].split   # the qkv GEMM writes the v columns as h8 planes when the block was packed for the fp16 P V
         ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
         ao = ws.planes("blk_ao", B * T, Da, fmt=vf)

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 4   # 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm)
+PACK_FORMAT = 5   # 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
 
 
 def unwrap_state_dict(ck):
@@ -90,7 +90,7 @@ def _enc(o):
     if isinstance(o, ops.Planes):
         full = getattr(o, "full", None)
         return {"__planes__": True, "p": (full if full is not None else o.p).cpu(), "n": o.n, "k": o.k, "kpad": o.kpad, "stacked": full is not None,
-                "fmt": o.fmt, "weight": o.weight}
+                "fmt": o.fmt, "weight": o.weight, "split": o.split}
     if isinstance(o, torch.Tensor):
         return o.cpu()
     if isinstance(o, dict):
@@ -104,10 +104,10 @@ def _dec(o, dev):
     if isinstance(o, dict) and o.get("__planes__"):
         buf = o["p"].to(dev)
         if o["stacked"]:
-            pl = ops.Planes(buf[:o["n"]], o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False))
+            pl = ops.Planes(buf[:o["n"]], o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False), o.get("split", 0))
             pl.full = buf
             return pl
-        return ops.Planes(buf, o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False))
+        return ops.Planes(buf, o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False), o.get("split", 0))
     if isinstance(o, torch.Tensor):
         return o.to(dev)
     if isinstance(o, dict):

@@ -44,7 +44,7 @@ SIGNATURES = {
     "mmsa_convnext_mlp_fused": [P, L, L, P, L, P, L, P, P, P, P, L, L, I, I, I, I, P],
     "mmsa_split_planes": [P, L, I, I, I, P, I, P],
     "mmsa_attention": [P, L, P, P, P, L, I, I, I, I, I, I, F, P],
-    "mmsa_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, I, F, I, P],
+    "mmsa_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, I, F, I, I, P],
     "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_relpos_bias_planes": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, I, L, L, I, I, P],
@@ -63,8 +63,8 @@ SIGNATURES = {
     "mmsa_pool_hw": [P, L, P, L, I, I, I, I, P],
     "mmsa_ca_apply": [P, L, P, L, P, L, P, L, I, I, I, I, P],
     "mmsa_tail_fuse": [P, L, L, P, L, P, P, P, P, L, I, I, I, I, I, I, P],
-    "mmsa_global_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, F, I, P],
-    "mmsa_window_attention_planes": [P, L, P, P, P, P, L, I, I, I, I, I, I, F, I, P],
+    "mmsa_global_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, F, I, I, P],
+    "mmsa_window_attention_planes": [P, L, P, P, P, P, L, I, I, I, I, I, I, F, I, I, P],
     "mmsa_nchw_to_planes": [P, L, P, L, I, I, L, P],
     "mmsa_head_fuse": [P, P, I, I, P, I, I, P, I, I, L, P, P, P, L, P, L, I, I, I, I, I, P],
     "mmsa_tokens_to_nchw": [P, L, P, I, L, I, P],

@@ -72,8 +72,9 @@ class Planes:
     (32 fp16, then four 16-byte chunks of lo / q(hi) bytes; `weight` = the chunk order of a W operand).  Used for weights
     [N, K] and for activations; a producer writes the format of the Planes it is handed."""
 
-    def __init__(self, p, n=None, k=None, kpad=None, fmt=FMT_B3, weight=False):
+    def __init__(self, p, n=None, k=None, kpad=None, fmt=FMT_B3, weight=False, split=0):
         self.p = p
+        self.split = split   # > 0 (multiple of 32, fmt FMT_B3): columns >= split are h8-encoded (the v third of qkv planes: fp16 hi for the attention kernels' P V)
         self.n = p.shape[0] if n is None else n
         self.kpad = p.shape[1] // 2 if kpad is None else kpad
         self.k = self.kpad if k is None else k
@@ -91,7 +92,7 @@ class Planes:
 
     def rows(self, lo, hi=None):
         """Row slice (same columns)."""
-        return Planes(self.p[lo:hi], None, self.k, self.kpad, self.fmt, self.weight)
+        return Planes(self.p[lo:hi], None, self.k, self.kpad, self.fmt, self.weight, self.split)
 
     def cols(self, lo, hi):
         """Column slice [lo, hi) of the matrix (both multiples of 32): the k-blocks are self-contained in the layout."""
@@ -110,14 +111,25 @@ def pad32(k):
     return (k + 31) // 32 * 32
 
 
-def alloc_planes(rows, cols, device, zero=False, fmt=FMT_B3):
+def alloc_planes(rows, cols, device, zero=False, fmt=FMT_B3, split=0):
     f = torch.zeros if zero else torch.empty
-    return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols), fmt)
+    if split and (split % 32 or fmt != FMT_B3 or not 0 < split < cols):
+        raise RuntimeError(f"mmsa.alloc_planes: split={split} must be a multiple of 32 inside a bf16 hi/lo matrix of {cols} columns")
+    return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols), fmt, split=split)
+
+
+def cp_format(pl):
+    """The GEMM's output-format argument for these planes (include/mmsa.h: bits 0..7 format, bits 8.. = split / 32)."""
+    return FMT_B3 if pl is None else pl.fmt | ((pl.split // 32) << 8)
 
 
 def planes_to_float(pl, cols=None):
     """Debug/test helper: reconstruct hi + lo as fp32 [rows, cols] (torch ops; not used on the product path)."""
     r, w = pl.p.shape
+    if pl.split:   # bf16 hi/lo columns below the split, h8 (activation chunk order) from it on
+        lo_part = planes_to_float(Planes(pl.p[:, :2 * pl.split], pl.n, pl.split, pl.split, FMT_B3))
+        hi_part = planes_to_float(Planes(pl.p[:, 2 * pl.split:], pl.n, pl.kpad - pl.split, pl.kpad - pl.split, FMT_H8))
+        return torch.cat([lo_part, hi_part], 1)[:, :(pl.k if cols is None else cols)]
     if pl.fmt == FMT_H8:
         blk = pl.p.contiguous().view(torch.uint8).view(r, w // 64, 128)
         hi = blk[:, :, :64].contiguous().view(torch.float16).float()                       # [r, nb, 32]
@@ -180,7 +192,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     lib.call("mmsa_gemm_split3", pa, pap, lda, stride_a, w.p.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
-             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, out_planes.fmt if out_planes is not None else FMT_B3, GEMM_MAX_GRID, _stream())
+             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, cp_format(out_planes), GEMM_MAX_GRID, _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
         nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)
@@ -306,12 +318,31 @@ def relpos_bias(qkv, rh, rw, rp, b, h, w, heads, hd, ws):
     return rp
 
 
+def _v_fmt(qkv, qkv_bias, d):
+    """v_fmt argument of the attention kernels from the planes' own description: 1 when the v columns (from 2*D on) of BOTH the qkv
+    planes and the bias planes are h8-encoded (Planes.split), 0 for plain bf16 hi/lo planes."""
+    if qkv.split != qkv_bias.split or qkv.split not in (0, 2 * d) or qkv.fmt != FMT_B3 or qkv_bias.fmt != FMT_B3:
+        raise RuntimeError(f"mmsa attention: qkv planes (split {qkv.split}) and bias planes (split {qkv_bias.split}) must both be bf16 hi/lo "
+                           f"planes, either plain or with the v columns from {2 * d} on as h8 planes")
+    return 1 if qkv.split else 0
+
+
+def split_planes_qkv(x2d, d):
+    """fp32 [N, 3*d] (q | k | v) -> qkv Planes with q, k as bf16 hi/lo planes and v as h8 planes (Planes.split = 2*d): the layout the
+    qkv GEMM writes for the attention kernels' fp16 P V.  Also for the [1, 3*d] bias row (pad tokens: k = v = bias)."""
+    if (2 * d) % 32 or d % 32:
+        raise RuntimeError("mmsa.split_planes_qkv: embed dim must be a multiple of 32")
+    qk = split_planes(x2d[:, :2 * d].contiguous())
+    v = split_planes(x2d[:, 2 * d:].contiguous(), fmt=FMT_H8)
+    return Planes(torch.cat([qk.p, v.p], 1).contiguous(), x2d.shape[0], 3 * d, 3 * d, FMT_B3, split=2 * d)
+
+
 def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
     if isinstance(qkv, Planes):
         pq, _, _, ldq = qkv.mat("qkv")
         po, _, _, ldo = out.mat("out")
         lib.call("mmsa_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(rp),
-                 po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _stream())
+                 po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd), _stream())
     else:
         pq, _, _, ldq = _mat(qkv, "qkv")
         po, _, _, ldo = _mat(out, "out")
@@ -346,7 +377,7 @@ def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale):
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
     lib.call("mmsa_global_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relg.p, torch.int16), po, ldo,
-             b, h, w, heads, hd, scale, out.fmt, _stream())
+             b, h, w, heads, hd, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd), _stream())
     return out
 
 
@@ -372,7 +403,8 @@ def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
     lib.call("mmsa_window_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relp.p, torch.int16),
-             _chk(window_selector(ws, qkv.p.device), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _stream())
+             _chk(window_selector(ws, qkv.p.device), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, out.fmt,
+             _v_fmt(qkv, qkv_bias, heads * hd), _stream())
     return out
 
 

@@ -55,10 +55,11 @@ def test_batch_and_determinism():
         assert_close(a, r, what="batch 3")
         assert torch.equal(a, b), "two runs on the same input must agree bit for bit (no order-dependent reduction on the path)"
     # images are independent: batch element 1 alone gives the same result (at this toy size the row count decides which
-    # GEMM kernel runs, so not the same bits; at ViT-L sizes it is bit-exact: test_inference_gpu.py)
+    # GEMM kernel runs, so not the same bits; at ViT-L sizes it is bit-exact: test_inference_gpu.py).  The fp16 rounding of v in
+    # the attention kernels turns a last-bit difference of the two GEMM kernels into an occasional 2^-12 step: 2e-5, not 1e-5.
     f_1, _ = m(x[1:2].to(DEV))
     for a, s in zip(f_a, f_1):
-        assert rel_l2(a[1:2], s) < 1e-5
+        assert rel_l2(a[1:2], s) < 2e-5
 
 
 def test_vitb512_probes(golden_dir):

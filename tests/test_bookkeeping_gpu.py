@@ -55,17 +55,27 @@ def _expected_and_qkv(win, B, H, W, ws, hd, amp, max_corr):
     return torch.cat([q, k, v], 1).contiguous(), expect
 
 
+@pytest.mark.parametrize("vf", [False, True])
 @pytest.mark.parametrize("H,W,ws", GEOMS)
-def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws):
-    """wattn_persist_kernel (head_dim 64: the ViT-B / ViT-L path): partition, 64->70-style padding, unpartition as integers."""
+def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws, vf):
+    """wattn_persist_kernel (head_dim 64: the ViT-B / ViT-L path): partition, 64->70-style padding, unpartition as integers.
+    vf: the production form -- v columns as h8 planes, P V on the fp16 MFMA; fp16 holds integers up to 2048 exactly, so the id
+    travels as two base-1024 digits (channels 0..31 the low digit, 32..63 the high one)."""
     import mmsa
     from mmsa import ops
     g = np.load(os.path.join(golden_dir, "bookkeeping.npz"))
     win = g[f"wp_{H}_{W}_{ws}"]
     B, hd = 2, 64
     qkv, expect = _expected_and_qkv(win, B, H, W, ws, hd, amp=4.0, max_corr=0.6)     # logits: 64*16/8 = 128 on the match, <= 0.6*128 elsewhere
-    qp = ops.split_planes(qkv.to(DEV))
-    bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)    # pad slots: k = v = bias = 0
+    if vf:
+        ids = qkv[:, 2 * hd].clone()
+        qkv[:, 2 * hd:2 * hd + 32] = torch.remainder(ids, 1024.0)[:, None]
+        qkv[:, 2 * hd + 32:] = torch.floor(ids / 1024.0)[:, None]
+        qp = ops.split_planes_qkv(qkv.to(DEV), hd)
+        bias_p = ops.split_planes_qkv(torch.zeros(1, 3 * hd, device=DEV), hd)
+    else:
+        qp = ops.split_planes(qkv.to(DEV))
+        bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)    # pad slots: k = v = bias = 0
     relp = ops.window_relpos_planes(torch.zeros(2 * ws - 1, hd, device=DEV), torch.zeros(2 * ws - 1, hd, device=DEV), ws)
     out = ops.alloc_planes(B * H * W, hd, DEV)
     ops.window_attention(qp, bias_p, relp, out, B, H, W, 1, hd, ws, hd ** -0.5)
@@ -73,6 +83,8 @@ def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws):
     # the softmax is one-hot up to the rounding of exp2 / the normalisation (1e-7 relative): ids are recovered by rounding
     assert (got - got.round()).abs().max() < 1e-2, "the softmax was not one-hot"
     ids = got.round().to(torch.int64)
+    if vf:
+        ids = (ids[:, :32] + 1024 * ids[:, 32:]).repeat(1, 2)
     assert torch.equal(ids, expect[:, None].expand(-1, hd)), f"window bookkeeping differs for {H}x{W} ws={ws}"
     # and the inverse table of the reference: window_unpartition(window_partition(idx)) == idx, i.e. every token was written
     assert torch.equal(torch.from_numpy(g[f"wu_{H}_{W}_{ws}"]).reshape(-1), torch.arange(1, B * H * W + 1))

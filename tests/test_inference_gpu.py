@@ -189,5 +189,7 @@ def test_slide_runner_equals_slide_inference(models):
             frame.copy_(torch.randn(1, 6, 300, 420, generator=g).to(DEV))
         cm, unc = sr.run()
         torch.cuda.synchronize()
-        want = inf.argmax_map(inf.slide_inference(m, h, frame, (256, 256), (160, 160), max_batch=len(boxes)))
+        # the plain function on the chains' own sub-batch size: at this toy size the row count decides which GEMM kernel runs (not the
+        # same bits for another batch size -- tests/test_backbone_gpu.py; at ViT-L sizes there is one kernel per shape)
+        want = inf.argmax_map(inf.slide_inference(m, h, frame, (256, 256), (160, 160), max_batch=len(boxes) // 2))
         assert int(unc.item()) == 0 and torch.equal(cm, want)

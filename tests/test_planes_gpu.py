@@ -79,7 +79,8 @@ def test_layernorm_planes_and_patchify(ops):
 @pytest.mark.parametrize("H,W,heads,hd,ws,table", [
     (16, 16, 2, 32, 14, 27), (20, 20, 2, 64, 14, 27), (64, 64, 2, 64, 14, 27),
     (14, 14, 2, 32, 0, 31), (20, 12, 3, 64, 0, 39), (64, 64, 2, 64, 0, 127)])
-def test_attention_planes(ops, H, W, heads, hd, ws, table):
+@pytest.mark.parametrize("vf", [False, True])
+def test_attention_planes(ops, H, W, heads, hd, ws, table, vf):
     import mmsa.backbone as bb
     B, D = 2, heads * hd
     att = R.Attention(D, heads, (table // 2 + 1, table // 2 + 1))
@@ -96,8 +97,11 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table):
         else:
             ref = att(x)
     T = H * W
-    qkv = ops.alloc_planes(B * T, 3 * D, DEV)
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D if vf else 0)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
+    if vf:   # the GEMM's split output against a host-side split of the same matrix: q | k bf16 hi/lo, v fp16 hi + e5m2 lo
+        qkv_f = (x.view(-1, D) @ sd["qkv.weight"].t() + sd["qkv.bias"]).to(DEV)
+        assert_close(planes_to_float(qkv), qkv_f, tol=5e-5, what="qkv planes with the v columns as h8 planes")
     if ws:
         rh, rw = bb._rel_table(ws, sd["rel_pos_h"].to(DEV)), bb._rel_table(ws, sd["rel_pos_w"].to(DEV))
         kk = 2 * ws
@@ -107,11 +111,12 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table):
     rp = torch.empty(B * heads * T, kk, device=DEV)
     ops.relpos_bias(qkv, rh, rw, rp, B, H, W, heads, hd, ws)
     ao = ops.alloc_planes(B * T, D, DEV)
-    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV), kpad=3 * D)
+    bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
+    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
     ops.attention(qkv, biasp, rp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
-    assert_close(out.view(B, H, W, D), ref, what=f"attention planes {H}x{W} ws={ws}")
+    assert_close(out.view(B, H, W, D), ref, what=f"attention planes {H}x{W} ws={ws} vf={vf}")
 
 
 def test_msda_and_dwconv_planes_outputs(ops):
@@ -138,8 +143,10 @@ def test_msda_and_dwconv_planes_outputs(ops):
 
 @pytest.mark.parametrize("H,W,heads,ws", [(16, 16, 2, 14), (20, 20, 2, 14), (64, 64, 2, 14), (30, 22, 3, 7), (14, 14, 1, 14),
                                           (9, 33, 2, 5)])
-def test_window_attention_fused_relpos(ops, H, W, heads, ws):
-    """K/V-resident windowed kernel (rel-pos fused, no mmsa_relpos_bias pass) vs the oracle's Attention on partitioned windows."""
+@pytest.mark.parametrize("vf", [False, True])
+def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
+    """K/V-resident windowed kernel (rel-pos fused, no mmsa_relpos_bias pass) vs the oracle's Attention on partitioned windows.
+    vf: the v third of the qkv planes (GEMM output and bias row) as h8 planes -> P V on the fp16 MFMA (v_fmt = 1)."""
     hd, B = 64, 2
     D = heads * hd
     L = 2 * ws - 1
@@ -154,17 +161,21 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws):
         xw, pad_hw = R.window_partition(x, ws)
         ref = R.window_unpartition(att(xw), ws, pad_hw, (H, W))
     T = H * W
-    qkv = ops.alloc_planes(B * T, 3 * D, DEV)
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D if vf else 0)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
     relp = ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws)
-    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV), kpad=3 * D)
+    bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
+    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
     ao = ops.alloc_planes(B * T, D, DEV)
     ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
-    assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws}")
+    assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws} vf={vf}")
     with pytest.raises(RuntimeError):
         ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, 15, hd ** -0.5)
+    if vf:   # qkv planes and bias planes must agree on the format of the v columns
+        with pytest.raises(RuntimeError):
+            ops.window_attention(qkv, ops.split_planes(bias_row, kpad=3 * D), relp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
 
 
 def test_layernorm_row_groups_and_wrap(ops):
@@ -236,8 +247,9 @@ def test_dwpair_gate_and_ca_apply_planes(ops):
     assert_close(planes_to_float(zp), refz, tol=5e-5, what="ca_apply planes")
 
 
+@pytest.mark.parametrize("vf", [False, True])
 @pytest.mark.parametrize("H", [64, 32])
-def test_global_attention_fused_relpos(ops, H):
+def test_global_attention_fused_relpos(ops, H, vf):
     """Global flash kernel with the rel-pos terms computed in its prologue (no prepass) vs the oracle's Attention."""
     import mmsa.backbone as bb
     W, heads, hd, B = 64, 2, 64, 2
@@ -252,15 +264,16 @@ def test_global_attention_fused_relpos(ops, H):
     with torch.no_grad():
         ref = att(x)
     T = H * W
-    qkv = ops.alloc_planes(B * T, 3 * D, DEV)
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D if vf else 0)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
     relg = ops.global_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV))
-    biasp = ops.split_planes(sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV), kpad=3 * D)
+    bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
+    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
     ao = ops.alloc_planes(B * T, D, DEV)
     ops.global_attention(qkv, biasp, relg, ao, B, H, W, heads, hd, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
-    assert_close(out.view(B, H, W, D), ref, what=f"global attention fused rel-pos {H}x{W}")
+    assert_close(out.view(B, H, W, D), ref, what=f"global attention fused rel-pos {H}x{W} vf={vf}")
 
 
 @pytest.mark.parametrize("M,N,K,mode", [
