@@ -8,6 +8,11 @@
 // All are one pass over the canvas, HBM-bound.
 #include "common.h"
 
+// No fused multiply-add contraction in this file: the canvas path (bilinear_accum + div_count + argmax) and the one-pass class map
+// (slide_argmax) must round the SAME interpolation formula identically, or an exact tie between two classes in one of them is not a
+// tie in the other (seen once in 2 073 600 pixels of a 1080 x 1920 frame, where the compiler had contracted the two differently).
+#pragma clang fp contract(off)
+
 __global__ __launch_bounds__(256) void bilinear_accum_kernel(const float* __restrict__ src, int C, int hs, int ws, long sstrideB,
                                                              float* __restrict__ dst, int Hd, int Wd, int y0, int x0, int hc, int wc,
                                                              float* __restrict__ count, float rh, float rw, int accumulate) {

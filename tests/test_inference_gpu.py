@@ -132,6 +132,37 @@ def test_fused_class_maps_equal_the_unfused_path(models):
         lib.call("mmsa_slide_argmax", lg.data_ptr(), 1, 7, 16, 16, (ctypes.c_int * 3)(0, 40, 0), out.data_ptr(), 1, 80, 80, 64, 64, unc.data_ptr(), ops._stream())
 
 
+def test_class_map_paths_round_identically_on_exact_ties():
+    """The canvas path (bilinear_accum + div_count + argmax) and the one-pass kernel (slide_argmax) evaluate the same interpolation
+    formula; they must also ROUND it the same way (no fused multiply-add in one and not the other), or an exact tie between two
+    classes in one path is no tie in the other.  Class 5 is a copy of class 2: every pixel is a tie, the first class must win in
+    both paths, over two overlapping windows."""
+    import ctypes
+    import mmsa.inference as inf
+    from mmsa import lib, ops
+    g = torch.Generator().manual_seed(11)
+    lg = torch.randn(2, 7, 16, 16, generator=g) * 0.1
+    lg[:, 2] += 3.0
+    lg[:, 5] = lg[:, 2]
+    lg = lg.to(DEV)
+    H, W, hc, wc = 64, 88, 64, 64
+    wins = [(0, 0, 0), (0, 0, 24)]                       # (image, y0, x0): columns 24..63 are covered twice
+    canvas = torch.zeros(1, 7, H, W, device=DEV)
+    count = torch.zeros(1, H, W, device=DEV)
+    for k, (_, y0, x0) in enumerate(wins):
+        inf._resize_into(lg[k:k + 1], canvas, y0, x0, hc, wc, count=count, accumulate=True)
+    lib.call("mmsa_div_count_nchw", canvas.data_ptr(), count.data_ptr(), 1, 7, H * W, ops._stream())
+    want = inf.argmax_map(canvas)
+    out = torch.zeros(1, H, W, dtype=torch.uint8, device=DEV)
+    unc = torch.zeros(1, dtype=torch.int32, device=DEV)
+    tab = (ctypes.c_int * 6)(*[v for w in wins for v in w])
+    lib.call("mmsa_slide_argmax", lg.data_ptr(), 2, 7, 16, 16, tab, out.data_ptr(), 1, H, W, hc, wc, unc.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    assert int(unc.item()) == 0
+    assert torch.equal(canvas[:, 2], canvas[:, 5]) and bool((want == 2).all()), "the canvas path must see exact ties and pick the first class"
+    assert torch.equal(out, want), "the one-pass class map rounds the interpolation differently from the canvas path"
+
+
 def test_crop_batch_kernel():
     import ctypes
     import mmsa.inference as inf
