@@ -674,8 +674,27 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
     hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
   } else {
     const int nitems = nWin * heads * B;
+    // Grid: a workgroup walks items g, g + G, g + 2G, ... of a list that holds the interior windows first and the windows that
+    // overhang the image (fewer live query tiles: cheaper) last.  Candidates: the fewest workgroups that finish in ceil(items / CUs)
+    // items each (leaves CUs to concurrent streams) and one per CU; the cheaper schedule by a two-class cost model wins -- with 200
+    // of 256 workgroups every workgroup of ViT-L's 25 x 16 x 2 items got 3 interior + 1 edge item, with 256 it is 2 + 1 (or 2).
+    const int nWh_ = cdiv(H, window_size), nWw_ = a.nWw, nHB = heads * B;
+    const int n_int = (nWh_ - 1) * (nWw_ - 1) * nHB;                    // items of interior windows (they come first)
+    const int live_h = H - (nWh_ - 1) * window_size, live_w = W - (nWw_ - 1) * window_size;
+    const double edge_cost = 0.35 + 0.65 * (0.5 * (live_h + live_w) / window_size);   // fixed part (K/V transfer, barriers) + live query tiles
+    auto schedule_cost = [&](int G) {
+      double worst = 0.0;
+      for (int g = 0; g < G; ++g) {
+        double c = 0.0;
+        for (int it = g; it < nitems; it += G) c += it < n_int ? 1.0 : edge_cost;
+        worst = c > worst ? c : worst;
+      }
+      return worst;
+    };
     const int rounds = cdiv(nitems, num_cus);
-    const int grid = cdiv(nitems, rounds);   // the fewest workgroups that still finish in `rounds` items each: the other CUs stay free for concurrent streams
+    int grid = cdiv(nitems, rounds);
+    const int grid_all = nitems < num_cus ? nitems : num_cus;
+    if (schedule_cost(grid_all) < schedule_cost(grid) - 1e-9) grid = grid_all;
     if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
     else hipLaunchKernelGGL(wattn_persist_kernel<false>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
   }
