@@ -276,6 +276,59 @@ def test_global_attention_fused_relpos(ops, H, vf):
     assert_close(out.view(B, H, W, D), ref, what=f"global attention fused rel-pos {H}x{W} vf={vf}")
 
 
+@pytest.mark.parametrize("fmt", ["b3", "h8"])
+@pytest.mark.parametrize("M,N,K,outk", [
+    (8192, 1024, 4096, "C"),      # lin2: one tile per workgroup, 128 k-tiles (124 of them straight-line steps)
+    (4096, 4096, 1024, "P"),      # lin1 of one image: 4 tiles per workgroup on 128 of the CUs' worth of tiles, planes output
+    (21504, 1024, 256, "C"),      # extractor ConvFFN fc2: 8 k-tiles per tile (4 straight-line), 5.25 tiles per workgroup, residual
+    (3000, 640, 384, "P"),        # ragged bottom edge, 12 k-tiles
+])
+def test_gemm_straight_line_steps_race_screen(ops, M, N, K, outk, fmt):
+    """Race screen of the GEMM main loop's straight-line k-tile steps (gemm_v2.hip K_STEP_PP_FAST: the same barriers and counted waits
+    as the general step, both groups executing both waits) and of the h8 fp8-first MFMA order: 60 launches per shape, the odd ones
+    while a second stream keeps the memory system and half of the CUs busy, every result bit-identical to the first and within the
+    format's tolerance of fp64."""
+    h8 = fmt == "h8"
+    f = ops.FMT_H8 if h8 else ops.FMT_B3
+    a = torch.randn(M, K, generator=g(130)) * 0.5
+    w = torch.randn(N, K, generator=g(131)) / K ** 0.5
+    ad, wd = a.to(DEV), w.to(DEV)
+    bias = torch.randn(N, generator=g(132)).to(DEV)
+    resid = torch.randn(M, N, generator=g(133)).to(DEV) if outk == "C" else None
+    ref = ad.double() @ wd.double().t() + bias.double()
+    ref = (ref + resid.double() if resid is not None else torch.nn.functional.gelu(ref)).float()
+    ap = ops.split_planes(ad, kpad=K, fmt=f)
+    wp = ops.split_planes(wd, fmt=f, weight=h8)
+    side = torch.cuda.Stream()
+    junk_a = torch.randn(8192, 2048, device=DEV)
+    junk_w = ops.split_planes(torch.randn(2048, 2048, device=DEV))
+    junk_o = torch.empty(8192, 2048, device=DEV)
+    first = None
+    for rep in range(60):
+        if rep & 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    ops.gemm(junk_a, junk_w, junk_o)
+                    junk_o.mul_(0.5)
+        if outk == "C":
+            out = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(ap, wp, out, bias=bias, resid=resid)
+            got = out
+        else:
+            outp = ops.alloc_planes(M, N, DEV, fmt=f)
+            ops.gemm(ap, wp, bias=bias, act="gelu", out_planes=outp)
+            got = outp.p
+        if first is None:
+            first = got.clone()
+            val = got if outk == "C" else planes_to_float(outp)
+            assert_close(val, ref, tol=2e-4 if h8 else 3e-5, what=f"gemm {M}x{N}x{K} {fmt} {outk}")
+        else:
+            assert torch.equal(got, first), f"launch {rep} of {M}x{N}x{K} {fmt} {outk} differs from the first"
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K,mode", [
     (70000, 200, 96, "C"),        # 548 tiles on 256 persistent workgroups (3 per workgroup), 3 k-tiles, ragged M and N
     (9000, 1100, 160, "P"),       # 324 tiles, 5 k-tiles, planes-only output, ragged right edge
