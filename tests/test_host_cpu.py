@@ -304,3 +304,44 @@ def test_checkpoint_unwrap_conventions():
     assert unwrap_state_dict({"a": t}) == {"a": t}
     with pytest.raises(RuntimeError):
         unwrap_state_dict([t])
+
+
+def test_planes_with_a_column_split_host_logic():
+    """ops.Planes.split (qkv planes: q, k as bf16 hi/lo, the v columns as h8 planes): allocation checks, the GEMM's cp_fmt encoding
+    (include/mmsa.h: bits 8.. = split / 32), the v_fmt the attention wrappers derive from it, and the decode helper on a hand-packed
+    row (no GPU: torch ops only)."""
+    import mmsa
+    from mmsa import ops
+    pl = ops.alloc_planes(4, 96, "cpu", split=64)
+    assert pl.split == 64 and pl.fmt == ops.FMT_B3 and pl.rows(1, 3).split == 64
+    assert ops.cp_format(pl) == ops.FMT_B3 | (2 << 8) and ops.cp_format(None) == ops.FMT_B3
+    assert ops.cp_format(ops.alloc_planes(4, 96, "cpu", fmt=ops.FMT_H8)) == ops.FMT_H8
+    for bad in (dict(split=48), dict(split=96), dict(split=64, fmt=ops.FMT_H8)):
+        with pytest.raises(RuntimeError):
+            ops.alloc_planes(4, 96, "cpu", **bad)
+    d = 32
+    qkv, bias = ops.alloc_planes(8, 3 * d, "cpu", split=2 * d), ops.alloc_planes(1, 3 * d, "cpu", split=2 * d)
+    assert ops._v_fmt(qkv, bias, d) == 1
+    assert ops._v_fmt(ops.alloc_planes(8, 3 * d, "cpu"), ops.alloc_planes(1, 3 * d, "cpu"), d) == 0
+    with pytest.raises(RuntimeError):
+        ops._v_fmt(qkv, ops.alloc_planes(1, 3 * d, "cpu"), d)
+    # hand-packed row: two bf16 hi/lo blocks, one h8 block (32 fp16 hi, then four 16-byte chunks: 8 e5m2 bytes of lo * 2^11 | 8 of hi)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 96, generator=g)
+    p = torch.zeros(2, 192, dtype=torch.int16)
+    for blk in range(2):
+        v = x[:, 32 * blk:32 * blk + 32]
+        hi = v.bfloat16()
+        lo = (v - hi.float()).bfloat16()
+        p[:, 64 * blk:64 * blk + 32] = hi.view(torch.int16)
+        p[:, 64 * blk + 32:64 * blk + 64] = lo.view(torch.int16)
+    v = x[:, 64:]
+    hi = v.half()
+    lo8 = ((v - hi.float()) * 2048.0).to(torch.float8_e5m2).view(torch.uint8)
+    qh8 = hi.float().to(torch.float8_e5m2).view(torch.uint8)
+    chunks = torch.cat([lo8.view(2, 4, 1, 8), qh8.view(2, 4, 1, 8)], 2).reshape(2, 64)      # chunk g = elements 8g .. 8g+7
+    p[:, 128:160] = hi.view(torch.int16)
+    p[:, 160:192] = chunks.view(torch.int16)
+    got = ops.planes_to_float(ops.Planes(p, 2, 96, 96, ops.FMT_B3, split=64))
+    assert torch.equal(got[:, :64], x[:, :64].bfloat16().float() + (x[:, :64] - x[:, :64].bfloat16().float()).bfloat16().float())
+    assert (got[:, 64:] - x[:, 64:]).abs().max() <= 2.0 ** -13 * x.abs().max()
