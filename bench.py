@@ -410,7 +410,7 @@ def main():
             "metric": "images/sec encoder fwd @1024x1024 RGB+LiDAR ViT-L",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck, attention Q K^T); attention P V on one fp16 MFMA (P and v rounded to fp16) where the 'attnv' site is on; fp32 accumulate, fp32 activations", "data": "synthetic",
+            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) where the 'attnv' site is on; fp32 accumulate, fp32 activations", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else

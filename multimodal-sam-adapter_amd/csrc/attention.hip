@@ -45,14 +45,19 @@ struct AttnArgs {
 
 // REL (with PL, FB, HD = 64): the rel-pos terms are computed in the kernel's prologue (MFMA, like wattn.hip) instead of being
 // read from the prepass output
-// VF (with PL): the v columns of the qkv planes carry an fp16 hi part (h8 planes: the qkv GEMM writes them that way, common.h
+// VF = 2 (with REL): q, k, v, the pad-token bias row and the rel-pos tables are h8 planes and EVERY contraction of the kernel is one
+// fp16 MFMA on their hi parts -- rel-pos terms, Q K^T (two MFMAs per score tile instead of six) and P V; the lo parts are neither
+// loaded nor staged.  Same study: 3.2e-5 relative on f1..f4 with every operand of every attention block rounded to fp16 (the
+// rounding errors of q and k are random and average out over the head dimension and the keys; scores are O(10)).
+// VF = 1 (with PL): the v columns of the qkv planes carry an fp16 hi part (h8 planes: the qkv GEMM writes them that way, common.h
 // MMSA_CP_SPLIT) and P V runs as ONE fp16 MFMA per product with P rounded to fp16 -- instead of three bf16 MFMAs on hi/lo pairs of
 // both.  P <= 1 has 11 significant bits in fp16 and its rounding errors average out over the keys; measured on the CPU oracle
 // (ViT-B 512^2, every attention block): 2.9e-5 relative on f1..f4 against 1.2e-4 for a bf16 P.  Q K^T stays on
 // bf16 hi/lo pairs: the scores are exponentiated.
-template <int HD, bool PL, bool FB, bool REL = false, bool VF = false>
+template <int HD, bool PL, bool FB, bool REL = false, int VF = 0>
 __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(AttnArgs a) {
-  static_assert(!VF || PL, "the fp16 P V path reads planes");
+  static_assert(VF == 0 || PL, "the fp16 paths read planes");
+  static_assert(VF != 2 || REL, "the all-fp16 form exists for the fused rel-pos kernel");
   constexpr int NCH = HD / 8;            // 16-byte k-chunks per row
   constexpr int KS = HD / 32;            // MFMA k-steps over the head dim
   constexpr int DT = HD / 16;            // output d tiles
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       if constexpr (PL) {  // planes: fragments are plain 16-byte loads; the softmax scale is applied to S instead
         const unsigned short* qq = pq_b + qrow + ilv(colq + ks * 32 + 8 * G);
         qh[sub][ks] = *reinterpret_cast<const bf16x8*>(qq);
-        ql_[sub][ks] = *reinterpret_cast<const bf16x8*>(qq + 32);
+        if constexpr (VF != 2) ql_[sub][ks] = *reinterpret_cast<const bf16x8*>(qq + 32);
         continue;
       }
       float4 v0 = *reinterpret_cast<const float4*>(qp + ks * 32 + 8 * G);
@@ -188,12 +193,18 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         for (int ks = 0; ks < KS; ++ks) {
           const unsigned short* rr = a.relg + (long)(ax * 128 + 16 * t + l15) * 128 + 64 * ks + 8 * G;
           const bf16x8 rh_ = *reinterpret_cast<const bf16x8*>(rr);
-          const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rr + 32);
+          if constexpr (VF == 2) {
 #pragma unroll
-          for (int sub = 0; sub < 2; ++sub) {
-            acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[sub][ks], acc[sub], 0, 0, 0);
-            acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql_[sub][ks], acc[sub], 0, 0, 0);
-            acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[sub][ks], acc[sub], 0, 0, 0);
+            for (int sub = 0; sub < 2; ++sub)
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[sub][ks]), acc[sub], 0, 0, 0);
+          } else {
+            const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rr + 32);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[sub][ks], acc[sub], 0, 0, 0);
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql_[sub][ks], acc[sub], 0, 0, 0);
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[sub][ks], acc[sub], 0, 0, 0);
+            }
           }
         }
 #pragma unroll
@@ -251,14 +262,14 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
           const unsigned short* kr_ = pq_b + (long)tk_ * a.ldq + ilv(colk + c);              \
           const unsigned short* vr_ = pq_b + (long)tk_ * a.ldq + ilv(colv + c);              \
           rkh[i] = *reinterpret_cast<const uint4*>(kr_);                                     \
-          rkl[i] = *reinterpret_cast<const uint4*>(kr_ + 32);                                \
+          if constexpr (VF != 2) rkl[i] = *reinterpret_cast<const uint4*>(kr_ + 32);         \
           rvh[i] = *reinterpret_cast<const uint4*>(vr_);                                     \
-          if constexpr (!VF) rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);             \
+          if constexpr (VF == 0) rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);         \
         } else if (tk_ == -1) {                                                              \
           rkh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c));                    \
-          rkl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c) + 32);               \
+          if constexpr (VF != 2) rkl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c) + 32); \
           rvh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c));                    \
-          if constexpr (!VF) rvl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c) + 32); \
+          if constexpr (VF == 0) rvl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c) + 32); \
         } else {                                                                             \
           rkh[i] = make_uint4(0u, 0u, 0u, 0u); rkl[i] = rkh[i]; rvh[i] = rkh[i]; rvl[i] = rkh[i]; \
         }                                                                                    \
@@ -287,10 +298,10 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         const int c = squart * (HD / 4) + 8 * i;                                             \
         const int ko = (c >> 3) * (64 * 16) + skey * 16;                                     \
         *reinterpret_cast<uint4*>(Khi + ko) = rkh[i];                                        \
-        *reinterpret_cast<uint4*>(Klo + ko) = rkl[i];                                        \
+        if constexpr (VF != 2) *reinterpret_cast<uint4*>(Klo + ko) = rkl[i];                 \
         const int vo = skey * VSTR + c * 2;                                                  \
         *reinterpret_cast<uint4*>(Vhi + vo) = rvh[i];                                        \
-        if constexpr (!VF) *reinterpret_cast<uint4*>(Vlo + vo) = rvl[i];                     \
+        if constexpr (VF == 0) *reinterpret_cast<uint4*>(Vlo + vo) = rvl[i];                 \
       }                                                                                      \
     } else {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
@@ -336,12 +347,18 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (ks * 4 + G) * (64 * 16) + (16 * t + l15) * 16;
         const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(Khi + off);
-        const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(Klo + off);
+        if constexpr (VF == 2) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-          s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[sub][ks], s[sub][t], 0, 0, 0);
-          s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql_[sub][ks], s[sub][t], 0, 0, 0);
-          s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[sub][ks], s[sub][t], 0, 0, 0);
+          for (int sub = 0; sub < 2; ++sub)
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[sub][ks]), s[sub][t], 0, 0, 0);
+        } else {
+          const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(Klo + off);
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[sub][ks], s[sub][t], 0, 0, 0);
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql_[sub][ks], s[sub][t], 0, 0, 0);
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[sub][ks], s[sub][t], 0, 0, 0);
+          }
         }
       }
     }
@@ -522,14 +539,14 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
   } while (0)
 #define ATTN_LAUNCH_VF(HD_, FB_)                                                                                           \
   do {                                                                                                                     \
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, true, FB_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((attn_kernel<HD_, true, FB_, false, true>), grid, dim3(256), smem, stream, a);                      \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_kernel<HD_, true, FB_, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((attn_kernel<HD_, true, FB_, false, 1>), grid, dim3(256), smem, stream, a);                      \
   } while (0)
-  MMSA_CHECK_ARG(a.vf == 0 || (a.vf == 1 && planes), "attention: v_fmt %d (0 = bf16 hi/lo planes, 1 = h8 planes for the v columns)", a.vf);
+  MMSA_CHECK_ARG(a.vf == 0 || (planes && a.vf == (a.relg ? 2 : 1)), "attention: v_fmt %d (0 = bf16 hi/lo planes; 1 = h8 planes for the v columns, the entry with a rel-pos prepass; 2 = h8 planes throughout, the fused rel-pos entry)", a.vf);
   if (head_dim == 64) {
     if (planes && a.relg) {
       MMSA_CHECK_ARG(fb && H <= 64 && 128 * a.KWs * (int)sizeof(float) <= 2 * 8 * 64 * 16 + 2 * 64 * VSTR, "attention: the fused rel-pos path needs a W = 64, H <= 64 global grid");
-      if (a.vf) hipLaunchKernelGGL((attn_kernel<64, true, true, true, true>), grid, dim3(256), smem, stream, a);
+      if (a.vf) hipLaunchKernelGGL((attn_kernel<64, true, true, true, 2>), grid, dim3(256), smem, stream, a);
       else hipLaunchKernelGGL((attn_kernel<64, true, true, true>), grid, dim3(256), smem, stream, a);
     } else if (planes && a.vf) { if (fb) ATTN_LAUNCH_VF(64, true); else ATTN_LAUNCH_VF(64, false); }
     else if (planes) { if (fb) ATTN_LAUNCH(64, true, true); else ATTN_LAUNCH(64, true, false); }

@@ -122,6 +122,14 @@ enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
 #define MMSA_H8_MFMA_SCALE 0x74747474     // e8m0 127 - 11 in every byte: the block scale that undoes MMSA_H8_LO_SCALE
 typedef __attribute__((ext_vector_type(2))) _Float16 mmsa_h2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // operand of v_mfma_f32_16x16x32_f16
+// two floats -> fp16 hi pair + fp16 lo pair (lo = a - hi, itself rounded to fp16: 22 significant bits together)
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
+  const mmsa_f32x2 v = {a, b};
+  const mmsa_h2 h = __builtin_convertvector(v, mmsa_h2);
+  const mmsa_f32x2 r = v - __builtin_convertvector(h, mmsa_f32x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, mmsa_h2));
+}
 // two floats -> 2 packed fp16, round to nearest even (softmax probabilities of the attention kernels' fp16 P V)
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {
   const mmsa_f32x2 v = {a, b};

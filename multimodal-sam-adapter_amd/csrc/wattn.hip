@@ -315,8 +315,10 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
 #define WP_R_BYTES (2 * 64 * 128)        // rel-pos table image: [ks][64 rows] of 128 B (GEMM LDS image)
 #define WP_LDS (WA_K_BYTES + 2 * WP_V_BYTES + WA_E_BYTES + WP_R_BYTES + WA_WAVES * WA_B_BYTES)
 
-// VF: the v columns of the qkv planes are h8 planes (fp16 hi) and P V is one fp16 MFMA per product with P rounded to fp16
-// (attention.hip, attn_kernel: same scheme, same error study); the V lo image is then neither transferred nor read.
+// VF: q, k, v, the pad-token bias row and the rel-pos table are h8 planes and every contraction of the kernel is ONE fp16 MFMA on
+// their hi parts (attention.hip, attn_kernel VF = 2: same scheme, same error study): rel-pos terms 8 MFMAs instead of 24, Q K^T 2 per
+// key tile instead of 6, P V 1 instead of 3 with P rounded to fp16; the rel-pos bias operand stays a hi + lo pair (two fp16 MFMAs
+// against the fp16 selector).  The lo parts are not read; the V lo image is not transferred.
 template <bool VF>
 __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs a, int nWin, int nitems) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                        \
       const unsigned short* qq = qrow + 2 * (head * 64 + 32 * ks) + 8 * G;                                    \
       qh[ks] = *reinterpret_cast<const bf16x8*>(qq);                                                          \
-      ql[ks] = *reinterpret_cast<const bf16x8*>(qq + 32);                                                     \
+      if constexpr (!VF) ql[ks] = *reinterpret_cast<const bf16x8*>(qq + 32);                                  \
     }                                                                                                         \
   }
 
@@ -454,10 +456,14 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
         for (int ks = 0; ks < 2; ++ks) {
           const unsigned char* rb = Rs + (ks * 64 + 16 * t) * 128;
           const bf16x8 rh_ = *reinterpret_cast<const bf16x8*>(rb + frag_hi);
-          const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rb + frag_lo);
-          tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[ks], tt[t], 0, 0, 0);
-          tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql[ks], tt[t], 0, 0, 0);
-          tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[ks], tt[t], 0, 0, 0);
+          if constexpr (VF) {
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[ks]), tt[t], 0, 0, 0);
+          } else {
+            const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rb + frag_lo);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[ks], tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql[ks], tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[ks], tt[t], 0, 0, 0);
+          }
         }
       }
       {
@@ -481,10 +487,17 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
         const float4 b0 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G);
         const float4 b1 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G + 4);
         uint4 hh, ll;
-        split2(b0.x, b0.y, hh.x, ll.x);
-        split2(b0.z, b0.w, hh.y, ll.y);
-        split2(b1.x, b1.y, hh.z, ll.z);
-        split2(b1.z, b1.w, hh.w, ll.w);
+        if constexpr (VF) {
+          split2_f16(b0.x, b0.y, hh.x, ll.x);
+          split2_f16(b0.z, b0.w, hh.y, ll.y);
+          split2_f16(b1.x, b1.y, hh.z, ll.z);
+          split2_f16(b1.z, b1.w, hh.w, ll.w);
+        } else {
+          split2(b0.x, b0.y, hh.x, ll.x);
+          split2(b0.z, b0.w, hh.y, ll.y);
+          split2(b1.x, b1.y, hh.z, ll.z);
+          split2(b1.z, b1.w, hh.w, ll.w);
+        }
         bqh = __builtin_bit_cast(bf16x8, hh);
         bql = __builtin_bit_cast(bf16x8, ll);
       }
@@ -501,16 +514,25 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
 #pragma unroll
       for (int t = 0; t < 13; ++t) {
         const bf16x8 e_ = *reinterpret_cast<const bf16x8*>(Es + 16 * t * 64 + frag_e);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bql, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bqh, s[t], 0, 0, 0);
+        if constexpr (VF) {   // selector in fp16 (1.0 = 0x3C00), bias operand as an fp16 hi + lo pair
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bql), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bqh), s[t], 0, 0, 0);
+        } else {
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bql, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bqh, s[t], 0, 0, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const unsigned char* kb = Ks + (ks * WA_NKEY + 16 * t) * 128;
           const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(kb + frag_hi);
-          const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(kb + frag_lo);
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], s[t], 0, 0, 0);
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], s[t], 0, 0, 0);
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], s[t], 0, 0, 0);
+          if constexpr (VF) {
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[ks]), s[t], 0, 0, 0);
+          } else {
+            const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(kb + frag_lo);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], s[t], 0, 0, 0);
+          }
         }
         if (t & 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 13 tiles' fragment reads (spills at 128 VGPRs)
       }
@@ -634,7 +656,7 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
                                             int out_fmt, int v_fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "window_attention: bad output plane format %d", out_fmt);
-  MMSA_CHECK_ARG(v_fmt == 0 || v_fmt == 1, "window_attention: v_fmt %d (0 = bf16 hi/lo planes, 1 = h8 planes for the v columns)", v_fmt);
+  MMSA_CHECK_ARG(v_fmt == 0 || v_fmt == 2, "window_attention: v_fmt %d (0 = bf16 hi/lo planes; 2 = qkv, bias and rel-pos planes in the h8 format and an fp16 selector: every contraction on the fp16 MFMA)", v_fmt);
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0, "window_attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64, "window_attention: head_dim %d not supported by this kernel (64)", head_dim);
   MMSA_CHECK_ARG(window_size >= 1 && window_size <= 14, "window_attention: window_size %d not supported (1..14)", window_size);

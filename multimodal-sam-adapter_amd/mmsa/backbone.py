@@ -279,6 +279,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # of the qkv planes -- these bias rows and the qkv GEMM's output -- is h8-encoded (ops.Planes.split)
                 qkv_bp=(ops.split_planes_qkv(qkv_bias.reshape(1, -1).contiguous(), Da) if ("attnv" in h8_sites and Da % 32 == 0)
                         else ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da)),
+                # ... and for the kernels with the rel-pos terms fused (head_dim 64) the whole row, the qkv GEMM's whole output and the
+                # rel-pos tables are h8 planes: every contraction of those kernels runs on the fp16 hi parts (v_fmt = 2)
+                qkv_bp16=(ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_H8) if "attnv" in h8_sites else None),
                 proj=planes(proj_w, fmt=vfmt), proj_b=sd[b + "attn.proj.bias"],
                 lin1=planes(sd[b + "mlp.lin1.weight"], fmt=vfmt), lin1_b=sd[b + "mlp.lin1.bias"],
                 lin2=planes(sd[b + "mlp.lin2.weight"], fmt=vfmt), lin2_b=sd[b + "mlp.lin2.bias"],
@@ -290,7 +293,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 L = 2 * wsz - 1
                 th = blk["rph"] if blk["rph"].shape[0] == L else _linear_resize_rows(blk["rph"], L)
                 tw = blk["rpw"] if blk["rpw"].shape[0] == L else _linear_resize_rows(blk["rpw"], L)
-                blk["relp"] = ops.window_relpos_planes(th, tw, wsz)
+                blk["relp"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_H8 if blk["qkv_bp16"] is not None else ops.FMT_B3)
         # --- TwinConvNeXt
         def cfmt(w2d):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path):
             # h8 operands for the pointwise convs whose two contraction lengths (C and 4C) are multiples of 64 and that do not run on the fused stage-0 kernel
@@ -488,7 +491,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # global block on a 64-wide grid: rel-pos terms computed inside the attention kernel from the packed tables
                 th = blk["rph"] if blk["rph"].shape[0] == 2 * Hp - 1 else _linear_resize_rows(blk["rph"], 2 * Hp - 1)
                 tw = blk["rpw"] if blk["rpw"].shape[0] == 2 * Wp - 1 else _linear_resize_rows(blk["rpw"], 2 * Wp - 1)
-                relg = ops.global_relpos_planes(th, tw)
+                relg = ops.global_relpos_planes(th, tw, fmt=ops.FMT_H8 if blk["qkv_bp16"] is not None else ops.FMT_B3)
                 g["rel"].append(None)
             else:
                 g["rel"].append((_rel_table(Hp, blk["rph"]), _rel_table(Wp, blk["rpw"])))
@@ -646,20 +649,24 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         vf = bp["qkv"].fmt   # operand format of this block's GEMMs: the producers below write it (qkv's own output stays bf16 hi/lo for the attention kernels)
         n = ws.planes("blk_n", B * T, D, fmt=vf)
         ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
-        qkv = ws.planes("blk_qkv", B * T, 3 * Da)
-        qkv.split = bp["qkv_bp"].split   # the qkv GEMM writes the v columns as h8 planes when the block was packed for the fp16 P V
+        fused = bp.get("relp") is not None or relg is not None
+        all16 = fused and bp["qkv_bp16"] is not None    # "attnv": the fused kernels run every contraction on fp16 hi parts of h8 planes
+        qkv = ws.planes("blk_qkv", B * T, 3 * Da, fmt=ops.FMT_H8 if all16 else ops.FMT_B3)
+        bias_p = bp["qkv_bp16"] if all16 else bp["qkv_bp"]
+        if not all16:
+            qkv.split = bias_p.split   # the kernel with a rel-pos prepass: the qkv GEMM writes the v columns as h8 planes (fp16 P V only)
         ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
         ao = ws.planes("blk_ao", B * T, Da, fmt=vf)
         if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
-            ops.window_attention(qkv, bp["qkv_bp"], bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
+            ops.window_attention(qkv, bias_p, bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
         elif relg is not None:           # global block on a 64-wide grid: flash kernel with the rel-pos terms fused
-            ops.global_attention(qkv, bp["qkv_bp"], relg, ao, B, Hp, Wp, heads, hd, scale)
+            ops.global_attention(qkv, bias_p, relg, ao, B, Hp, Wp, heads, hd, scale)
         else:
             kk = 2 * wsz if wsz else Hp + Wp
             rp = ws.get("blk_rp", B * heads * T, kk)
             ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
-            ops.attention(qkv, bp["qkv_bp"], rp, ao, B, Hp, Wp, heads, hd, wsz, scale)
+            ops.attention(qkv, bias_p, rp, ao, B, Hp, Wp, heads, hd, wsz, scale)
         ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
         ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
         h = ws.planes("blk_h", B * T, bp["lin1"].n, fmt=vf)

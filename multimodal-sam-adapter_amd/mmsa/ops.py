@@ -318,12 +318,18 @@ def relpos_bias(qkv, rh, rw, rp, b, h, w, heads, hd, ws):
     return rp
 
 
-def _v_fmt(qkv, qkv_bias, d):
-    """v_fmt argument of the attention kernels from the planes' own description: 1 when the v columns (from 2*D on) of BOTH the qkv
-    planes and the bias planes are h8-encoded (Planes.split), 0 for plain bf16 hi/lo planes."""
-    if qkv.split != qkv_bias.split or qkv.split not in (0, 2 * d) or qkv.fmt != FMT_B3 or qkv_bias.fmt != FMT_B3:
+def _v_fmt(qkv, qkv_bias, d, fused=False, rel=None):
+    """v_fmt argument of the attention kernels from the planes' own description (include/mmsa.h): 0 = plain bf16 hi/lo planes;
+    1 = the v columns (from 2*D on) of BOTH the qkv planes and the bias planes are h8-encoded (Planes.split; the entry with a rel-pos
+    prepass); 2 = qkv, bias and rel-pos planes are h8 planes throughout (the fused rel-pos entries: every contraction on fp16)."""
+    if qkv.fmt == FMT_H8 or qkv_bias.fmt == FMT_H8 or (rel is not None and rel.fmt == FMT_H8):
+        if not (fused and qkv.fmt == FMT_H8 and qkv_bias.fmt == FMT_H8 and rel is not None and rel.fmt == FMT_H8
+                and not (qkv.weight or qkv_bias.weight or rel.weight)):
+            raise RuntimeError("mmsa attention: h8 planes need the fused rel-pos entry with qkv, bias AND rel-pos planes in the h8 (activation) format")
+        return 2
+    if qkv.split != qkv_bias.split or qkv.split not in (0, 2 * d) or (fused and qkv.split):
         raise RuntimeError(f"mmsa attention: qkv planes (split {qkv.split}) and bias planes (split {qkv_bias.split}) must both be bf16 hi/lo "
-                           f"planes, either plain or with the v columns from {2 * d} on as h8 planes")
+                           f"planes, either plain or -- for the entry with a rel-pos prepass -- with the v columns from {2 * d} on as h8 planes")
     return 1 if qkv.split else 0
 
 
@@ -350,7 +356,7 @@ def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
     return out
 
 
-def window_relpos_planes(rel_pos_h, rel_pos_w, ws):
+def window_relpos_planes(rel_pos_h, rel_pos_w, ws, fmt=FMT_B3):
     """Pack a windowed block's rel-pos tables for window_attention: [64, hd] fp32 -> Planes; rows 0..2ws-2 = rel_pos_h,
     rows 32.. = rel_pos_w (tables must already have 2*ws-1 rows: get_rel_pos's resize, IE:568-575, is the caller's)."""
     L = 2 * ws - 1
@@ -359,17 +365,18 @@ def window_relpos_planes(rel_pos_h, rel_pos_w, ws):
     m = torch.zeros(64, rel_pos_h.shape[1], dtype=torch.float32, device=rel_pos_h.device)
     m[:L] = rel_pos_h
     m[32:32 + L] = rel_pos_w
-    return split_planes(m)
+    return split_planes(m, fmt=fmt)
 
 
-def global_relpos_planes(rel_pos_h, rel_pos_w):
-    """Pack a global block's rel-pos tables (already 2H-1 / 2W-1 rows) for global_attention: [256, hd] -> Planes."""
+def global_relpos_planes(rel_pos_h, rel_pos_w, fmt=FMT_B3):
+    """Pack a global block's rel-pos tables (already 2H-1 / 2W-1 rows) for global_attention: [256, hd] -> Planes (fmt FMT_H8 with h8
+    qkv planes: the all-fp16 form of the kernel)."""
     if rel_pos_h.shape[0] > 127 or rel_pos_w.shape[0] > 127:
         raise RuntimeError("mmsa.global_relpos_planes: tables must have at most 127 rows")
     m = torch.zeros(256, rel_pos_h.shape[1], dtype=torch.float32, device=rel_pos_h.device)
     m[:rel_pos_h.shape[0]] = rel_pos_h
     m[128:128 + rel_pos_w.shape[0]] = rel_pos_w
-    return split_planes(m)
+    return split_planes(m, fmt=fmt)
 
 
 def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale):
@@ -377,21 +384,23 @@ def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale):
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
     lib.call("mmsa_global_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relg.p, torch.int16), po, ldo,
-             b, h, w, heads, hd, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd), _stream())
+             b, h, w, heads, hd, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd, fused=True, rel=relg), _stream())
     return out
 
 
 _SELECTORS = {}
 
 
-def window_selector(ws, device):
-    """[208, 32] bf16 0/1 matrix of mmsa_window_attention_planes: row j selects key row j // ws and key column 14 + j % ws."""
-    key = (ws, str(device))
+def window_selector(ws, device, f16=False):
+    """[208, 32] 0/1 matrix of mmsa_window_attention_planes: row j selects key row j // ws and key column 14 + j % ws; 1.0 in bf16, or
+    in fp16 for the all-fp16 form of the kernel (v_fmt = 2)."""
+    key = (ws, str(device), f16)
     if key not in _SELECTORS:
         sel = torch.zeros(208, 32, dtype=torch.int16)
         j = torch.arange(min(ws * ws, 208))
-        sel[j, j // ws] = 0x3F80
-        sel[j, 14 + j % ws] = 0x3F80
+        one = 0x3C00 if f16 else 0x3F80
+        sel[j, j // ws] = one
+        sel[j, 14 + j % ws] = one
         _SELECTORS[key] = sel.to(device)
     return _SELECTORS[key]
 
@@ -402,9 +411,10 @@ def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
         raise RuntimeError(f"mmsa.window_attention: window_size {ws} not supported (1..14)")
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
+    vf = _v_fmt(qkv, qkv_bias, heads * hd, fused=True, rel=relp)
     lib.call("mmsa_window_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relp.p, torch.int16),
-             _chk(window_selector(ws, qkv.p.device), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, out.fmt,
-             _v_fmt(qkv, qkv_bias, heads * hd), _stream())
+             _chk(window_selector(ws, qkv.p.device, f16=vf == 2), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, out.fmt,
+             vf, _stream())
     return out
 
 

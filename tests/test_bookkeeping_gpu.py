@@ -59,7 +59,7 @@ def _expected_and_qkv(win, B, H, W, ws, hd, amp, max_corr):
 @pytest.mark.parametrize("H,W,ws", GEOMS)
 def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws, vf):
     """wattn_persist_kernel (head_dim 64: the ViT-B / ViT-L path): partition, 64->70-style padding, unpartition as integers.
-    vf: the production form -- v columns as h8 planes, P V on the fp16 MFMA; fp16 holds integers up to 2048 exactly, so the id
+    vf: the production form -- h8 planes, every contraction on the fp16 MFMA; fp16 holds integers up to 2048 exactly, so the id
     travels as two base-1024 digits (channels 0..31 the low digit, 32..63 the high one)."""
     import mmsa
     from mmsa import ops
@@ -71,12 +71,13 @@ def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws, vf):
         ids = qkv[:, 2 * hd].clone()
         qkv[:, 2 * hd:2 * hd + 32] = torch.remainder(ids, 1024.0)[:, None]
         qkv[:, 2 * hd + 32:] = torch.floor(ids / 1024.0)[:, None]
-        qp = ops.split_planes_qkv(qkv.to(DEV), hd)
-        bias_p = ops.split_planes_qkv(torch.zeros(1, 3 * hd, device=DEV), hd)
+        qp = ops.split_planes(qkv.to(DEV), fmt=ops.FMT_H8)
+        bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd, fmt=ops.FMT_H8)
     else:
         qp = ops.split_planes(qkv.to(DEV))
         bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)    # pad slots: k = v = bias = 0
-    relp = ops.window_relpos_planes(torch.zeros(2 * ws - 1, hd, device=DEV), torch.zeros(2 * ws - 1, hd, device=DEV), ws)
+    relp = ops.window_relpos_planes(torch.zeros(2 * ws - 1, hd, device=DEV), torch.zeros(2 * ws - 1, hd, device=DEV), ws,
+                                    fmt=ops.FMT_H8 if vf else ops.FMT_B3)
     out = ops.alloc_planes(B * H * W, hd, DEV)
     ops.window_attention(qp, bias_p, relp, out, B, H, W, 1, hd, ws, hd ** -0.5)
     got = ops.planes_to_float(out).cpu()

@@ -146,7 +146,7 @@ def test_msda_and_dwconv_planes_outputs(ops):
 @pytest.mark.parametrize("vf", [False, True])
 def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
     """K/V-resident windowed kernel (rel-pos fused, no mmsa_relpos_bias pass) vs the oracle's Attention on partitioned windows.
-    vf: the v third of the qkv planes (GEMM output and bias row) as h8 planes -> P V on the fp16 MFMA (v_fmt = 1)."""
+    vf: qkv (GEMM output), bias row and rel-pos table as h8 planes and an fp16 selector -> every contraction on the fp16 MFMA (v_fmt = 2)."""
     hd, B = 64, 2
     D = heads * hd
     L = 2 * ws - 1
@@ -161,11 +161,12 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
         xw, pad_hw = R.window_partition(x, ws)
         ref = R.window_unpartition(att(xw), ws, pad_hw, (H, W))
     T = H * W
-    qkv = ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D if vf else 0)
+    pf = ops.FMT_H8 if vf else ops.FMT_B3
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV, fmt=pf)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
-    relp = ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws)
+    relp = ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws, fmt=pf)
     bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
-    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
+    biasp = ops.split_planes(bias_row, kpad=3 * D, fmt=pf)
     ao = ops.alloc_planes(B * T, D, DEV)
     ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)
@@ -173,9 +174,14 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
     assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws} vf={vf}")
     with pytest.raises(RuntimeError):
         ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, 15, hd ** -0.5)
-    if vf:   # qkv planes and bias planes must agree on the format of the v columns
+    if vf:   # qkv, bias and rel-pos planes must agree on the format; the split form belongs to the entry with a rel-pos prepass
         with pytest.raises(RuntimeError):
             ops.window_attention(qkv, ops.split_planes(bias_row, kpad=3 * D), relp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
+        with pytest.raises(RuntimeError):
+            ops.window_attention(qkv, biasp, ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws), ao, B, H, W, heads, hd, ws, hd ** -0.5)
+        with pytest.raises(RuntimeError):
+            ops.window_attention(ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D), ops.split_planes_qkv(bias_row, D),
+                                 ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws), ao, B, H, W, heads, hd, ws, hd ** -0.5)
 
 
 def test_layernorm_row_groups_and_wrap(ops):
@@ -264,11 +270,12 @@ def test_global_attention_fused_relpos(ops, H, vf):
     with torch.no_grad():
         ref = att(x)
     T = H * W
-    qkv = ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D if vf else 0)
+    pf = ops.FMT_H8 if vf else ops.FMT_B3     # vf: h8 planes throughout, every contraction of the kernel on the fp16 MFMA (v_fmt = 2)
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV, fmt=pf)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
-    relg = ops.global_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV))
+    relg = ops.global_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), fmt=pf)
     bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
-    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
+    biasp = ops.split_planes(bias_row, kpad=3 * D, fmt=pf)
     ao = ops.alloc_planes(B * T, D, DEV)
     ops.global_attention(qkv, biasp, relg, ao, B, H, W, heads, hd, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)

@@ -5,14 +5,15 @@ sys.path.insert(0, os.path.join(ROOT, "multimodal-sam-adapter_amd"))
 import torch, mmsa
 ops = mmsa.ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-vf = os.environ.get("MMSA_WATTN_VF", "1") == "1"    # v columns as h8 planes: P V on the fp16 MFMA (the production form)
+vf = os.environ.get("MMSA_WATTN_VF", "1") == "1"    # h8 planes throughout: every contraction on the fp16 MFMA (the production form)
 H, W, heads, hd, ws = 64, 64, 16, 64, 14
 D = heads * hd
 dev = "cuda"
 x, brow = torch.randn(B * H * W, 3 * D, device=dev), torch.randn(1, 3 * D, device=dev)
-qkv = ops.split_planes_qkv(x, D) if vf else ops.split_planes(x)
-bias = ops.split_planes_qkv(brow, D) if vf else ops.split_planes(brow, kpad=3 * D)
-relp = ops.window_relpos_planes(torch.randn(27, hd, device=dev) * 0.3, torch.randn(27, hd, device=dev) * 0.3, ws)
+pf = ops.FMT_H8 if vf else ops.FMT_B3
+qkv = ops.split_planes(x, fmt=pf)
+bias = ops.split_planes(brow, kpad=3 * D, fmt=pf)
+relp = ops.window_relpos_planes(torch.randn(27, hd, device=dev) * 0.3, torch.randn(27, hd, device=dev) * 0.3, ws, fmt=pf)
 out = ops.alloc_planes(B * H * W, D, dev)
 for _ in range(3):
     ops.window_attention(qkv, bias, relp, out, B, H, W, heads, hd, ws, hd ** -0.5)
