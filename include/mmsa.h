@@ -135,8 +135,11 @@ int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const floa
 int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const float* rp,
                           uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim,
                           int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
-                          int v_fmt /* 0: v columns of qkv_planes / bias_planes are bf16 hi/lo planes; 1: h8 planes (fp16 hi, as the qkv GEMM
-                                       writes them with cp_fmt = MMSA_FMT_B3 | (2D/32) << 8): P V runs on the fp16 MFMA with P rounded to fp16 */,
+                          int v_fmt /* 0: qkv_planes / bias_planes are bf16 hi/lo planes; 1 (this entry): their v columns are h8 planes (fp16 hi,
+                                       as the qkv GEMM writes them with cp_fmt = MMSA_FMT_B3 | (2D/32) << 8): P V runs on the fp16 MFMA with
+                                       P rounded to fp16; 2 (the two fused rel-pos entries below): qkv_planes, bias_planes AND relpos_planes
+                                       are h8 planes throughout (and the window kernel's selector holds fp16 ones): every contraction of
+                                       the kernel is one fp16 MFMA on the hi parts */,
                           mmsa_stream_t stream);
 
 /* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
@@ -218,7 +221,7 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
  *     H <= 64 and a multiple of 4, head_dim 64.  No mmsa_relpos_bias pass. --- */
 int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const uint16_t* relpos_planes,
                                  uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim, float scale,
-                                 int out_fmt /* MMSA_FMT_* of out_planes */, int v_fmt /* as mmsa_attention_planes */, mmsa_stream_t stream);
+                                 int out_fmt /* MMSA_FMT_* of out_planes */, int v_fmt /* 0 or 2: see mmsa_attention_planes */, mmsa_stream_t stream);
 
 /* --- windowed attention with the rel-pos bias fused (Block.forward IE:382-423 on a window_size > 0 block: window_partition ->
  *     Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 -> window_unpartition).  qkv / bias / out as in
@@ -229,7 +232,7 @@ int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uin
 int mmsa_window_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes,
                                  const uint16_t* relpos_planes, const uint16_t* selector, uint16_t* out_planes, long ldo, int B, int H, int W,
                                  int heads, int head_dim, int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
-                                 int v_fmt /* as mmsa_attention_planes */, mmsa_stream_t stream);
+                                 int v_fmt /* 0 or 2: see mmsa_attention_planes */, mmsa_stream_t stream);
 
 /* --- Segformer decode head (segmentation/mmseg_custom/models/decode_heads/segformer_head.py:47-66; the 1x1 convs are
  *     mmsa_gemm_split3 calls).  nchw_to_planes: backbone map [B,C,HW] fp32 (image b at b*strideB) -> interleaved planes
