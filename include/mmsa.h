@@ -101,8 +101,7 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
  * The result goes to fp32 `C`, to planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both.
  * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`:
- * bits 0..5 MMSA_FMT_*, bit 6 (0x40) = store only the hi half (first 64 bytes) of every 128-byte line -- for a consumer that reads hi
- * parts only (attention v_fmt = 2); the rest of the line may keep its old content --, bits 8.. = split / 32 -- columns >= split (a multiple of 32; 0 = none) are written as MMSA_FMT_H8 planes
+ * bits 0..7 MMSA_FMT_*, bits 8.. = split / 32 -- columns >= split (a multiple of 32; 0 = none) are written as MMSA_FMT_H8 planes
  * whatever the base format (the qkv projection: q and k bf16 hi/lo, v with an fp16 hi part for the attention kernels' v_fmt = 1).
  * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
  * its share of the CUs); 0 = all CUs.  Results do not depend on it. */

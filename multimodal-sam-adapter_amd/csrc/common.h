@@ -111,14 +111,10 @@ __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k
 // operand bytes of the fp8 MFMA are just the chunks of two consecutive k-blocks, and byte p of A always meets byte p of W with
 // the roles (lo, q(hi)) crossed.  Values are clamped to +-57344 (the largest e5m2 / a finite fp16) before the split.
 enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
-// Output-plane format argument of the GEMM (`cp_fmt`): bits 0..5 = format of the columns below the split, bit 6 = hi halves only,
-// bits 8.. = split / 32;
+// Output-plane format argument of the GEMM (`cp_fmt`): bits 0..7 = format of the columns below the split, bits 8.. = split / 32;
 // columns >= split (a multiple of 32, 0 = no split) are written as MMSA_FMT_H8.  The qkv projection writes q and k as bf16 hi/lo
 // planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: DESIGN.md 4.1).
-#define MMSA_CP_BASE(f_) ((f_) & 0x3f)
-// bit 6: only the hi half of every 128-byte line is written (the 64 bytes of bf16 / fp16 hi values); the consumer reads hi parts only
-// -- the attention kernels' all-fp16 form (v_fmt = 2) -- and the other 64 bytes of the line keep whatever they held
-#define MMSA_CP_HI_ONLY 0x40
+#define MMSA_CP_BASE(f_) ((f_) & 0xff)
 #define MMSA_CP_SPLIT(f_) (((f_) >> 8) * 32)
 #define MMSA_CP_AT(f_, col_) ((MMSA_CP_SPLIT(f_) > 0 && (col_) >= MMSA_CP_SPLIT(f_)) ? MMSA_FMT_H8 : MMSA_CP_BASE(f_))
 #define MMSA_H8_MAX 57344.0f

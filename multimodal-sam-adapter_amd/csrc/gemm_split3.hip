@@ -334,7 +334,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 int M, int N, int K, int batch, int act, float alpha,
                                 int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
   const bool ap = Ap != nullptr;
-  MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && cp_fmt >= 0 && (cp_fmt & 0x80) == 0 && (MMSA_CP_BASE(cp_fmt) == MMSA_FMT_B3 || MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
+  MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && cp_fmt >= 0 && (MMSA_CP_BASE(cp_fmt) == MMSA_FMT_B3 || MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
   MMSA_CHECK_ARG(MMSA_CP_SPLIT(cp_fmt) == 0 || (out_mode == 0 && MMSA_CP_SPLIT(cp_fmt) < N), "gemm_split3: the output-format split %d needs a plain [M, N] planes output with N=%d beyond it", MMSA_CP_SPLIT(cp_fmt), N);
   MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 operands need A planes and K %% 64 == 0 (K=%d)", K);
   MMSA_CHECK_ARG((A || Ap) && Wp && (C || Cp), "gemm_split3: null pointer");

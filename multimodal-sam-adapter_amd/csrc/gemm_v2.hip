@@ -609,7 +609,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       const int nb_ = n0 + wn * swid;
       const int cp_base = MMSA_CP_BASE(a.cp_fmt);
       const bool cp_split = MMSA_CP_SPLIT(a.cp_fmt) != 0;   // kernel-uniform: columns >= the split leave as h8 planes (common.h)
-      const bool cp_store = !(a.cp_fmt & MMSA_CP_HI_ONLY) || !(lane & 4);   // hi-only output: lanes 4-7 / 12-15 of a 16-lane row segment hold the lines' second halves
       const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
       const int cl = (lane & 15) * 4;
       const bool lane_ok = cl < swid;        // 96-column tiles: the lanes of the (skipped) fourth n-tile only keep the loads in bounds
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int m = mb + rl0 + 4 * i;
-              if (m < a.M && cp_store) *reinterpret_cast<uint4*>(Cp + (long)m * a.ldcp + ilv(n & ~63) + 8 * (lane & 15)) = pk[i];
+              if (m < a.M) *reinterpret_cast<uint4*>(Cp + (long)m * a.ldcp + ilv(n & ~63) + 8 * (lane & 15)) = pk[i];
             }
           }
         }
@@ -756,7 +755,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
               if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
-              if (Cp && cp_store) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
+              if (Cp) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
             }
           }
         } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare
@@ -833,7 +832,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
               if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
-              if (Cp && cp_store) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
+              if (Cp) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
             }
           }
         } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare

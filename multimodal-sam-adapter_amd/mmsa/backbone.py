@@ -653,7 +653,6 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         all16 = fused and bp["qkv_bp16"] is not None    # "attnv": the fused kernels run every contraction on fp16 hi parts of h8 planes
         qkv = ws.planes("blk_qkv", B * T, 3 * Da, fmt=ops.FMT_H8 if all16 else ops.FMT_B3)
         bias_p = bp["qkv_bp16"] if all16 else bp["qkv_bp"]
-        qkv.hi_only = all16    # the fused kernels read fp16 hi parts only: the GEMM stores half of every line
         if not all16:
             qkv.split = bias_p.split   # the kernel with a rel-pos prepass: the qkv GEMM writes the v columns as h8 planes (fp16 P V only)
         ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)

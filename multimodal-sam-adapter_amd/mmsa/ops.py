@@ -75,7 +75,6 @@ class Planes:
     def __init__(self, p, n=None, k=None, kpad=None, fmt=FMT_B3, weight=False, split=0):
         self.p = p
         self.split = split   # > 0 (multiple of 32, fmt FMT_B3): columns >= split are h8-encoded (the v third of qkv planes: fp16 hi for the attention kernels' P V)
-        self.hi_only = False   # GEMM output only: write just the hi half of every 128-byte line (the consumer reads hi parts only: attention v_fmt = 2)
         self.n = p.shape[0] if n is None else n
         self.kpad = p.shape[1] // 2 if kpad is None else kpad
         self.k = self.kpad if k is None else k
@@ -119,12 +118,9 @@ def alloc_planes(rows, cols, device, zero=False, fmt=FMT_B3, split=0):
     return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols), fmt, split=split)
 
 
-CP_HI_ONLY = 0x40   # include/mmsa.h: bit 6 of cp_fmt
-
-
 def cp_format(pl):
     """The GEMM's output-format argument for these planes (include/mmsa.h: bits 0..7 format, bits 8.. = split / 32)."""
-    return FMT_B3 if pl is None else pl.fmt | (CP_HI_ONLY if pl.hi_only else 0) | ((pl.split // 32) << 8)
+    return FMT_B3 if pl is None else pl.fmt | ((pl.split // 32) << 8)
 
 
 def planes_to_float(pl, cols=None):
@@ -137,8 +133,6 @@ def planes_to_float(pl, cols=None):
     if pl.fmt == FMT_H8:
         blk = pl.p.contiguous().view(torch.uint8).view(r, w // 64, 128)
         hi = blk[:, :, :64].contiguous().view(torch.float16).float()                       # [r, nb, 32]
-        if pl.hi_only:
-            return hi.reshape(r, w // 2)[:, :(pl.k if cols is None else cols)]
         ch = blk[:, :, 64:].reshape(r, w // 64, 4, 2, 8)                                    # chunk g: (lo | q(hi)) or (q(hi) | lo)
         lo = ch[:, :, :, 1 if pl.weight else 0].contiguous().view(torch.float8_e5m2).float().reshape(r, w // 64, 32)
         out = (hi + lo / 2048.0).reshape(r, w // 2)
