@@ -646,7 +646,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         T = Hp * Wp
         # intermediate activations travel as bf16 hi/lo planes: split once by the producer, consumed by the
         # GEMM / attention kernels with plain 16-byte copies (same bytes as fp32, no re-splitting per column block)
-        vf = bp["qkv"].fmt   # operand format of this block's GEMMs: the producers below write it (qkv's own output stays bf16 hi/lo for the attention kernels)
+        vf = bp["qkv"].fmt   # operand format of this block's GEMMs: the producers below write it (qkv's own output format is the attention kernel's choice: below)
         n = ws.planes("blk_n", B * T, D, fmt=vf)
         ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
         fused = bp.get("relp") is not None or relg is not None
