@@ -42,7 +42,7 @@ const char* mmsa_last_error(void);
 /* testing aid: fill the LDS of every CU with `pattern` (finds kernels that read LDS they did not write) */
 int mmsa_debug_poison_lds(unsigned pattern, mmsa_stream_t stream);
 /* testing / A-B aid: force the workgroup flavour of mmsa_gemm_split3's LDS-DMA kernel (4 = 128-row tiles, two workgroups per CU;
- * 8 = 256-row ping-pong tiles; 0 = automatic by shape).  Results are bit-identical either way (same k order per output element). */
+ * 8 = 256-row ping-pong tiles; 3 = the 4-wave kernel whose epilogue runs inside the next k loop, gemm_v3.hip; 0 = automatic by shape).  Results are bit-identical either way (same k order per output element). */
 int mmsa_debug_gemm_flavour(int waves_per_workgroup);
 int mmsa_event_create(void** ev);
 int mmsa_event_record(void* ev, mmsa_stream_t stream);

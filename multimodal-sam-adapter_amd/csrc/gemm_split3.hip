@@ -277,6 +277,15 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream);
+// gemm_v3.hip: the kernel whose epilogue runs inside the next tile's k loop; returns 1 = launched, 0 = not its shape (fall through to gemm_v2)
+int mmsa_gemm_v3_launch(const unsigned short* Ap, long lda, long strideA,
+                        const unsigned short* Wp, long strideW,
+                        const float* bias, long strideBias, const float* colscale,
+                        const float* resid, long ldr, long strideR, int resid_mod, float beta,
+                        float* C, long ldc, long strideC,
+                        unsigned short* Cp, long ldcp, long strideCp,
+                        int M, int N, int K, int batch, int act, float alpha,
+                        int out_mode, int fmt, int cp_fmt, int max_grid, hipStream_t stream);
 
 // ---- tiny problems (CoordinateAttention's 1x1 convs on pooled maps, AM:187-201: M = B*(h+w) <= ~1000 rows, N or K of 8..48): a
 // 128 x 128 MFMA tile would be one or two workgroups walking K alone (64 us for M = 128, N = 48, K = 1536).  Here one wave owns
@@ -384,10 +393,14 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
     MMSA_CHECK_LAUNCH("gemm_split3(tiny)");
     return MMSA_OK;
   }
-  if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow)))   // h8 operands: only the LDS-DMA kernel reads them
+  if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow))) {   // h8 operands: only the LDS-DMA kernels read them
+    const int r3 = mmsa_gemm_v3_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR, resid_mod, beta,
+                                       C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha, out_mode, fmt, cp_fmt, max_grid, stream);
+    if (r3 != 0) return r3 < 0 ? r3 : MMSA_OK;
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
                                out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream);
+  }
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
   const bool gen = out_mode != 0 || resid_mod > 0;
   if (ap) {

@@ -877,8 +877,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 
 static int g_num_cus = 0;
 static int g_nw_override = 0;   // testing / A-B aid: 4 or 8 forces the workgroup flavour of every later launch, 0 = automatic
+extern int g_mmsa_v3_mode;      // gemm_v3.hip
 extern "C" int mmsa_debug_gemm_flavour(int waves_per_workgroup) {
   g_nw_override = (waves_per_workgroup == 4 || waves_per_workgroup == 8) ? waves_per_workgroup : 0;
+  g_mmsa_v3_mode = waves_per_workgroup == 3 ? 1 : (g_nw_override ? 0 : -1);   // 3: the epilogue-in-the-k-loop kernel wherever it takes the shape; 4 / 8: gemm_v2's flavours only
   return MMSA_OK;
 }
 

@@ -136,6 +136,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         build_tree(self, self.cfg)
         self._packed = None
         self._ws = None
+        self._taps = None     # per-stage copies for the error-budget test (forward_taps); None on the product path
         self.register_load_state_dict_post_hook(lambda m, _: m.invalidate())
         self.init_weights(pretrained)
         # TwinConvNeXt.init_weights (TC:382-443) loads `checkpoint` -- a URL in every shipped config.  There is no network here:
@@ -536,6 +537,32 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
             return self._vit(x, B, H, W, c1, cbuf, c1_ready), None
 
+    @torch.no_grad()
+    def forward_taps(self, x):
+        """forward() that also returns copies of the intermediate tensors the oracle taps (oracle/ref_encoder.py OracleEncoder.forward
+        `taps`): twin{i} / fuse{i} (NCHW), c1, c_in, x_in, x{i}, c{i} ([B, N, D]).  Test aid of the per-stage error budget
+        (tests/test_backbone_gpu.py::test_vitl1024_error_budget); the copies are plain device-to-device clones on the launch streams."""
+        self._taps = {}
+        try:
+            outs, _ = self.forward(x)
+            torch.cuda.synchronize(x.device)
+            taps = self._taps
+        finally:
+            self._taps = None
+        B, _, H, W = x.shape
+        D = self.cfg["embed_dim"]
+        res = {}
+        for k, v in taps.items():
+            if k.startswith(("twin", "fuse")):
+                i = int(k[-1])
+                h, w = H // (4 << i), W // (4 << i)
+                res[k] = v.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
+            else:
+                res[k] = v.reshape(B, -1, D)
+        for i, f in enumerate(outs):
+            res[f"f{i + 1}"] = f
+        return outs, res
+
     def forward_pipelined(self, x_next):
         """Throughput mode (two-stage software pipeline over consecutive batches).  The spatial prior module depends only on
         the image, and every ViT block depends on it (the first injector reads c2..c4), so inside one batch the two cannot
@@ -596,6 +623,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.im2col_nchw(x, 0, 3, p, a)
         xs = [ws.get(f"x{i}", B * T, D) for i in range(len(self.interaction_indexes) + 1)]
         ops.gemm(a, pk["pe_w"], xs[0], bias=pk["pe_b"], resid=geo["pos"], resid_mod=T)
+        taps = self._taps
+        if taps is not None:
+            taps["x_in"], taps["c_in"] = xs[0].clone(), cbuf[:B * Nc].clone()
 
         # ---- interactions (AM:567-581)
         for i, idx in enumerate(self.interaction_indexes):
@@ -605,10 +635,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp, geo["relg"][bi])
             for ex in it["ext"]:
                 self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
+            if taps is not None:
+                taps[f"x{i}"], taps[f"c{i}"] = xs[i + 1].clone(), cbuf[:B * Nc].clone()
 
         # ---- tail (BK:316-337)
         if c1_ready is not None:
             torch.cuda.current_stream().wait_event(c1_ready)
+        if taps is not None:
+            taps["c1_map"] = c1.clone()
         outs = []
         c2p = ws.planes("up_a", B * n2, D, fmt=pk["up"].fmt)
         for bi in range(B):
@@ -751,6 +785,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         #     hold the LDS of every CU, so the other stream's kernels queue behind them.
         ev_x = []
         self._twin_batched(x, B, sizes, tcat, ev_x, tcat_p)
+        if self._taps is not None:
+            for i in range(4):
+                self._taps[f"twin{i}"] = tcat[i].clone()
         # --- RoadFormer2Neck (AM:364-394) + fc1..4 (AM:947-956): one stream per level, gated on that level's two inputs
         offs = [0, 0, sizes[1][0] * sizes[1][1], sizes[1][0] * sizes[1][1] + sizes[2][0] * sizes[2][1]]
         joins = []
@@ -932,6 +969,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             zo = ws.get("nk_g", P, C)  # fn is dead now
             ops.ca_apply(z, att, zo, B, h, w)
             sa = HW * C
+        if self._taps is not None:
+            self._taps[f"fuse{level}"] = ops.planes_to_float(zo, cols=C) if pl_ok else zo[:, :C].clone()
         # fc_i (AM:947-956) straight into c1 / the c2|c3|c4 token buffer (level embed folded into the bias)
         if out_stride_b == 0:
             ops.gemm(zo, lv["fc"], out, bias=lv["fc_b"])

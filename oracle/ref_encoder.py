@@ -658,7 +658,7 @@ class OracleEncoder(nn.Module):
         c4 = c4 + self.level_embed[2]
         c = torch.cat([c2, c3, c4], dim=1)
         if taps is not None:
-            taps["c1"], taps["c_in"] = c1, c
+            taps["c1_map"], taps["c_in"] = c1, c   # (c1_map: "c1" is the adapter tokens after interaction 1 below)
         d1, d2 = deform_inputs(x.shape[2], x.shape[3], x.dtype)
         x, H, W = self.patch_embed(x)
         bs, n, dim = x.shape
