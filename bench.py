@@ -33,7 +33,12 @@ Extra objects:
                   the launch stream), against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline -- the CPU oracle (oracle/ref_encoder.py, a PyTorch-CPU restatement validated against the reference)
                   timed on this box's physical host cores on ONE 1024x1024 image (rank 0, N=1 only): one small warm-up
-                  forward, then the median of up to 3 runs inside a 45 s budget.
+                  forward, then the median of 3 runs (120 s budget), plus the ViT-B 512x512 line of SURVEY 8(d) (median of 5).
+  hbm_kernels  -- GB/s of the HBM-bound kernels of the step against 8 TB/s, from the committed counter passes
+                  (profiles/rNN_hbm_kernels.json, tools/pmc_all.sh).
+
+MMSA_BENCH_STUB=1 (tests only): no GPU -- gloo on CPU tensors, the device step replaced by a stand-in of known duration; exercises
+rank spawning, sharding, the barrier / max-over-ranks timing, the logits all-gather and the JSON assembly of the N > 1 path.
 """
 import argparse
 import glob
@@ -50,6 +55,7 @@ for p in (ROOT, os.path.join(ROOT, "multimodal-sam-adapter_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+STUB = os.environ.get("MMSA_BENCH_STUB") == "1"   # tests/test_host_cpu.py: the N > 1 control path without a GPU
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FLOPS_PER_IMAGE = {"vitl1024": 4.5207e12, "vitb512": 0.5411e12}   # algorithmic GEMM/conv/bmm FLOPs per image (vith1024: no figure -> null)
 
@@ -75,10 +81,13 @@ def parse():
 
 def spawn_ranks(n):
     """Parent of a self-launched multi-GPU run: starts one child per GPU and relays rank 0's stdout.  Makes no GPU call
-    (torch.cuda.device_count() does not initialise the device on this image)."""
+    (torch.cuda.device_count() does not initialise the device on this image).  All children are polled: the first one that
+    exits non-zero takes the others down with it (a rank that dies at start-up would otherwise leave rank 0 in the rendezvous
+    until its timeout), and the whole job is bounded by MMSA_BENCH_TIMEOUT seconds (default 1800)."""
+    import tempfile
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not STUB:
         print(f"[bench] --gpus {n} asked for but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     s = socket.socket()
@@ -86,16 +95,35 @@ def spawn_ranks(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].stdout.read().decode()
+                                      stdout=out0 if r == 0 else sys.stderr))
+    deadline = time.time() + float(os.environ.get("MMSA_BENCH_TIMEOUT", "1800"))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out0)
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is not None:
+                live.remove(p)
+                rc = max(rc, abs(c))
+        if (rc or time.time() > deadline) and live:
+            print(f"[bench] stopping {len(live)} rank(s): " + ("a rank failed" if rc else "timeout"), file=sys.stderr)
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 3
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return rc
 
@@ -143,13 +171,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if STUB and os.environ.get("MMSA_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(7)       # tests: a rank that dies at start-up (the parent must stop the others instead of waiting for their rendezvous)
+    if STUB:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a_, **k_: None   # this process never touches a GPU
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("MMSA_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if STUB:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import mmsa
     from mmsa.dist import allgather_logits
@@ -158,14 +195,18 @@ def main():
 
     cfg = CONFIGS[a.config]
     torch.manual_seed(1234)
-    model = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
-    if not a.default_init:
+    if STUB:
+        a.no_graph = a.no_verify = a.no_roofline = a.no_cpu_baseline = a.no_head = True
+        a.chains = 1
+    model = None if STUB else mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    if model is not None and not a.default_init:
         model.load_state_dict(seeded_state_dict(model, seed=cfg["seed"]))
-    x = make_input(cfg, batch=a.batch, seed=1234 + rank).to(dev)
+    x = make_input(cfg if not STUB else CONFIGS["tiny256"], batch=a.batch, seed=1234 + rank).to(dev)
     if os.environ.get("MMSA_FUSE_DWLN") == "1":   # A/B aid: ConvNeXt depthwise conv + LayerNorm as one kernel (slower: csrc/conv_ln.hip)
         model.fuse_dwconv_ln = True
 
     head = None
+    stub_logits = torch.full((a.batch, 25, 8, 8), float(rank)) if STUB else None
     if not a.no_head:
         hcfg = HEAD_CONFIGS["head_vitl"]
         hkw = dict(hcfg["kwargs"])
@@ -182,6 +223,9 @@ def main():
         return feats[0]
 
     def local_step():                      # everything that is captured in the HIP graph
+        if STUB:                           # stand-in of known duration: rank r's step takes 10 (r + 1) ms
+            time.sleep(0.01 * (rank + 1))
+            return stub_logits
         fs = encoder_step()
         return head(fs) if head is not None else fs[0]
 
@@ -280,15 +324,17 @@ def main():
     gathered = [None]
 
     def run():
-        replay()                            # chains: both sub-batch chains of the step, joined into this stream (a step ends before the next starts)
-        if head is not None and use_dist:   # the pipeline's only exchange step; outside the graph (RCCL owns its stream)
-            gathered[0] = allgather_logits(local_out)
+        out_ = replay()                     # chains: both sub-batch chains of the step, joined into this stream (a step ends before the next starts)
+        if (head is not None or STUB) and use_dist:   # the pipeline's only exchange step; outside the graph (RCCL owns its stream)
+            gathered[0] = allgather_logits(out_ if STUB else local_out)
 
     dt = timed(run)
     imgs = a.batch * world * a.steps
     value = imgs / dt
-    if head is not None and use_dist and rank == 0:
+    if (head is not None or STUB) and use_dist and rank == 0:
         assert gathered[0].shape[0] == world * a.batch
+        if STUB:    # every rank's shard arrived, in rank order
+            assert [float(gathered[0][r * a.batch, 0, 0, 0]) for r in range(world)] == [float(r) for r in range(world)]
 
     # ---- what was timed is what is verified (untimed; every rank)
     verified = None
@@ -321,9 +367,12 @@ def main():
                 x[0].copy_(make_input(cfg, batch=1)[0].to(dev))       # the golden input into image 0 of the graph's input buffer
                 replay()
                 torch.cuda.synchronize()
+                # the maps THIS replay wrote: a captured graph writes the tensors of its capture (graph_feats); an eager step (--no-graph,
+                # or capture unavailable) allocates fresh outputs on every call, which encoder_step leaves in feats[0]
+                cur = graph_feats if graphed else feats[0]
                 worst = 0.0
                 for i in range(4):
-                    f0 = (graph_feats[i] if chains is None else chains.feats[0][i])[0]
+                    f0 = (cur[i] if chains is None else chains.feats[0][i])[0]
                     pi = probe_index(f0.numel(), 2048, seed=100 + i).to(dev)
                     got = f0.flatten()[pi].double().cpu()
                     ref = torch.from_numpy(g[f"f{i+1}_probe"]).double()
@@ -391,23 +440,40 @@ def main():
         torch.set_num_threads(ncores)
         tiny = CONFIGS["tiny256"]
         R.OracleEncoder(**tiny["kwargs"])(make_input(tiny, batch=1))      # warm-up: thread pool, oneDNN primitives
-        orc = R.OracleEncoder(**cfg["kwargs"])
-        xc = make_input(cfg, batch=1, seed=1234)
-        times, t_all = [], time.perf_counter()
-        while len(times) < 3 and (not times or time.perf_counter() - t_all + times[-1] < 45.0):
-            tc = time.perf_counter()
-            orc(xc)
-            times.append(time.perf_counter() - tc)
-        tcpu = statistics.median(times)
+
+        def cpu_line(name, runs, budget):
+            c = CONFIGS[name]
+            orc = R.OracleEncoder(**c["kwargs"])
+            xc = make_input(c, batch=1, seed=1234)
+            times, t_all = [], time.perf_counter()
+            while len(times) < runs and (not times or time.perf_counter() - t_all + times[-1] < budget):
+                tc = time.perf_counter()
+                orc(xc)
+                times.append(time.perf_counter() - tc)
+            return statistics.median(times), times
+
+        tcpu, times = cpu_line("vitl1024", 3, 120.0)
+        tb, times_b = cpu_line("vitb512", 5, 40.0)
         cpu = {"value": round(1.0 / tcpu, 4), "unit": "images/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model,
                "sample": f"1 image 1024x1024 ViT-L RGB+LiDAR, fp32 PyTorch-CPU oracle, {ncores} threads (physical cores), tiny warm-up forward then "
-                         f"median of {len(times)} run(s): " + ", ".join(f"{t:.1f}" for t in times) + " s"}
+                         f"median of {len(times)} run(s): " + ", ".join(f"{t:.1f}" for t in times) + " s",
+               "vitb512": {"value": round(1.0 / tb, 4), "unit": "images/s",
+                           "sample": f"1 image 512x512 ViT-B (BASELINE configs[0]), same threads, median of {len(times_b)} run(s): "
+                                     + ", ".join(f"{t:.2f}" for t in times_b) + " s"}}
 
     if rank == 0:
-        fpi = FLOPS_PER_IMAGE.get(a.config)
-        headline = a.config == "vitl1024"
+        fpi = FLOPS_PER_IMAGE.get(a.config) if not STUB else None
+        headline = a.config == "vitl1024" and not STUB
+        size = cfg["kwargs"]["img_size"] if not STUB else 0
+        arch = {"vitl1024": "ViT-L", "vith1024": "ViT-H", "vitb512": "ViT-B", "tiny256": "tiny fixture model"}[a.config]
+        hbm = None
+        hfile = latest_profile("hbm_kernels.json")
+        if hfile and headline and not a.no_roofline:
+            hj = json.load(open(hfile))
+            hbm = {"peak_GBps": hj.get("peak_GBps", 8000.0), "source": f"profiles/{os.path.basename(hfile)}",
+                   "kernels": {k: {"GBps": v["GBps"], "frac": v["frac"]} for k, v in hj["kernels"].items()}}
         out = {
-            "metric": "images/sec encoder fwd @1024x1024 RGB+LiDAR ViT-L",
+            "metric": f"images/sec encoder fwd @{size}x{size} RGB+LiDAR {arch}" if not STUB else "stub (no GPU): control path of the N > 1 bench",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) where the 'attnv' site is on; fp32 accumulate, fp32 activations", "data": "synthetic",
@@ -423,7 +489,8 @@ def main():
             "verified": verified,
             "encoder_only": encoder_only,
             "end_to_end_algorithmic_tflops": round(value * fpi / 1e12, 1) if fpi else None,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "chains_probe_ms": chain_probe,
+            "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         try:   # RCCL prints a banner through C stdio; flush it so that the JSON line is the LAST line of stdout
             import ctypes

@@ -105,6 +105,15 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * whatever the base format (the qkv projection: q and k bf16 hi/lo, v with an fp16 hi part for the attention kernels' v_fmt = 1).
  * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
  * its share of the CUs); 0 = all CUs.  Results do not depend on it. */
+/* LayerNorm folded into a producer / consumer pair of GEMMs (base/image_encoder.py:396-421: x -> norm1 -> qkv, x -> norm2 -> lin1).  One-shot
+ * extras of the NEXT mmsa_gemm_split3 call (cleared by it; that call must be one the LDS-DMA kernel takes: activation planes, M >= 128):
+ *   rowstats_out [M, N/64, 2] fp32: the call also writes, per output row and 64-column strip, the sum and the sum of squares of the fp32
+ *     values it stores (plain fp32 output, no activation, N % 64 == 0) -- the producer of the residual stream;
+ *   rownorm_mean_rstd [M, 2] + rownorm_colsum [N] (batch stride = strideBias): the call runs on the RAW stream's planes against W o w and its
+ *     epilogue computes rstd_r * (acc - mean_r * colsum_n) + bias_n before the activation (planes-only output, N % 128 == 0) -- the consumer.
+ * mmsa_rowstats_finalize turns the strip sums into (mean, rstd) per row (D = 64 * strips columns, biased variance, eps inside the root). */
+int mmsa_gemm_next_extras(float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum);
+int mmsa_rowstats_finalize(const float* rowstats, int rows, int strips, int D, float eps, float* mean_rstd, mmsa_stream_t stream);
 int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      const uint16_t* Wp, long strideW,
                      const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,

@@ -276,7 +276,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         float* C, long ldc, long strideC,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream);
+                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
+                        float* rs_out, const float* rn_mr, const float* rn_cs);
 // gemm_v3.hip: the kernel whose epilogue runs inside the next tile's k loop; returns 1 = launched, 0 = not its shape (fall through to gemm_v2)
 int mmsa_gemm_v3_launch(const unsigned short* Ap, long lda, long strideA,
                         const unsigned short* Wp, long strideW,
@@ -333,6 +334,16 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a, int ncg) {
 }
 
 
+// One-shot extras of the NEXT mmsa_gemm_split3 call (include/mmsa.h): kept out of that entry's 33-argument signature.  Launches are
+// issued from one host thread at a time (the bindings hold the GIL), so a process-wide slot is enough; it is cleared by the call.
+static struct { float* rs_out; const float* rn_mr; const float* rn_cs; } g_gemm_extras = {nullptr, nullptr, nullptr};
+extern "C" int mmsa_gemm_next_extras(float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum) {
+  MMSA_CHECK_ARG(!rownorm_mean_rstd == !rownorm_colsum, "gemm_next_extras: mean/rstd rows and column sums go together");
+  MMSA_CHECK_ARG(!(rowstats_out && rownorm_mean_rstd), "gemm_next_extras: a GEMM either writes row statistics or normalises by them");
+  g_gemm_extras.rs_out = rowstats_out; g_gemm_extras.rn_mr = rownorm_mean_rstd; g_gemm_extras.rn_cs = rownorm_colsum;
+  return MMSA_OK;
+}
+
 // C-ABI entry: see include/mmsa.h for the contract.
 extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long lda, long strideA,
                                 const unsigned short* Wp, long strideW,
@@ -343,6 +354,12 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 int M, int N, int K, int batch, int act, float alpha,
                                 int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
   const bool ap = Ap != nullptr;
+  float* const rs_out = g_gemm_extras.rs_out;
+  const float* const rn_mr = g_gemm_extras.rn_mr;
+  const float* const rn_cs = g_gemm_extras.rn_cs;
+  g_gemm_extras.rs_out = nullptr; g_gemm_extras.rn_mr = nullptr; g_gemm_extras.rn_cs = nullptr;
+  const bool extras = rs_out || rn_mr;
+  MMSA_CHECK_ARG(!extras || (ap && M >= 128), "gemm_split3: row statistics / row normalisation need activation planes and M >= 128");
   MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && cp_fmt >= 0 && (MMSA_CP_BASE(cp_fmt) == MMSA_FMT_B3 || MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
   MMSA_CHECK_ARG(MMSA_CP_SPLIT(cp_fmt) == 0 || (out_mode == 0 && MMSA_CP_SPLIT(cp_fmt) < N), "gemm_split3: the output-format split %d needs a plain [M, N] planes output with N=%d beyond it", MMSA_CP_SPLIT(cp_fmt), N);
   MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 operands need A planes and K %% 64 == 0 (K=%d)", K);
@@ -387,20 +404,21 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   static const bool no_tiny = getenv("MMSA_GEMM_NO_TINY") != nullptr;   // A/B aid
   // routed by the problem's small dimension, NOT by the row count (rows scale with the image batch: a batch-dependent choice of
   // kernel would make results depend on how images are batched); M <= 16384 covers 32 images of the largest pooled map
-  if (!ap && !Cp && out_mode == 0 && resid_mod <= 0 && (N <= 64 || K <= 64) && M <= 16384 && !no_tiny) {
+  if (!ap && !Cp && out_mode == 0 && resid_mod <= 0 && (N <= 64 || K <= 64) && M <= 16384 && !no_tiny && !extras) {
     const int ncg = cdiv(N, 8);
     hipLaunchKernelGGL(gemm_tiny_kernel, dim3(cdiv((long)M * ncg, 4), batch), dim3(256), 0, stream, a, ncg);
     MMSA_CHECK_LAUNCH("gemm_split3(tiny)");
     return MMSA_OK;
   }
   if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow))) {   // h8 operands: only the LDS-DMA kernels read them
-    const int r3 = mmsa_gemm_v3_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR, resid_mod, beta,
-                                       C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha, out_mode, fmt, cp_fmt, max_grid, stream);
+    const int r3 = extras ? 0 : mmsa_gemm_v3_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR, resid_mod, beta,
+                                                    C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha, out_mode, fmt, cp_fmt, max_grid, stream);
     if (r3 != 0) return r3 < 0 ? r3 : MMSA_OK;
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
-                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream);
+                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream, rs_out, rn_mr, rn_cs);
   }
+  MMSA_CHECK_ARG(!extras, "gemm_split3: this shape is not routed to the LDS-DMA kernel, which alone writes row statistics / normalises rows");
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
   const bool gen = out_mode != 0 || resid_mod > 0;
   if (ap) {

@@ -42,6 +42,14 @@ struct GemmV2Args {
   int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
                // that fills the CUs better: N = 384 gives 3 tiles of 128 (192 tiles on 256 CUs for the ConvNeXt pw2 GEMMs) or 4 of 96 (256 tiles)
   int cp_fmt;  // format of the planes output Cp: MMSA_FMT_B3 (bf16 hi | lo) or MMSA_FMT_H8 (fp16 hi | e5m2 lo, q(hi): common.h), independent of the operands' format
+  // LayerNorm folded into a producer / consumer pair of GEMMs (mmsa_gemm_next_extras; IE:396-421: x -> norm -> qkv / lin1):
+  //   rs_out: this GEMM (the producer of the residual stream: proj, lin2, the injector's output projection) also writes, per output row
+  //           and 64-column strip, the sum and the sum of squares of the fp32 values it stores: rs_out[(row * rs_strips + strip) * 2 + {0,1}]
+  //   rn_mr / rn_cs: this GEMM (the consumer: qkv, lin1) runs on the RAW stream's planes against W o w and normalises in its epilogue:
+  //           out = rstd_r * (acc - mean_r * cs_n) + bias_n   with (mean_r, rstd_r) = rn_mr[2 r], rn_mr[2 r + 1] and cs_n = rn_cs[n] =
+  //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
+  float* rs_out; int rs_strips;
+  const float* rn_mr; const float* rn_cs;
   int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
 };
 
@@ -668,21 +676,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       if constexpr (EPI_UNROLL && !GEN) direct = fast && Cp && !C && !resid && ni4 && a.debug == 0 && (((uintptr_t)bias | (uintptr_t)colscale) & 15) == 0;
       if constexpr (EPI_UNROLL && !GEN) {
         if (direct) {
-          float4 bn_[4], cn_[4];
+          float4 bn_[4], cn_[4], sn_[4];
+          const bool rn = a.rn_mr != nullptr;       // kernel-uniform: row-normalising epilogue (LayerNorm folded in)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             const int ci = nb_ + ni * 16 + 4 * g;     // fast: the whole 64-column strip is inside N
             bn_[ni] = bias ? *reinterpret_cast<const float4*>(bias + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
             cn_[ni] = colscale ? *reinterpret_cast<const float4*>(colscale + ci) : make_float4(1.f, 1.f, 1.f, 1.f);
             cn_[ni].x *= a.alpha; cn_[ni].y *= a.alpha; cn_[ni].z *= a.alpha; cn_[ni].w *= a.alpha;
+            sn_[ni] = rn ? *reinterpret_cast<const float4*>(a.rn_cs + (long)bz * a.strideBias + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
           unsigned short* wrow = reinterpret_cast<unsigned short*>(stg + l15 * 68);
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi) {
             const int mb = m0 + wm * 64 + mi * 16;
+            float mu = 0.f, rs = 1.f;                 // this lane's row of the sub-tile (rows beyond M: clamped, never stored)
+            if (rn) {
+              const float2 mr = *reinterpret_cast<const float2*>(a.rn_mr + 2 * ((long)bz * a.M + min(mb + l15, a.M - 1)));
+              mu = mr.x; rs = mr.y;
+            }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-              float4 o = make_float4(acc[ni][mi][0] + bn_[ni].x, acc[ni][mi][1] + bn_[ni].y, acc[ni][mi][2] + bn_[ni].z, acc[ni][mi][3] + bn_[ni].w);
+              float4 o;
+              if (rn) {   // rstd * (acc - mean * colsum) + bias: the two roundings of the reference's (x - mean) * rstd are not reproduced, the value is
+                o = make_float4(fmaf(rs, fmaf(-mu, sn_[ni].x, acc[ni][mi][0]), bn_[ni].x), fmaf(rs, fmaf(-mu, sn_[ni].y, acc[ni][mi][1]), bn_[ni].y),
+                                fmaf(rs, fmaf(-mu, sn_[ni].z, acc[ni][mi][2]), bn_[ni].z), fmaf(rs, fmaf(-mu, sn_[ni].w, acc[ni][mi][3]), bn_[ni].w));
+              } else {
+                o = make_float4(acc[ni][mi][0] + bn_[ni].x, acc[ni][mi][1] + bn_[ni].y, acc[ni][mi][2] + bn_[ni].z, acc[ni][mi][3] + bn_[ni].w);
+              }
               acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
               if (act != ACT_NONE) {
                 if (act == ACT_GELU) o = gelu4(o);
@@ -707,18 +728,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       // measured time-neutral against the transposed whole-row stores on every shape and on the step, same box: not kept.)
       if (direct) {
       } else if constexpr (EPI_UNROLL) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 16;
-        // residual rows first: 4 independent 16-byte loads in flight, no waits inside the element loops
-        float4 rr[4];
-        if (fast && resid) {
+        // residual rows one sub-tile AHEAD: the 4 loads of sub-tile mi + 1 are issued before sub-tile mi is processed (its LDS round
+        // trips, arithmetic and stores cover their latency).  Requested per sub-tile -- behind the previous sub-tile's stores, which the
+        // compiler must assume alias them when the GEMM updates its residual in place -- a tile's epilogue was four serialised memory
+        // round trips: 33 us of a 127 us launch at one tile per workgroup (lin2 of one image, profiles/r03_v3_vs_v2.txt).  (All four
+        // sub-tiles up front would need 64 registers and spills.)
+        float4 rrn[4];
+        auto load_rr = [&](int mi_) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             long drow_, rrow; int dcol;
-            map_row(min(mb + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
-            rr[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
+            map_row(min(m0 + wm * 64 + mi_ * 16 + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
+            rrn[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
           }
+        };
+        if (fast && resid) load_rr(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 16;
+        float4 rr[4];
+        if (fast && resid) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rr[i] = rrn[i];
+          if (mi < 3) load_rr(mi + 1);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -750,6 +782,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
               pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
             }
             const int m = mb + rl;
+            if (a.rs_out) {   // kernel-uniform: sum and sum of squares of this row's 64 columns (the 16 lanes of one DPP row hold them)
+              float s1 = (o.x + o.y) + (o.z + o.w), s2 = fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w);
+#pragma unroll
+              for (int sh = 8; sh > 0; sh >>= 1) { s1 += __shfl_xor(s1, sh, 64); s2 += __shfl_xor(s2, sh, 64); }
+              if ((lane & 15) == 0 && m < a.M)
+                *reinterpret_cast<float2*>(a.rs_out + (((long)bz * a.M + m) * a.rs_strips + (nb_ >> 6)) * 2) = make_float2(s1, s2);
+            }
             if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
             else if (m < a.M && lane_ok) {
               long drow_, rrow; int dcol;
@@ -893,8 +932,16 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         float* C, long ldc, long strideC,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
+                        int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
+                        float* rs_out, const float* rn_mr, const float* rn_cs) {
   GemmV2Args a;
+  // LayerNorm fold (mmsa_gemm_next_extras): both forms run on the unrolled fast epilogue of 128-column tiles with whole 64-column strips
+  MMSA_CHECK_ARG(!rs_out || (C && out_mode == 0 && resid_mod <= 0 && act == ACT_NONE && (N & 63) == 0 && (ldc & 3) == 0 && (!resid || (ldr & 3) == 0) && (!Cp || (ldcp & 3) == 0)),
+                 "gemm(v2): row statistics need a plain fp32 output, no activation, N %% 64 == 0 (N=%d)", N);
+  MMSA_CHECK_ARG(!rn_mr || (rn_cs && Cp && !C && !resid && out_mode == 0 && resid_mod <= 0 && (N & 127) == 0 && (act == ACT_NONE || act == ACT_GELU || act == ACT_RELU) &&
+                            ((((uintptr_t)bias) | ((uintptr_t)colscale) | ((uintptr_t)rn_cs)) & 15) == 0 && (strideBias & 3) == 0),
+                 "gemm(v2): the row-normalising epilogue needs a planes-only output, N %% 128 == 0 (N=%d), 16-byte aligned column vectors", N);
+  a.rs_out = rs_out; a.rs_strips = N >> 6; a.rn_mr = rn_mr; a.rn_cs = rn_cs;
   a.Ap = Ap; a.lda = lda; a.strideA = strideA;
   a.Wp = Wp; a.strideW = strideW;
   a.ldw = 2L * K;
@@ -915,7 +962,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   // forces one, MMSA_GEMM_NW4_MAXK = k routes shapes with K <= k to it.  Results are bit-identical either way.  (bf16 planes only.)
   static const int nw_force = getenv("MMSA_GEMM_NW") ? atoi(getenv("MMSA_GEMM_NW")) : 0;
   static const int nw4_maxk = getenv("MMSA_GEMM_NW4_MAXK") ? atoi(getenv("MMSA_GEMM_NW4_MAXK")) : 0;
-  const int nw = h8 ? 8 : g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
+  const int nw = (h8 || rs_out || rn_mr) ? 8 : g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
   const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
   a.nbm = cdiv(M, bm);
   a.bn = V2_BN;
@@ -946,7 +993,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   const int cus = (max_grid > 0 && max_grid < g_num_cus) ? max_grid : g_num_cus;
   // 96-column tiles when they occupy the CUs better: rounds(tiles) x relative tile cost (0.75) against rounds of 128-column tiles.
   // fp32 output only (the planes epilogue writes whole 64-column strips) and no pixel-shuffle / broadcast-residual store.
-  if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96) {
+  if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96 && N % 96 == 0 && !rs_out) {   // (a ragged last 96-column tile would run the element-wise
+    // epilogue: N = 256 -- the ConvFFN fc1 of the extractors -- was routed here and spent 40 of its 92 us in it, profiles/r03_v3_vs_v2.txt)
     static const bool no96 = getenv("MMSA_GEMM_NO96") != nullptr;   // A/B aid
     const int nbn96 = cdiv(N, 96);
     const long t96 = (long)a.nbm * nbn96 * batch;

@@ -333,3 +333,26 @@ extern "C" int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, cons
   MMSA_CHECK_LAUNCH("lnhw_apply");
   return MMSA_OK;
 }
+
+
+// ---- LayerNorm folded into GEMMs (IE:396-421): the producer GEMM of the residual stream leaves, per row and 64-column strip, the sum and
+// the sum of squares of what it stored (mmsa_gemm_next_extras); this turns them into (mean, rstd) per row for the consumer's epilogue.
+// Strips are combined in double (E[x^2] - mean^2 on fp32 partial sums of 64 values each; biased variance, eps inside the root as nn.LayerNorm).
+__global__ void rowstats_finalize_kernel(const float* __restrict__ rs, int rows, int strips, int D, float eps, float* __restrict__ mr) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(rs) + (long)r * strips;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < strips; ++i) { const float2 v = p[i]; s1 += (double)v.x; s2 += (double)v.y; }
+  const double mean = s1 / D;
+  double var = s2 / D - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  reinterpret_cast<float2*>(mr)[r] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
+extern "C" int mmsa_rowstats_finalize(const float* rowstats, int rows, int strips, int D, float eps, float* mean_rstd, hipStream_t stream) {
+  MMSA_CHECK_ARG(rowstats && mean_rstd && rows > 0 && strips > 0 && D == strips * 64, "rowstats_finalize: bad args (D = 64 * strips)");
+  hipLaunchKernelGGL(rowstats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rowstats, rows, strips, D, eps, mean_rstd);
+  MMSA_CHECK_LAUNCH("rowstats_finalize");
+  return MMSA_OK;
+}

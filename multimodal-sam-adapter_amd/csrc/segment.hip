@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void slide_argmax_kernel(const float* __restri
       }
     ++nk;
   }
-  if (nk == 0 || nk > 8) { atomicAdd(uncovered, 1); return; }   // more than 8 overlapping windows per pixel: not supported, reported
+  if (nk == 0 || nk > 8) {   // no window, or more than 8 overlapping windows per pixel: not supported -- counted, and the pixel gets 255, never an unwritten byte
+    atomicAdd(uncovered, 1);
+    out[((long)b * H + y) * W + x] = 255;
+    return;
+  }
   const float cnt = (float)nk;
   float best = -INFINITY;
   int bi = 0;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void slide_argmax_kernel(const float* __restri
 
 extern "C" int mmsa_slide_argmax(const float* logits, int n, int C, int hs, int ws, const int* windows /* HOST [n,3] */, unsigned char* out,
                                  int B, int H, int W, int hc, int wc, int* uncovered /* device int, zeroed by the caller */, hipStream_t stream) {
-  MMSA_CHECK_ARG(logits && out && uncovered && C > 0 && C <= 256 && hs > 0 && ws > 0 && hc > 0 && wc > 0 && B > 0 && H <= 65535 && B <= 65535, "slide_argmax: bad args");
+  MMSA_CHECK_ARG(logits && out && uncovered && C > 0 && C <= 255 && hs > 0 && ws > 0 && hc > 0 && wc > 0 && B > 0 && H <= 65535 && B <= 65535, "slide_argmax: bad args");
   WindowTable wt;
   int rc = fill_windows(wt, windows, n, B, H, W, hc, wc, "slide_argmax");
   if (rc) return rc;

@@ -198,8 +198,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # projections, ConvFFN); "up" = the 2x2 transposed conv of the tail.  The TwinConvNeXt / neck GEMMs stay on bf16 hi/lo (the most
     # error-sensitive part of the path: SURVEY appendix F).  `model.h8_sites = ()` or MMSA_H8=none keeps every site on bf16 hi/lo.
     # "attnv" = the attention kernels run P V on the fp16 MFMA: the v third of the qkv planes (GEMM output and bias rows) is h8-encoded
-    # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study); Q K^T stays on bf16 hi/lo.
+    # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study); the kernels with the rel-pos terms
+    # fused run Q K^T and the rel-pos terms on fp16 hi parts too -- per block, and only while its logits are small (_attn_mode).
     H8_DEFAULT = ("vit", "inter", "up", "attnv")
+    attention_precision = "auto"   # 'auto' | 'f16' | 'b3': operand precision INSIDE the attention kernels where the "attnv" site allows fp16 (_attn_mode)
 
     def _h8_sites(self):
         env = os.environ.get("MMSA_H8")
@@ -269,6 +271,19 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         hidden_ = sd["blocks.0.mlp.lin1.weight"].shape[0]
         vfmt = ops.FMT_H8 if ("vit" in h8_sites and D % 64 == 0 and Da % 64 == 0 and hidden_ % 64 == 0) else ops.FMT_B3
         pk["vit_fmt"] = vfmt
+        # LayerNorm fold (IE:396-421): norm1 / norm2 of the ViT blocks live in their consumer GEMMs.  The producer of the
+        # residual stream (proj, lin2, the injector's output projection) also writes the stream as planes and per-row strip sums; qkv / lin1
+        # run on W o w and compute rstd * (x W'^T - mean * colsum(W')) + (W b + bias) in their epilogue.  tools/lnfold_study.py: same error as
+        # LayerNorm + GEMM on the seeded weights, + 1.5e-5 at |mean| = 4.5 std.  Needs whole 128-column tiles and 64-column strips.
+        fold = (os.environ.get("MMSA_FOLD_LN", "1") != "0" and bool(getattr(self, "fold_ln", True)) and D % 64 == 0
+                and (3 * Da) % 128 == 0 and hidden_ % 128 == 0)
+        pk["fold_ln"] = fold
+
+        def folded(w, bias, lnw, lnb, fmt):
+            """(planes of W o lnw, column sums of those planes as the kernel will read them, W lnb + bias)"""
+            pl = planes((w * lnw[None, :]).contiguous(), fmt=fmt)
+            cs = ops.planes_to_float(pl, cols=w.shape[1])[: w.shape[0]].double().sum(1).float().contiguous()
+            return pl, cs, (w.double() @ lnb.double()).float().add_(bias).contiguous()
         for i in range(cfg["depth"]):
             b = f"blocks.{i}."
             qkv_w, qkv_bias = pad_head_rows(sd[b + "attn.qkv.weight"], 3), pad_head_rows(sd[b + "attn.qkv.bias"], 3)
@@ -283,18 +298,25 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # ... and for the kernels with the rel-pos terms fused (head_dim 64) the whole row, the qkv GEMM's whole output and the
                 # rel-pos tables are h8 planes: every contraction of those kernels runs on the fp16 hi parts (v_fmt = 2)
                 qkv_bp16=(ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_H8) if "attnv" in h8_sites else None),
+                # ... and plain bf16 hi/lo planes for a block whose logit range rules fp16 operands out (attention_precision, _attn_mode)
+                qkv_bp_b3=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da),
                 proj=planes(proj_w, fmt=vfmt), proj_b=sd[b + "attn.proj.bias"],
                 lin1=planes(sd[b + "mlp.lin1.weight"], fmt=vfmt), lin1_b=sd[b + "mlp.lin1.bias"],
                 lin2=planes(sd[b + "mlp.lin2.weight"], fmt=vfmt), lin2_b=sd[b + "mlp.lin2.bias"],
                 rph=pad_cols(sd[b + "attn.rel_pos_h"]), rpw=pad_cols(sd[b + "attn.rel_pos_w"]),
-                ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"]))
+                ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"], index=i))
+            if fold:   # the consumers' weights carry their LayerNorm (the unfolded planes are not kept: the fold is all or nothing per model)
+                blk = pk["blocks"][-1]
+                blk["qkv"], blk["qkv_cs"], blk["qkv_bf"] = folded(qkv_w, qkv_bias, blk["n1w"], blk["n1b"], vfmt)
+                blk["lin1"], blk["lin1_cs"], blk["lin1_bf"] = folded(sd[b + "mlp.lin1.weight"], sd[b + "mlp.lin1.bias"], blk["n2w"], blk["n2b"], vfmt)
         for blk in pk["blocks"]:   # windowed blocks with head_dim 64: rel-pos tables packed for the fused window kernel
             wsz = blk["ws"]
             if wsz and wsz <= 14 and hd_ == 64:
                 L = 2 * wsz - 1
                 th = blk["rph"] if blk["rph"].shape[0] == L else _linear_resize_rows(blk["rph"], L)
                 tw = blk["rpw"] if blk["rpw"].shape[0] == L else _linear_resize_rows(blk["rpw"], L)
-                blk["relp"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_H8 if blk["qkv_bp16"] is not None else ops.FMT_B3)
+                blk["relp"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_B3)
+                blk["relp16"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_H8) if blk["qkv_bp16"] is not None else None
         # --- TwinConvNeXt
         def cfmt(w2d):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path):
             # h8 operands for the pointwise convs whose two contraction lengths (C and 4C) are multiples of 64 and that do not run on the fused stage-0 kernel
@@ -445,6 +467,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                       ext=[pack_extractor(b + "extractor.", fold_c=share_c)])
             if i == n_int - 1:
                 it["ext"] += [pack_extractor(b + "extra_extractors.0."), pack_extractor(b + "extra_extractors.1.")]
+            it["inj"]["first_block"] = self.interaction_indexes[i][0]   # whose qkv GEMM reads the stream planes the injector writes (LayerNorm fold)
             pk["inter"].append(it)
         # --- tail: ConvTranspose2d(D,D,2,2) weight [Cin, Cout, 2, 2] -> rows (i,j,co), K = ci  (BK:55,324)
         up = sd["up.weight"]
@@ -492,7 +515,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # global block on a 64-wide grid: rel-pos terms computed inside the attention kernel from the packed tables
                 th = blk["rph"] if blk["rph"].shape[0] == 2 * Hp - 1 else _linear_resize_rows(blk["rph"], 2 * Hp - 1)
                 tw = blk["rpw"] if blk["rpw"].shape[0] == 2 * Wp - 1 else _linear_resize_rows(blk["rpw"], 2 * Wp - 1)
-                relg = ops.global_relpos_planes(th, tw, fmt=ops.FMT_H8 if blk["qkv_bp16"] is not None else ops.FMT_B3)
+                relg = (ops.global_relpos_planes(th, tw, fmt=ops.FMT_B3),
+                        ops.global_relpos_planes(th, tw, fmt=ops.FMT_H8) if blk["qkv_bp16"] is not None else None)
                 g["rel"].append(None)
             else:
                 g["rel"].append((_rel_table(Hp, blk["rph"]), _rel_table(Wp, blk["rpw"])))
@@ -630,9 +654,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # ---- interactions (AM:567-581)
         for i, idx in enumerate(self.interaction_indexes):
             it = pk["inter"][i]
-            self._injector(it["inj"], xs[i], xs[i + 1], cbuf, geo, B, T, Nc)
+            self._injector(it["inj"], xs[i], xs[i + 1], cbuf, geo, B, T, Nc)   # (with the LayerNorm fold: also the producer of block idx[0]'s stream planes)
             for bi in range(idx[0], idx[-1] + 1):
-                self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp, geo["relg"][bi])
+                self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp, geo["relg"][bi],
+                            next_fmt=pk["blocks"][bi + 1]["qkv"].fmt if bi < idx[-1] else None)
             for ex in it["ext"]:
                 self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
             if taps is not None:
@@ -671,44 +696,138 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         return [f1, f2, f3, f4]
 
     # ------------------------------------------------------------------ SAM ViT block (IE:382-423)
-    def _block(self, bp, rel, x, B, Hp, Wp, relg=None):
+    def _stream_planes(self, rows, fmt):
+        """(planes of the residual stream in its next consumer's operand format, its per-row strip sums) -- written by the stream's producer
+        GEMMs when the LayerNorms are folded"""
+        D = self.cfg["embed_dim"]
+        return (self._ws.planes("blk_xp", rows, D, fmt=fmt), self._ws.get("blk_rs", rows, 2 * (D // 64)))
+
+    def _block(self, bp, rel, x, B, Hp, Wp, relg=None, next_fmt=None):
+        """One SAM ViT block in place on x.  `next_fmt` (LayerNorm fold): operand format of the NEXT block's qkv GEMM, whose stream planes
+        this block's lin2 then writes; None = nobody reads them (last block before an extractor)."""
         ws, cfg = self._ws, self.cfg
         D, heads = cfg["embed_dim"], cfg["num_heads"]
         hd = self._hd_pad                 # head width the kernels see (zero-padded to a multiple of 32: _pack)
         scale = self._hd_true ** -0.5     # IE:445: head_dim ** -0.5 of the model's true width
         Da = heads * hd
         T = Hp * Wp
+        fold = self._packed["fold_ln"]    # norm1 / norm2 inside the qkv / lin1 GEMMs; x's planes and row sums come from its producer
         # intermediate activations travel as bf16 hi/lo planes: split once by the producer, consumed by the
         # GEMM / attention kernels with plain 16-byte copies (same bytes as fp32, no re-splitting per column block)
-        vf = bp["qkv"].fmt   # operand format of this block's GEMMs: the producers below write it (qkv's own output format is the attention kernel's choice: below)
-        n = ws.planes("blk_n", B * T, D, fmt=vf)
-        ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
         fused = bp.get("relp") is not None or relg is not None
-        all16 = fused and bp["qkv_bp16"] is not None    # "attnv": the fused kernels run every contraction on fp16 hi parts of h8 planes
+        # fp16 operands inside the attention kernels ("attnv" site) only where this block's logits are small enough: _attn_mode (on the
+        # first forward it may also move this block's qkv GEMM to bf16 hi/lo operands)
+        vf0 = bp["qkv"].fmt
+        f16 = bp["qkv_bp16"] is not None and self._attn_mode(bp, x, B * T, Da, heads, hd, scale) == "f16"
+        vf = bp["qkv"].fmt   # operand format of this block's qkv GEMM: its producer wrote the stream planes / LayerNorm writes them in it
+        if fold:
+            xp, rs = self._stream_planes(B * T, vf)
+            if vf != vf0:    # that first forward only: the planes were written for the old format -- split the stream again
+                ops.split_planes(x, kpad=D, out=xp)
+            mr = ws.get("blk_mr", B * T, 2)
+            ops.rowstats_finalize(rs, B * T, D, 1e-6, mr)
+            n = None
+        else:
+            n = ws.planes("blk_n", B * T, D, fmt=vf)
+            ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
+        all16 = fused and f16            # the fused kernels: every contraction on fp16 hi parts of h8 planes (v_fmt = 2), or none (0)
         qkv = ws.planes("blk_qkv", B * T, 3 * Da, fmt=ops.FMT_H8 if all16 else ops.FMT_B3)
-        bias_p = bp["qkv_bp16"] if all16 else bp["qkv_bp"]
-        if not all16:
-            qkv.split = bias_p.split   # the kernel with a rel-pos prepass: the qkv GEMM writes the v columns as h8 planes (fp16 P V only)
-        ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
+        if all16:
+            bias_p = bp["qkv_bp16"]
+        elif f16 and not fused:          # the kernel with a rel-pos prepass: the qkv GEMM writes the v columns as h8 planes (fp16 P V only, v_fmt = 1)
+            bias_p = bp["qkv_bp"]
+            qkv.split = bias_p.split
+        else:
+            bias_p = bp["qkv_bp_b3"]
+        if fold:
+            ops.gemm(xp, bp["qkv"], bias=bp["qkv_bf"], out_planes=qkv, row_norm=(mr, bp["qkv_cs"]))
+        else:
+            ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
-        ao = ws.planes("blk_ao", B * T, Da, fmt=vf)
+        ao = ws.planes("blk_ao", B * T, Da, fmt=bp["proj"].fmt)
         if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
-            ops.window_attention(qkv, bias_p, bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
+            ops.window_attention(qkv, bias_p, bp["relp16"] if all16 else bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
         elif relg is not None:           # global block on a 64-wide grid: flash kernel with the rel-pos terms fused
-            ops.global_attention(qkv, bias_p, relg, ao, B, Hp, Wp, heads, hd, scale)
+            ops.global_attention(qkv, bias_p, relg[1] if all16 else relg[0], ao, B, Hp, Wp, heads, hd, scale)
         else:
             kk = 2 * wsz if wsz else Hp + Wp
             rp = ws.get("blk_rp", B * heads * T, kk)
             ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
             ops.attention(qkv, bias_p, rp, ao, B, Hp, Wp, heads, hd, wsz, scale)
-        ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
-        ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
+        vf = bp["lin1"].fmt              # the MLP's operand format (the qkv GEMM of a block with large logits runs on bf16 hi/lo: _attn_mode)
         h = ws.planes("blk_h", B * T, bp["lin1"].n, fmt=vf)
+        if fold:
+            xp, rs = self._stream_planes(B * T, vf)
+            ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x, out_planes=xp, rowstats_out=rs)
+            ops.rowstats_finalize(rs, B * T, D, 1e-6, mr)
+            ops.gemm(xp, bp["lin1"], bias=bp["lin1_bf"], act="gelu", out_planes=h, row_norm=(mr, bp["lin1_cs"]))
+            if next_fmt is not None:   # the next block's norm1 is folded too: this GEMM is its producer
+                xp, rs = self._stream_planes(B * T, next_fmt)
+                ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x, out_planes=xp, rowstats_out=rs)
+            else:
+                ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x)
+            return
+        ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
+        n = ws.planes("blk_n", B * T, D, fmt=vf)
+        ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
         ops.gemm(n, bp["lin1"], bias=bp["lin1_b"], act="gelu", out_planes=h)
         ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x)
 
+    # fp16 operands inside the attention kernels are safe only while the logits stay small: the rounding error of q.k grows with the
+    # logit's magnitude and is then exponentiated.  tools/attention_precision_study.py --logit-scale (CPU oracle, ViT-B, f1..f4 against
+    # fp32): max |logit| 3.8 (the seeded test weights) -> 3e-5 for the all-fp16 kernels; 13 -> 1.5e-4; 48 -> 8e-3 (P V alone in fp16:
+    # 3e-3), while bf16 hi/lo operands stay at 3e-6 / 1e-5.  Released SAM checkpoints are peakier than the seeded weights, so the
+    # format is a MEASURED per-block decision, not a constant.
+    ATTN_F16_MAX_LOGIT = 8.0
+
+    def _attn_mode(self, bp, x, rows, Da, heads, hd, scale):
+        """'f16' or 'b3' for this block's attention kernels.  `attention_precision` (or MMSA_ATTN): 'f16' / 'b3' force one; 'auto'
+        (default) decides ONCE per block, on the first forward after packing, from that batch's largest |q.k| * scale (computed here
+        with torch from the block's own input and qkv weights: calibration like the weight packing, not part of later
+        forwards or of a captured graph) and keeps the decision: 'f16' iff it is <= ATTN_F16_MAX_LOGIT."""
+        pol = os.environ.get("MMSA_ATTN") or getattr(self, "attention_precision", "auto")
+        if pol in ("f16", "b3"):
+            return pol
+        mode = bp.get("amode")
+        if mode is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("mmsa: run one eager forward before capturing a graph (per-block attention precision is decided on it)")
+            D_ = self.cfg["embed_dim"]
+            w = ops.planes_to_float(bp["qkv"], cols=D_)[:2 * Da]
+            if self._packed["fold_ln"]:      # packed weight = W o n1w, bias = W n1b + qkv bias: feed the normalised stream without its affine part
+                qk = torch.nn.functional.layer_norm(x[:rows], (D_,), None, None, 1e-6) @ w.t() + bp["qkv_bf"][:2 * Da]
+            else:
+                qk = torch.nn.functional.layer_norm(x[:rows], (D_,), bp["n1w"], bp["n1b"], 1e-6) @ w.t() + bp["qkv_b"][:2 * Da]
+            q = qk[:, :Da].reshape(rows, heads, hd).transpose(0, 1)
+            k = qk[:, Da:].reshape(rows, heads, hd).transpose(0, 1)
+            # an upper bound over ALL token pairs of the batch (windows and images are not told apart: conservative), head by head
+            mx = 0.0
+            for h_ in range(heads):
+                kh = k[h_]
+                for r0 in range(0, rows, 8192):
+                    mx = max(mx, float((q[h_, r0:r0 + 8192] @ kh.t()).abs().max()) * scale)
+            bp["max_logit"] = mx
+            mode = bp["amode"] = "f16" if mx <= self.ATTN_F16_MAX_LOGIT else "b3"
+            if mode == "b3" and bp["qkv"].fmt == ops.FMT_H8:
+                # the projection that makes those logits must not lose them either: q and k with 2^-15.6 products turn a logit of 48
+                # into an error of ~1e-3 before the exponential.  This block's qkv GEMM moves to bf16 hi/lo operands (2^-17), repacked here.
+                sdw = self.state_dict()
+                i = bp["index"]
+                w = sdw[f"blocks.{i}.attn.qkv.weight"].to(x.device, torch.float32)
+                if self._hd_pad != self._hd_true:
+                    v = w.reshape(3, heads, self._hd_true, -1)
+                    wp_ = v.new_zeros(3, heads, hd, v.shape[-1])
+                    wp_[:, :, :self._hd_true] = v
+                    w = wp_.reshape(3 * Da, -1)
+                if self._packed["fold_ln"]:
+                    w = w * bp["n1w"][None, :]
+                bp["qkv"] = ops.split_planes(w.contiguous(), None, fmt=ops.FMT_B3)
+                if self._packed["fold_ln"]:
+                    bp["qkv_cs"] = ops.planes_to_float(bp["qkv"], cols=w.shape[1])[: w.shape[0]].double().sum(1).float().contiguous()
+        return mode
+
     # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)
-    def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None):
+    def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None, stream_out=None):
         ws, cfg = self._ws, self.cfg
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
         dv = ap["val"].n
@@ -718,7 +837,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"])
         samp = ws.planes("msda_s", B * Lq, dv, fmt=ap["out"].fmt)
         ops.msda_fused(val, ss, lsi, raw, ref, None, B, S, M, dv // M, L, Lq, Pn, out_planes=samp)
-        ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale)
+        if stream_out is not None:   # the injector's output projection writes the ViT stream: also its planes and row sums (LayerNorm fold)
+            ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale, out_planes=stream_out[0], rowstats_out=stream_out[1])
+        else:
+            ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale)
 
     def _injector(self, ip, x_in, x_out, c, geo, B, T, Nc):  # AM:525-542
         ws, D = self._ws, self.cfg["embed_dim"]
@@ -730,7 +852,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.layernorm(c, pk["ln_one"], pk["ln_zero"], 1e-6, out_planes=fn)
         else:
             ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
-        self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"])
+        self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"],
+                   stream_out=(self._stream_planes(B * T, self._packed["blocks"][ip["first_block"]]["qkv"].fmt)
+                               if self._packed["fold_ln"] else None))
 
     def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
         ws, D = self._ws, self.cfg["embed_dim"]

@@ -11,13 +11,14 @@
 
 Pinned by tests/test_host_cpu.py against tests/golden/sam_ckpt.npz, which the reference's own loader and converter produced on
 seeded checkpoints (tools/oracle/make_golden.py::gen_sam_ckpt)."""
+import os
 import warnings
 
 import torch
 
 from . import ops
 
-PACK_FORMAT = 5   # 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
+PACK_FORMAT = 6   # 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
 
 
 def unwrap_state_dict(ck):
@@ -118,33 +119,82 @@ def _dec(o, dev):
 
 
 def _fingerprint(sd):
-    """Cheap identity of a state dict: key list + a double checksum (order-independent sums are exact enough to tell weights apart)."""
-    return [list(sd.keys()), float(sum(v.double().abs().sum().item() for v in sd.values() if v.dtype.is_floating_point))]
+    """Identity of a state dict: key list + an ORDER-DEPENDENT double checksum (tensor i weighs i + 1, its elements weigh by position
+    class: permuted tensors or permuted keys change it)."""
+    tot = 0.0
+    for i, (k, v) in enumerate(sd.items()):
+        if not v.dtype.is_floating_point or v.numel() == 0:
+            continue
+        d = v.detach().double().flatten()
+        tot += (i + 1) * (d.abs().sum().item() + 0.5 * d[::2].sum().item() + 0.25 * d[: max(d.numel() // 3, 1)].sum().item())
+    return [list(sd.keys()), tot]
+
+
+def _packed_checksum(enc):
+    """Order-dependent checksum over every tensor of the ENCODED packed tree (the plane buffers as stored): what load_packed
+    verifies before it trusts the planes instead of repacking."""
+    tot, idx = 0.0, [0]
+
+    def walk(o):
+        nonlocal tot
+        if isinstance(o, torch.Tensor):
+            idx[0] += 1
+            d = (o.to(torch.int64) if not o.dtype.is_floating_point else o.double()).flatten()
+            if d.numel():
+                tot += idx[0] * (float(d.double().abs().sum()) + 0.5 * float(d[::2].double().sum()))
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+    walk(enc)
+    return [idx[0], tot]
 
 
 def save_packed(model, path, device="cuda"):
-    """Pack `model`'s current weights on `device` (runs the HIP split kernels once) and write {state_dict, packed, fingerprint}."""
+    """Pack `model`'s current weights on `device` (runs the HIP split kernels once) and write {state_dict, packed, fingerprint, the
+    checksum of the packed planes, the pack-time settings the planes depend on}."""
     dev = torch.device(device)
     with torch.cuda.device(dev):
         pk = model._pack(dev)
         torch.cuda.synchronize(dev)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    torch.save({"format": PACK_FORMAT, "cfg": model.cfg, "state_dict": sd, "packed": _enc(pk), "fingerprint": _fingerprint(sd)}, path)
+    enc = _enc(pk)
+    torch.save({"format": PACK_FORMAT, "cfg": model.cfg, "state_dict": sd, "packed": enc, "fingerprint": _fingerprint(sd),
+                "packed_checksum": _packed_checksum(enc),
+                "settings": {"h8_sites": list(model._h8_sites()), "share_c_norm": bool(pk.get("share_c_norm", True)), "fold_ln": bool(pk.get("fold_ln", False))}}, path)
 
 
 def load_packed(model, path, device="cuda"):
     """Load a file written by save_packed: the plain state dict (strict) AND the packed planes, so the first forward skips _pack.
-    Refuses a file packed for another architecture or whose planes do not belong to the weights it carries."""
+    Refuses a file packed for another architecture, with other pack-time settings (operand-format sites, shared c-norm folding) than
+    the model's current ones, whose state dict or plane buffers fail their checksums, or whose planes are not the split of the weights
+    it carries (spot check: two weight matrices decoded back from their planes)."""
     blob = torch.load(path, map_location="cpu")
     if not isinstance(blob, dict) or blob.get("format") != PACK_FORMAT:
         raise RuntimeError(f"{path}: not an mmsa packed checkpoint (format {PACK_FORMAT})")
     if blob["cfg"] != model.cfg:
         raise RuntimeError(f"{path}: packed for a different architecture")
+    want = {"h8_sites": list(model._h8_sites()),
+            "share_c_norm": os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(model, "share_c_norm", True))}
+    want["fold_ln"] = bool((blob.get("settings") or {}).get("fold_ln")) if os.environ.get("MMSA_FOLD_LN", "1") != "0" and getattr(model, "fold_ln", True) else False
+    if blob.get("settings") != want:
+        raise RuntimeError(f"{path}: packed with settings {blob.get('settings')}, the model runs {want}: repack")
     if blob["fingerprint"] != _fingerprint(blob["state_dict"]):
-        raise RuntimeError(f"{path}: state dict and packed planes do not belong together")
+        raise RuntimeError(f"{path}: the state dict fails its checksum")
+    if blob.get("packed_checksum") != _packed_checksum(blob["packed"]):
+        raise RuntimeError(f"{path}: state dict and packed planes do not belong together (the plane buffers fail their checksum)")
     model.load_state_dict(blob["state_dict"], strict=True)       # invalidates any earlier pack (post hook)
     dev = torch.device(device)
     pk = _dec(blob["packed"], dev)
+    # spot check on the device: planes -> float must give back the weights they claim to be the split of
+    sd = blob["state_dict"]
+    for planes, w in ((pk["pe_w"], sd["patch_embed.proj.weight"].reshape(model.cfg["embed_dim"], -1)),
+                      (pk["blocks"][-1]["lin2"], sd[f"blocks.{model.cfg['depth'] - 1}.mlp.lin2.weight"])):
+        back = ops.planes_to_float(planes, cols=w.shape[1])[: w.shape[0]].cpu()
+        if not torch.allclose(back, w.float(), rtol=2e-3, atol=1e-6):
+            raise RuntimeError(f"{path}: state dict and packed planes do not belong together (planes decode to other weights)")
     pk["geom"] = {}
     pk["dev"] = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
     model._packed = pk

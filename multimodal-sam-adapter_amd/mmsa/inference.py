@@ -1,5 +1,6 @@
 """Inference glue of the reference's EncoderDecoder on device (segmentation/mmseg_custom/models/segmentors/encoder_decoder.py):
-`encode_decode` (ED:85-95), `slide_inference` (ED:191-234), `whole_inference`, and the class map of `simple_test` (ED:449,477).
+`encode_decode` (ED:85-95), `slide_inference` (ED:191-234), `whole_inference`, `whole_inference_dim` (ED:329-362),
+`whole_inference_dim_cut` (ED:364-413), the mode dispatch of `inference` (ED:417-447) and the class map of `simple_test` (ED:449,477).
 
 The crops of a sliding-window frame are batched through ONE backbone + head call (the reference runs them one by one,
 ED:205-214), and the resize / pad / accumulate / count of every crop is one kernel launch on the logits canvas."""
@@ -111,6 +112,28 @@ def _crops(img, chunk, crop_size, out=None):
     return out
 
 
+MAX_OVERLAP = 8   # windows per pixel mmsa_slide_argmax keeps in registers (csrc/segment.hip)
+
+
+def _check_overlap(boxes, what):
+    """The window grid is a product of row intervals and column intervals, so the largest per-pixel overlap is the product of the
+    largest per-row and per-column overlaps: checked on the host BEFORE launching, because the one-pass kernel classifies only pixels
+    covered by 1..MAX_OVERLAP windows (others get class 255 and are counted in its `uncovered` word)."""
+    def deepest(iv):
+        ev = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv], key=lambda t: (t[0], t[1]))   # half-open: close before open
+        cur = best = 0
+        for _, d in ev:
+            cur += d
+            best = max(best, cur)
+        return best
+    rows = sorted({(y1, y2) for y1, _, y2, _ in boxes})
+    cols = sorted({(x1, x2) for _, x1, _, x2 in boxes})
+    ov = deepest(rows) * deepest(cols)
+    if ov > MAX_OVERLAP:
+        raise RuntimeError(f"mmsa.{what}: the window grid covers some pixels {ov} times, the one-pass class-map kernel handles up to {MAX_OVERLAP} "
+                           "(use slide_inference + argmax_map, or a larger stride)")
+
+
 @_on_device
 @torch.no_grad()
 def slide_class_map(backbone, head, img, crop_size, stride, max_batch=8):
@@ -126,6 +149,7 @@ def slide_class_map(backbone, head, img, crop_size, stride, max_batch=8):
     if H < crop_size[0] or W < crop_size[1]:
         raise RuntimeError("mmsa.slide_class_map: the image must be at least as large as the crop")
     boxes = crop_boxes(H, W, crop_size, stride)
+    _check_overlap(boxes, "slide_class_map")
     _pair(backbone, head)
     jobs = [(b, box) for box in boxes for b in range(B)]      # the accumulation order of slide_inference
     if len(jobs) > 64:
@@ -172,6 +196,54 @@ def whole_inference(backbone, head, img):
 
 @_on_device
 @torch.no_grad()
+def whole_inference_dim(backbone, head, img, dim, rescale=True):
+    """ED:329-362 -- `test_cfg.mode = 'whole_dim'`, the test mode of every DELIVER config (dim = (1024, 1024)): the logits at input size
+    (encode_decode), resized once more (bilinear, align_corners=False) to `dim`.  The reference's method has no result for
+    `rescale=False` (it returns None and `inference` fails on it, ED:334-346,448): that call is refused here."""
+    if not rescale:
+        raise RuntimeError("mmsa.whole_inference_dim: rescale=False has no defined result in the reference (encoder_decoder.py:334-346 "
+                           "returns None); use whole_inference or whole_inference_dim_cut")
+    y = encode_decode(backbone, head, img)
+    if tuple(dim) == tuple(y.shape[2:]):
+        return y                      # the second resize is the identity (align_corners=False, same size)
+    out = torch.empty(y.shape[0], y.shape[1], dim[0], dim[1], device=y.device)
+    _resize_into(y, out, 0, 0, dim[0], dim[1])
+    return out
+
+
+@_on_device
+@torch.no_grad()
+def whole_inference_dim_cut(backbone, head, img, dim, cut_dim, rescale=True):
+    """ED:364-413 -- `test_cfg.mode = 'whole_dim_cut'`, the test mode of every FMB config (rescale=False, dim=(600,800), cut_dim=(800,600)):
+    the logits at input size, resized to `dim` when `rescale`, cropped to [:, :, :cut_dim[1], :cut_dim[0]] (a contiguous copy)."""
+    y = encode_decode(backbone, head, img)
+    if rescale and tuple(dim) != tuple(y.shape[2:]):
+        out = torch.empty(y.shape[0], y.shape[1], dim[0], dim[1], device=y.device)
+        _resize_into(y, out, 0, 0, dim[0], dim[1])
+        y = out
+    return y[:, :, :cut_dim[1], :cut_dim[0]].contiguous()
+
+
+@_on_device
+@torch.no_grad()
+def inference(backbone, head, img, test_cfg, rescale=True):
+    """ED:417-447 dispatch on `test_cfg['mode']` -- 'slide', 'whole', 'whole_dim', 'whole_dim_cut' ('slide_mod_sel' runs the segmentor's
+    modality-selection variant, ED:236-308, which needs a backbone with a selection head: not this backbone) -- returning the logits the
+    reference softmaxes (ED:448-470; flips are the caller's, as in the reference's test pipeline)."""
+    mode = test_cfg["mode"]
+    if mode == "slide":
+        return slide_inference(backbone, head, img, tuple(test_cfg["crop_size"]), tuple(test_cfg["stride"]))
+    if mode == "whole":
+        return whole_inference(backbone, head, img)
+    if mode == "whole_dim":
+        return whole_inference_dim(backbone, head, img, tuple(test_cfg["dim"]), rescale)
+    if mode == "whole_dim_cut":
+        return whole_inference_dim_cut(backbone, head, img, tuple(test_cfg["dim"]), tuple(test_cfg["cut_dim"]), rescale)
+    raise RuntimeError(f"mmsa.inference: test_cfg.mode '{mode}' is not one of slide / whole / whole_dim / whole_dim_cut")
+
+
+@_on_device
+@torch.no_grad()
 def argmax_map(seg_logit):
     """ED:449,477: softmax is monotonic, the prediction is the per-pixel argmax over the class axis -> uint8 [B, H, W]."""
     _check(seg_logit)
@@ -197,6 +269,7 @@ class SlideRunner:
         B, _, H, W = self.frame.shape
         self.crop_size = tuple(crop_size)
         boxes = crop_boxes(H, W, crop_size, stride)
+        _check_overlap(boxes, "SlideRunner")
         self.jobs = [(b, box) for box in boxes for b in range(B)]      # the accumulation order of slide_inference
         n = len(self.jobs)
         if n > 64:

@@ -156,9 +156,11 @@ def split_planes(w2d, kpad=None, out=None, fmt=FMT_B3, weight=False):
 
 def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=None, beta=1.0, resid_mod=0,
          batch=1, stride_a=0, stride_w=0, stride_bias=0, stride_r=0, stride_c=0, m=None, pixel_shuffle=None,
-         out_planes=None, stride_cp=0):
+         out_planes=None, stride_cp=0, rowstats_out=None, row_norm=None):
     """out / out_planes = beta*resid + colscale*alpha*act(a @ w^T + bias).
-    a: fp32 2-D view or activation Planes; w: weight Planes; out: fp32 view and/or out_planes: Planes."""
+    a: fp32 2-D view or activation Planes; w: weight Planes; out: fp32 view and/or out_planes: Planes.
+    LayerNorm fold (include/mmsa.h mmsa_gemm_next_extras): `rowstats_out` [M, N/64, 2] fp32 -- also write per-row strip sums of the stored
+    values; `row_norm` = (mean_rstd [M, 2], colsum [N]) -- out_planes = colscale*alpha*act(rstd_r * (a @ w^T - mean_r * colsum) + bias)."""
     fmt = w.fmt
     if isinstance(a, Planes):
         pap, ma, ka, lda = a.mat("A")
@@ -189,6 +191,8 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     if prof is not None:
         e0, e1 = _event(), _event()
         lib.call("mmsa_event_record", e0, _stream())
+    if rowstats_out is not None or row_norm is not None:
+        lib.call("mmsa_gemm_next_extras", _chk(rowstats_out), _chk(row_norm[0]) if row_norm else None, _chk(row_norm[1]) if row_norm else None)
     lib.call("mmsa_gemm_split3", pa, pap, lda, stride_a, w.p.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
@@ -227,6 +231,12 @@ def convnext_mlp_fused(a, w1, w2, b1, b2, gamma, x, m, batch=1, stride_a=0, stri
 
 def convnext_mlp_fused_supported(c):
     return c == 96
+
+
+def rowstats_finalize(rowstats, rows, d, eps, out):
+    """Strip sums of a GEMM's `rowstats_out` -> (mean, rstd) per row, [rows, 2] fp32 (LayerNorm statistics over d = 64 * strips columns)."""
+    lib.call("mmsa_rowstats_finalize", _chk(rowstats), rows, d // 64, d, eps, _chk(out), _stream())
+    return out
 
 
 def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None, group_rows=0, w_gstride=0, y_gcol=0, y_wrap=False):

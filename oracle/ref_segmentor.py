@@ -1,9 +1,11 @@
 """CPU restatement of the reference segmentor's inference glue -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 Follows segmentation/mmseg_custom/models/segmentors/encoder_decoder.py: `encode_decode` (:85-95), `slide_inference` (:191-234,
-without the optional rescale to `ori_shape`) and the argmax of `simple_test` (:449,477).  Pinned by tests/golden/slide.npz, which
+without the optional rescale to `ori_shape`), `whole_inference_dim` (:329-362), `whole_inference_dim_cut` (:364-413) and the argmax of
+`simple_test` (:449,477).  Pinned by tests/golden/slide.npz, which
 tools/oracle/make_golden.py produces by calling the reference's own, unmodified `EncoderDecoder.slide_inference` with a stand-in
-`self` whose `encode_decode` is a fixed seeded function (the window grid / pad / count / average logic is what is pinned)."""
+`self` whose `encode_decode` is a fixed seeded function (the window grid / pad / count / average logic is what is pinned), and by
+tests/golden/whole_dim.npz (the reference's own `whole_inference_dim` / `whole_inference_dim_cut`, same harness)."""
 import torch
 import torch.nn.functional as F
 
@@ -31,3 +33,20 @@ def slide_inference(encode_decode_fn, img, crop_size, stride, num_classes):
             count[:, :, y1:y2, x1:x2] += 1
     assert (count == 0).sum() == 0
     return preds / count
+
+
+def whole_inference_dim(encode_decode_fn, img, dim, rescale=True, align_corners=False):
+    """ED:329-362 behind this backbone (its second return value makes `encode_decode_test` return a tuple, ED:96-107): the logits at
+    input size, resized to `dim` when `rescale`.  Without `rescale` the reference's method returns None (it falls off its end,
+    ED:334-346): there is no result to restate, and the caller (`inference`, ED:448) fails on it."""
+    if not rescale:
+        return None
+    return F.interpolate(encode_decode_fn(img), size=dim, mode="bilinear", align_corners=align_corners)
+
+
+def whole_inference_dim_cut(encode_decode_fn, img, dim, cut_dim, rescale=True, align_corners=False):
+    """ED:364-413: as above, then the crop [:, :, :cut_dim[1], :cut_dim[0]]; without `rescale` the logits at input size are cropped."""
+    y = encode_decode_fn(img)
+    if rescale:
+        y = F.interpolate(y, size=dim, mode="bilinear", align_corners=align_corners)
+    return y[:, :, :cut_dim[1], :cut_dim[0]]

@@ -26,6 +26,11 @@ _VITB = dict(_VITL, img_size=512, embed_dim=768, depth=12, num_heads=12, deform_
 _VITH = dict(_VITL, embed_dim=1280, depth=32, num_heads=16, deform_num_heads=16,
              interaction_indexes=[[0, 7], [8, 15], [16, 23], [24, 31]], global_attn_indexes=[7, 15, 23, 31])
 
+# FMB family (configs/FMB/Segformer_MMSAM_adapter_large_FMB_800x800_ss_RGBTHERM.py:14,26-49): the ...NEWwithcp class at img_size 800 --
+# a 50 x 50 token grid: window padding 50 -> 56, pos-embed bicubic 64 -> 50, global rel-pos tables 127 -> 99 rows by linear
+# interpolation, GFFM LayerNorm length 200^2; at ViT-L head_dim 64 the global blocks take the attention kernel with a rel-pos prepass
+_VITL800 = dict(_VITL, img_size=800, conv_drop_path_rate=0.4)
+
 CONFIGS = {
     "tiny224": dict(kwargs=dict(_TINY, img_size=224), batch=1, seed=1, in_seed=5),
     "tiny256": dict(kwargs=dict(_TINY, img_size=256), batch=1, seed=2, in_seed=6),
@@ -33,6 +38,7 @@ CONFIGS = {
     "vitb512": dict(kwargs=_VITB, batch=1, seed=4, in_seed=8),
     "vitl1024": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9),
     "vith1024": dict(kwargs=_VITH, batch=1, seed=17, in_seed=18),
+    "vitl800": dict(kwargs=_VITL800, batch=1, seed=19, in_seed=20, type="SAMAdapterbimodalMixModNewInTwinConvNEWwithcp"),
 }
 
 

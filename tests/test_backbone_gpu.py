@@ -268,3 +268,100 @@ def test_packed_checkpoint_round_trip(tmp_path):
     other = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **CONFIGS["tiny224"]["kwargs"]))
     with pytest.raises(RuntimeError, match="different architecture"):
         C.load_packed(other, path, device=DEV)
+
+
+def _build_cfg(name):
+    import mmsa
+    cfg = CONFIGS[name]
+    m = mmsa.build_backbone(dict(type=cfg.get("type", "SAMAdapterbimodalMixModNewInTwinConvNEW"), **cfg["kwargs"]))
+    m.load_state_dict(seeded_state_dict(m, seed=cfg["seed"]), strict=True)
+    return cfg, m
+
+
+def test_vitl800_probes(golden_dir):
+    """The FMB config family (configs/FMB/..._800x800_ss_RGBTHERM.py:14,26-49): the ...NEWwithcp class at img_size 800 -- a 50 x 50 token
+    grid (window padding 50 -> 56, pos-embed bicubic 64 -> 50, global rel-pos tables 127 -> 99 rows by interpolation, GFFM LayerNorm over
+    200^2 pixels) whose global blocks take the attention kernel with a rel-pos prepass at head_dim 64 -- against probes of the imported
+    reference's own ...NEWwithcp class (tools/oracle/make_golden.py --only model:vitl800)."""
+    import mmsa
+    cfg, m = _build_cfg("vitl800")
+    assert type(m) is mmsa.BACKBONES.get("SAMAdapterbimodalMixModNewInTwinConvNEWwithcp")
+    g = np.load(os.path.join(golden_dir, "model_vitl800.npz"))
+    fs, _ = m(make_input(cfg).to(DEV))
+    assert [tuple(f.shape) for f in fs] == [(1, 1024, 200, 200), (1, 1024, 100, 100), (1, 1024, 50, 50), (1, 1024, 25, 25)]
+    for i, f in enumerate(fs):
+        pi = probe_index(f.numel(), 2048, seed=100 + i)
+        assert_close(f.flatten()[pi.to(DEV)].cpu(), torch.from_numpy(g[f"f{i+1}_probe"]), what=f"vitl800 f{i+1} probes")
+        st = g[f"f{i+1}_stats"]
+        assert abs(f.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-3 * st[3]
+
+
+# rel-L2 of every tap against the float64 oracle, as measured on MI355X in round 3 (profiles/r03_error_budget.txt, default operand
+# formats).  What the table says (DESIGN.md section 2): the TwinConvNeXt outputs carry 4e-6..1e-5 (bf16 hi/lo products through 36
+# blocks; the fp32 reference: 1.5e-7..5e-7), and GFFM's softmax over un-normalised energies (AM:242-267) amplifies it ~15-20 x at the
+# three small levels (fuse1..3: 0.8..1.4e-4; the fp32 reference amplifies its own noise the same way: 0.5..1.1e-5) -- that, not the
+# operand format of the ViT / interaction GEMMs, owns the 2e-4 of the outputs (identical with bf16 hi/lo everywhere).
+ERROR_BUDGET_VITL = {
+    "twin0": 3.9e-6, "twin1": 6.0e-6, "twin2": 8.4e-6, "twin3": 9.6e-6, "fuse0": 5.6e-6, "fuse1": 1.4e-4, "fuse2": 8.5e-5, "fuse3": 8.2e-5,
+    "c1_map": 6.9e-6, "c_in": 1.3e-4, "x_in": 4.0e-6, "x0": 4.6e-5, "c0": 1.7e-4, "x1": 5.8e-5, "c1": 1.9e-4, "x2": 6.3e-5, "c2": 2.0e-4,
+    "x3": 6.4e-5, "c3": 2.4e-4, "f1": 1.1e-4, "f2": 1.9e-4, "f3": 8.8e-5, "f4": 1.0e-4,
+}
+
+
+def test_vitl1024_error_budget(golden_dir):
+    """Per-stage attribution at ViT-L 1024^2: every intermediate the oracle taps, against the FLOAT64 oracle
+    (tests/golden/model_vitl1024_f64.npz, tools/oracle/make_f64.py), must stay within twice its recorded error.  A regression in one
+    stage shows up at that stage, not as a slow drift of the end-to-end probes towards the 1e-3 gate."""
+    from tools.error_budget import tap_errors
+    cfg, m = _build_cfg("vitl1024")
+    _, taps = m.forward_taps(make_input(cfg).to(DEV))
+    g = np.load(os.path.join(golden_dir, "model_vitl1024_f64.npz"))
+    errs = tap_errors(taps, g)
+    assert set(ERROR_BUDGET_VITL) <= set(errs), sorted(set(ERROR_BUDGET_VITL) - set(errs))
+    bad = {k: (errs[k][0], b) for k, b in ERROR_BUDGET_VITL.items() if not errs[k][0] <= 2.0 * b}
+    assert not bad, f"taps over twice their recorded budget (got rel-L2, recorded): {bad}"
+    for i in range(4):   # and the gate itself, against float64
+        assert errs[f"f{i + 1}"][0] <= 1e-3 and errs[f"f{i + 1}"][1] <= 1e-3
+
+
+def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_dir):
+    """fp16 operands inside the attention kernels only where the block's logits are small (backbone._attn_mode): with the
+    seeded weights (max |logit| ~ 4) 'auto' picks fp16 in every block and equals the forced 'f16' run bit for bit; with the q / k rows of
+    every qkv projection scaled so that the logits are 16 x larger, 'auto' falls back to bf16 hi/lo operands and stays within the gate
+    against the oracle on the SAME scaled weights, where the forced fp16 kernels do not."""
+    import mmsa
+    cfg, orc, m = _build("vitb512")
+    x = make_input(cfg)
+    g = np.load(os.path.join(golden_dir, "model_vitb512.npz"))
+    outs = {}
+    for pol in ("auto", "f16", "b3"):
+        m.attention_precision = pol
+        fs, _ = m(x.to(DEV))
+        outs[pol] = [f.clone() for f in fs]
+        for i, f in enumerate(fs):
+            pi = probe_index(f.numel(), 2048, seed=100 + i)
+            assert_close(f.flatten()[pi.to(DEV)].cpu(), torch.from_numpy(g[f"f{i+1}_probe"]), what=f"vitb512 {pol} f{i+1} probes")
+    blocks = m._packed["blocks"]
+    assert all(b["amode"] == "f16" and b["max_logit"] < 8.0 for b in blocks), [(b.get("amode"), b.get("max_logit")) for b in blocks]
+    assert all(torch.equal(a, b) for a, b in zip(outs["auto"], outs["f16"]))
+    assert not all(torch.equal(a, b) for a, b in zip(outs["b3"], outs["f16"]))
+    # peaky attention: logits x 16
+    sd = seeded_state_dict(orc, seed=cfg["seed"])
+    D = cfg["kwargs"]["embed_dim"]
+    for k in sd:
+        if k.endswith("attn.qkv.weight") or k.endswith("attn.qkv.bias"):
+            sd[k] = sd[k].clone()
+            sd[k][:2 * D] *= 4.0
+    orc.load_state_dict(sd)
+    ref, _ = orc(x)
+    m2 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m2.load_state_dict(sd)
+    fs, _ = m2(x.to(DEV))
+    modes = [b["amode"] for b in m2._packed["blocks"]]
+    assert modes.count("b3") >= len(modes) // 2, (modes, [round(b["max_logit"], 1) for b in m2._packed["blocks"]])
+    worst_auto = max(rel_l2(f, r) for f, r in zip(fs, ref))
+    m2.attention_precision = "f16"
+    fs16, _ = m2(x.to(DEV))
+    worst_f16 = max(rel_l2(f, r) for f, r in zip(fs16, ref))
+    assert worst_auto <= 1e-3, f"auto precision at 16 x logits: {worst_auto:.2e}"
+    assert worst_f16 > 2.0 * worst_auto, f"forced fp16 {worst_f16:.2e} vs auto {worst_auto:.2e}: the fallback should matter here"

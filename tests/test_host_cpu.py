@@ -155,6 +155,42 @@ def test_data_parallel_harness_gloo_world2():
     assert s0 == s1 == 1.5
 
 
+def _run_bench_stub(extra_env, args=("--gpus", "2", "--steps", "3", "--warmup", "1"), timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MMSA_BENCH_STUB="1", MMSA_BENCH_TIMEOUT="120", **extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_rank_body_gloo_world2():
+    """bench.py's own N > 1 control path end to end without a GPU (MMSA_BENCH_STUB=1: gloo, the device step replaced by a stand-in
+    that takes 10 (rank + 1) ms): `--gpus 2` spawns its two ranks, they rendezvous, time exactly K steps between barriers, all-gather
+    the per-rank logits every step, take the MAX over ranks, and rank 0 prints the one JSON line -- checked field by field."""
+    import json
+    r = _run_bench_stub({})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["unit"] == "images/s"
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
+    # the slower rank (20 ms per step) sets the time: max over ranks, not rank 0's own 10 ms
+    assert 20.0 <= line["ms_per_step"] < 200.0
+    assert abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+    assert line["roofline"] is None and line["cpu_baseline"] is None and line["verified"] is None
+
+
+def test_bench_parent_stops_the_job_when_a_rank_dies():
+    """A rank that exits at start-up must not leave the parent waiting for rank 0's rendezvous timeout."""
+    import time
+    t0 = time.time()
+    r = _run_bench_stub({"MMSA_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert time.time() - t0 < 100, "the parent waited for the surviving rank's rendezvous timeout"
+    assert "stopping" in r.stderr
+
+
 def test_head_registry_and_state_dict_contract(golden_dir):
     """SegformerHead drop-in: registry name, reference state_dict keys/shapes/order, loud failure without a GPU."""
     import mmsa

@@ -224,3 +224,30 @@ def test_slide_runner_equals_slide_inference(models):
         # same bits for another batch size -- tests/test_backbone_gpu.py; at ViT-L sizes there is one kernel per shape)
         want = inf.argmax_map(inf.slide_inference(m, h, frame, (256, 256), (160, 160), max_batch=len(boxes) // 2))
         assert int(unc.item()) == 0 and torch.equal(cm, want)
+
+
+def test_whole_dim_modes(models):
+    """`test_cfg.mode` 'whole_dim' (DELIVER configs) and 'whole_dim_cut' (FMB configs) on device against the oracle restatement of
+    ED:329-413 (pinned to the reference's own methods: tests/golden/whole_dim.npz), plus the mode dispatch of ED:417-447."""
+    import mmsa.inference as inf
+    cfg, orc, horc, m, h = models
+    x = make_input(cfg, batch=2, seed=17)
+    ed = lambda im: RS.encode_decode(orc, horc, im)
+    xd = x.to(DEV)
+    same = inf.whole_inference_dim(m, h, xd, (256, 256))
+    assert_close(same, RS.whole_inference_dim(ed, x, (256, 256)), what="whole_dim at the input size")
+    assert torch.equal(same, inf.encode_decode(m, h, xd))
+    assert_close(inf.whole_inference_dim(m, h, xd, (192, 240)), RS.whole_inference_dim(ed, x, (192, 240)), what="whole_dim to another size")
+    got = inf.whole_inference_dim_cut(m, h, xd, (192, 256), (256, 192), rescale=False)     # the FMB form: crop only
+    assert got.shape == (2, 7, 192, 256) and got.is_contiguous()
+    assert_close(got, RS.whole_inference_dim_cut(ed, x, (192, 256), (256, 192), rescale=False), what="whole_dim_cut, no rescale")
+    assert_close(inf.whole_inference_dim_cut(m, h, xd, (200, 300), (260, 150), rescale=True),
+                 RS.whole_inference_dim_cut(ed, x, (200, 300), (260, 150), rescale=True), what="whole_dim_cut, rescale")
+    with pytest.raises(RuntimeError, match="no defined result"):
+        inf.whole_inference_dim(m, h, xd, (256, 256), rescale=False)
+    # dispatch
+    assert torch.equal(inf.inference(m, h, xd, dict(mode="whole_dim", dim=(256, 256))), same)
+    assert torch.equal(inf.inference(m, h, xd, dict(mode="whole_dim_cut", dim=(192, 256), cut_dim=(256, 192)), rescale=False), got)
+    assert torch.equal(inf.inference(m, h, xd, dict(mode="whole")), same)
+    with pytest.raises(RuntimeError, match="not one of"):
+        inf.inference(m, h, xd, dict(mode="slide_mod_sel"))

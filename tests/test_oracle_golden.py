@@ -139,3 +139,22 @@ def test_oracle_slide_inference_matches_reference_method(golden_dir):
         img = torch.randn(2, 6, h, w, generator=torch.Generator().manual_seed(31))
         y = RS.slide_inference(toy_encode_decode(5, seed=77), img, (ch, cw), (sh, sw), 5)
         assert torch.equal(y, torch.from_numpy(gold[f"{tag}_out"])) or (y - torch.from_numpy(gold[f"{tag}_out"])).abs().max() < 1e-6
+
+
+def test_oracle_whole_dim_modes_match_reference_methods(golden_dir):
+    """oracle/ref_segmentor.whole_inference_dim / whole_inference_dim_cut vs the reference's own EncoderDecoder methods (golden
+    whole_dim.npz: 'whole_dim' at and off the input size, 'whole_dim_cut' without rescale -- the FMB configs -- and with)."""
+    import numpy as np
+    import torch
+    from oracle import ref_segmentor as RS
+    from tests.configs import toy_encode_decode
+    gold = np.load(os.path.join(golden_dir, "whole_dim.npz"))
+    for tag in "abcd":
+        h, w, d0, d1, c0, c1, rescale = [int(v) for v in gold[f"{tag}_cfg"]]
+        g = torch.Generator().manual_seed(33)
+        img = torch.randn(2, 6, h, w, generator=g)
+        fn = toy_encode_decode(5, seed=78)
+        y = RS.whole_inference_dim(fn, img, (d0, d1), bool(rescale)) if c0 == 0 else RS.whole_inference_dim_cut(fn, img, (d0, d1), (c0, c1), bool(rescale))
+        want = torch.from_numpy(gold[f"{tag}_out"])
+        assert y.shape == want.shape and torch.allclose(y, want, rtol=0, atol=1e-6), tag
+    assert RS.whole_inference_dim(toy_encode_decode(5, seed=78), torch.zeros(1, 6, 64, 64), (64, 64), rescale=False) is None

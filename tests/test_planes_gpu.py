@@ -548,3 +548,51 @@ def test_layernorm_h8_planes(ops, rows, C):
     ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out=yk)
     p2 = ops.split_planes(yk, fmt=ops.FMT_H8)
     assert torch.equal(p.p[:, :2 * ops.pad32(C)].cpu().view(torch.uint8).view(rows, -1, 128)[:, :C // 32], p2.p.cpu().view(torch.uint8).view(rows, -1, 128)[:, :C // 32])
+
+
+@pytest.mark.parametrize("fmt_name,act", [("b3", "none"), ("h8", "gelu")])
+def test_gemm_layernorm_fold(ops, fmt_name, act):
+    """LayerNorm folded into a producer / consumer pair of GEMMs (IE:396-421; include/mmsa.h mmsa_gemm_next_extras): the producer writes
+    x = resid + a W0^T + b0 as fp32 AND as planes AND its per-row strip sums; mmsa_rowstats_finalize turns them into (mean, rstd); the
+    consumer runs on the raw planes against W o w and normalises in its epilogue -- against LayerNorm + Linear in float64, with a stream
+    whose mean is not small against its spread."""
+    fmt = ops.FMT_H8 if fmt_name == "h8" else ops.FMT_B3
+    h8 = fmt == ops.FMT_H8
+    M, D, K0, N = 1024, 512, 256, 384
+    a0 = torch.randn(M, K0, generator=g(201))
+    w0 = torch.randn(D, K0, generator=g(202)) / K0 ** 0.5
+    b0 = torch.randn(D, generator=g(203)) * 0.1
+    res = torch.randn(M, D, generator=g(204)) + 1.5          # |mean| ~ 1.5 std
+    lnw, lnb = 1.0 + 0.1 * torch.randn(D, generator=g(205)), 0.05 * torch.randn(D, generator=g(206))
+    w = torch.randn(N, D, generator=g(207)) / D ** 0.5
+    b = torch.randn(N, generator=g(208)) * 0.1
+    x64 = res.double() + a0.double() @ w0.double().t() + b0.double()
+    ref = F.layer_norm(x64, (D,), lnw.double(), lnb.double(), 1e-6) @ w.double().t() + b.double()
+    if act == "gelu":
+        ref = F.gelu(ref)
+    ap = ops.split_planes(a0.to(DEV), kpad=K0, fmt=fmt)
+    w0p = ops.split_planes(w0.to(DEV), fmt=fmt, weight=h8)
+    x = res.to(DEV).clone()
+    xp = ops.alloc_planes(M, D, DEV, fmt=fmt)
+    rs = torch.full((M, 2 * (D // 64)), float("nan"), device=DEV)
+    ops.gemm(ap, w0p, x, bias=b0.to(DEV), resid=x, out_planes=xp, rowstats_out=rs)
+    assert_close(x, x64.float(), tol=3e-5, what="producer fp32 output")
+    assert_close(planes_to_float(xp), x64.float(), tol=6e-5, what="producer planes output")
+    want = torch.stack([x.double().view(M, D // 64, 64).sum(-1), (x.double() ** 2).view(M, D // 64, 64).sum(-1)], -1).view(M, -1)
+    assert_close(rs, want.float(), tol=1e-6, what="row strip sums")
+    mr = torch.empty(M, 2, device=DEV)
+    ops.rowstats_finalize(rs, M, D, 1e-6, mr)
+    assert_close(mr[:, 0], x.double().mean(1).float(), tol=1e-6, what="row mean")
+    assert_close(mr[:, 1], (x.double().var(1, unbiased=False) + 1e-6).rsqrt().float(), tol=2e-6, what="row rstd")
+    wp = ops.split_planes((w * lnw[None, :]).to(DEV).contiguous(), fmt=fmt, weight=h8)
+    cs = planes_to_float(wp)[:N, :D].double().sum(1).float().contiguous()
+    bf = (w.double() @ lnb.double()).float().add(b).to(DEV).contiguous()
+    out = ops.alloc_planes(M, N, DEV, fmt=fmt)
+    ops.gemm(xp, wp, bias=bf, act=act, out_planes=out, row_norm=(mr, cs))
+    assert_close(planes_to_float(out), ref.float(), tol=1e-4 if h8 else 4e-5, what=f"folded LayerNorm + Linear ({fmt_name})")
+    # the extras are one-shot: the same call without them is a plain GEMM again
+    out2 = ops.alloc_planes(M, N, DEV, fmt=fmt)
+    ops.gemm(xp, wp, bias=bf, act=act, out_planes=out2)
+    assert not torch.equal(out2.p, out.p)
+    with pytest.raises(RuntimeError, match="row statistics"):
+        ops.gemm(ap, w0p, x, bias=b0.to(DEV), act="gelu", rowstats_out=rs)

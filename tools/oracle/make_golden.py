@@ -111,7 +111,7 @@ def gen_bookkeeping():
 
 def gen_model(name, full):
     cfg = CONFIGS[name]
-    ref = ref_import.build_reference(**cfg["kwargs"])
+    ref = ref_import.build_reference(_withcp=cfg.get("type", "").endswith("withcp"), **cfg["kwargs"])
     keys = list(ref.state_dict().keys())
     shapes = [list(v.shape) for v in ref.state_dict().values()]
     sd = seeded_state_dict(ref, seed=cfg["seed"])
@@ -177,6 +177,30 @@ def gen_slide():
         out[f"{tag}_out"] = y.numpy()
     np.savez_compressed(os.path.join(OUT, "slide.npz"), **out)
     print("slide", {k: v.shape for k, v in out.items() if k.endswith("_out")}, flush=True)
+
+
+def gen_whole_dim():
+    """The reference's own EncoderDecoder.whole_inference_dim / whole_inference_dim_cut (the test modes of the DELIVER and FMB configs:
+    test_cfg mode='whole_dim' dim=(1024,1024); mode='whole_dim_cut' dim=(600,800) cut_dim=(800,600)) on a seeded image with the fixed toy
+    encode_decode of gen_slide (tests/golden/whole_dim.npz)."""
+    from tests.configs import toy_encode_decode
+    out = {}
+    cases = dict(a=((64, 64), (64, 64), None, True),          # 'whole_dim', dim == input size (DELIVER)
+                 b=((64, 80), (48, 60), None, True),          # 'whole_dim' to another size
+                 c=((80, 80), (60, 80), (80, 60), False),     # 'whole_dim_cut' as the FMB configs run it: no rescale, crop to [.., :60, :80]
+                 d=((80, 80), (60, 80), (70, 50), True))      # 'whole_dim_cut' with rescale
+    for tag, (hw, dim, cut, rescale) in cases.items():
+        g = torch.Generator().manual_seed(33)
+        img = torch.randn(2, 6, hw[0], hw[1], generator=g)
+        fn = toy_encode_decode(5, seed=78)
+        y = ref_import.reference_whole_dim(fn, img, dim, cut, rescale)
+        assert isinstance(y, tuple) and y[1] == (None,)
+        out[f"{tag}_cfg"] = np.array(list(hw) + list(dim) + (list(cut) if cut else [0, 0]) + [int(rescale)])
+        out[f"{tag}_out"] = y[0].numpy()
+    # rescale=False in 'whole_dim' mode: the reference's method falls off its end (ED:334-346) and returns None
+    assert ref_import.reference_whole_dim(toy_encode_decode(5, seed=78), torch.zeros(1, 6, 64, 64), (64, 64), None, False) is None
+    np.savez_compressed(os.path.join(OUT, "whole_dim.npz"), **out)
+    print("whole_dim", {k: v.shape for k, v in out.items() if k.endswith("_out")}, flush=True)
 
 
 def gen_ckpt():
@@ -282,6 +306,7 @@ def main():
     for n in ("tiny224", "tiny256", "tiny320"):
         gen_model(n, full=True)
     gen_slide()
+    gen_whole_dim()
     gen_ckpt()
     gen_head("head_vitl", full=False)
     gen_head("head_odd", full=True)

@@ -92,8 +92,8 @@ def _mk(name, **attrs):
 _installed = False
 
 
-def install():
-    """Install stubs and return the reference backbone class."""
+def install(withcp=False):
+    """Install stubs and return the reference backbone class (`withcp`: ...NEWwithcp, image_encoder_adapter_..._new_with_cp.py:28)."""
     global _installed
     import torch
     import torch.nn as nn
@@ -186,6 +186,11 @@ def install():
         def apply(value, shapes, lsi, loc, w, step):
             return ms_deform_attn_core_pytorch(value, shapes, loc, w)
     msda_mod.MSDeformAttnFunction = _Shim
+    if withcp:   # the second registered name (backbones/__init__.py:3-9): the FMB configs' class, its own module and adapter-modules file
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod = importlib.import_module(
+                "mmseg_custom.models.backbones.image_encoder_adapter_bimodal_mix_mod_new_in_twin_convnext_new_with_cp")
+        return mod.SAMAdapterbimodalMixModNewInTwinConvNEWwithcp
     return mod.SAMAdapterbimodalMixModNewInTwinConvNEW
 
 
@@ -209,7 +214,8 @@ def build_reference(**cfg):
     import contextlib
     import io
     import torch
-    cls = install()
+    cfg = dict(cfg)
+    cls = install(withcp=bool(cfg.pop("_withcp", False)))
     tmp = os.path.join(tempfile.gettempdir(), "mmsa_dummy_convnext.pth")
     if not os.path.exists(tmp):
         torch.save({"state_dict": {"dummy.key": torch.zeros(1)}}, tmp)
@@ -297,3 +303,31 @@ def reference_slide_inference(encode_decode_fn, img, crop_size, stride, num_clas
     fake = types.SimpleNamespace(test_cfg=types.SimpleNamespace(stride=stride, crop_size=crop_size), num_classes=num_classes,
                                  align_corners=False, encode_decode=lambda im, meta: encode_decode_fn(im))
     return mod.EncoderDecoder.slide_inference(fake, img, [dict(ori_shape=tuple(img.shape[2:]) + (3,))], False)
+
+
+def reference_whole_dim(encode_decode_fn, img, dim, cut_dim=None, rescale=True):
+    """Run the reference's own `EncoderDecoder.whole_inference_dim` (segmentors/encoder_decoder.py:329-362) or, with `cut_dim`,
+    `whole_inference_dim_cut` (:364-413), UNMODIFIED, with a stand-in `self` whose `encode_decode_test` returns what the reference's
+    does behind this backbone: the logits at input size plus the backbone's second return value `(None,)` (:96-107, BK:349)."""
+    import torch.nn as nn
+    install()
+    if "mmseg_custom.models.segmentors" not in sys.modules:
+        m = types.ModuleType("mmseg_custom.models.segmentors")
+        m.__path__ = [os.path.join(SEG, "mmseg_custom/models/segmentors")]
+        sys.modules["mmseg_custom.models.segmentors"] = m
+    import mmseg.models.segmentors.base as sb
+    import mmseg.ops as mo
+    import torch.nn.functional as F
+
+    class BaseSegmentor(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+    sb.BaseSegmentor = BaseSegmentor
+    mo.resize = lambda input, size=None, scale_factor=None, mode="nearest", align_corners=None, warning=True: F.interpolate(input, size, scale_factor, mode, align_corners)
+    mod = importlib.import_module("mmseg_custom.models.segmentors.encoder_decoder")
+    mod.resize = mo.resize
+    fake = types.SimpleNamespace(align_corners=False, encode_decode_test=lambda im, meta: (encode_decode_fn(im), (None,)))
+    meta = [dict(ori_shape=tuple(img.shape[2:]) + (3,))]
+    if cut_dim is None:
+        return mod.EncoderDecoder.whole_inference_dim(fake, img, meta, rescale, dim)
+    return mod.EncoderDecoder.whole_inference_dim_cut(fake, img, meta, rescale, dim, cut_dim)

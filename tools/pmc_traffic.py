@@ -27,3 +27,36 @@ res = {"kernel_family": gem, "launches_counted": launches,
        "per_kernel": {c: {k: v for k, v in out[c].items()} for c in out}}
 json.dump(res, open(f"profiles/{tag}_gemm_traffic.json", "w"), indent=1)
 print(json.dumps({k: res[k] for k in res if k != "per_kernel"}, indent=1))
+
+
+# ---- HBM-bound kernels: corrected bytes per launch / average duration of the SAME (counter) passes, against 8 TB/s
+def durations(c):
+    d, n = collections.defaultdict(float), collections.Counter()
+    for f in glob.glob(f"gpurun_out/pmc_{tag}_{c}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            d[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); n[k] += 1
+    return {k: d[k] / n[k] for k in d}   # ns per launch
+
+
+PEAK = 8000.0
+dur_f, dur_w = durations("FETCH_SIZE"), durations("WRITE_SIZE")
+want = ("layernorm_rows", "tail_fuse", "msda", "dwconv7", "dwconv_nhwc", "dwpair", "lnhw_apply", "ca_apply", "head_fuse", "colstats", "gconv_tiled",
+        "split_planes", "nchw_to_planes", "im2col", "pool_hw", "gelu_gate", "gram_tn", "wattn", "attn_kernel", "fillBuffer", "copyBuffer")
+hb = {}
+for k in sorted(out["FETCH_SIZE"]):
+    if not any(w in k for w in want) or k not in out["WRITE_SIZE"]:
+        continue
+    fl, wl_ = out["FETCH_SIZE"][k]["launches"], out["WRITE_SIZE"][k]["launches"]
+    rd = 2 * out["FETCH_SIZE"][k]["sum_kb"] * 1024 / max(fl, 1)
+    wr = out["WRITE_SIZE"][k]["sum_kb"] * 1024 / max(wl_, 1)
+    ns = 0.5 * (dur_f.get(k, 0.0) + dur_w.get(k, 0.0)) if (k in dur_f and k in dur_w) else dur_f.get(k, dur_w.get(k, 0.0))
+    if ns <= 0:
+        continue
+    gbps = (rd + wr) / ns
+    hb[k] = {"launches_per_pass": fl, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "us_per_launch": round(ns / 1e3, 2),
+             "GBps": round(gbps, 1), "frac": round(gbps / PEAK, 4), "ms_per_pass": round(ns * fl / 1e6, 3)}
+json.dump({"peak_GBps": PEAK, "note": "per kernel: (2 x FETCH_SIZE + WRITE_SIZE) per launch / average launch duration of the same rocprofv3 passes "
+           "(eager launches of one bench step, no HIP graph; FETCH doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted as traffic); frac = GB/s / 8000",
+           "kernels": hb}, open(f"profiles/{tag}_hbm_kernels.json", "w"), indent=1)
+print("hbm kernels:", {k[:40]: (v["GBps"], v["us_per_launch"]) for k, v in sorted(hb.items(), key=lambda t: -t[1]["ms_per_pass"])[:12]})
