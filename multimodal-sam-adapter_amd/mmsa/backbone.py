@@ -225,6 +225,38 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
 
     # ------------------------------------------------------------------ packing (one-time weight preprocessing)
     @torch.no_grad()
+    def _block_gemm_planes(self, sd, i, fmt, fold, dev):
+        """The four GEMM weights of ViT block i as operand planes of format `fmt` (+ the LayerNorm-folded forms of qkv / lin1 when
+        `fold`): head widths that are not a multiple of 32 zero-padded per head (ViT-H), see _pack."""
+        heads_, hd_true, hd_ = self.cfg["num_heads"], self._hd_true, self._hd_pad
+
+        def pad_head_rows(w, groups):
+            if hd_ == hd_true:
+                return w.contiguous()
+            v = w.reshape(groups, heads_, hd_true, *w.shape[1:])
+            out = v.new_zeros(groups, heads_, hd_, *w.shape[1:])
+            out[:, :, :hd_true] = v
+            return out.reshape(groups * heads_ * hd_, *w.shape[1:]).contiguous()
+
+        def planes(w2d):
+            return ops.split_planes(w2d.contiguous(), None, fmt=fmt, weight=fmt == ops.FMT_H8)
+
+        def folded(w, bias, lnw, lnb):
+            """(planes of W o lnw, column sums of those planes as the kernel will read them, W lnb + bias)"""
+            pl = planes(w * lnw[None, :])
+            cs = ops.planes_to_float(pl, cols=w.shape[1])[: w.shape[0]].double().sum(1).float().contiguous()
+            return pl, cs, (w.double() @ lnb.double()).float().add_(bias).contiguous()
+        b = f"blocks.{i}."
+        g = lambda k: sd[b + k].detach().to(dev, torch.float32)   # noqa: E731
+        qkv_w, qkv_bias = pad_head_rows(g("attn.qkv.weight"), 3), pad_head_rows(g("attn.qkv.bias"), 3)
+        proj_w = pad_head_rows(g("attn.proj.weight").t(), 1).t().contiguous()    # zero COLUMNS for the pad channels
+        out = dict(qkv=planes(qkv_w), proj=planes(proj_w), lin1=planes(g("mlp.lin1.weight")), lin2=planes(g("mlp.lin2.weight")))
+        if fold:   # the consumers' weights carry their LayerNorm (the unfolded planes are not kept: the fold is all or nothing per model)
+            out["qkv"], out["qkv_cs"], out["qkv_bf"] = folded(qkv_w, qkv_bias, g("norm1.weight"), g("norm1.bias"))
+            out["lin1"], out["lin1_cs"], out["lin1_bf"] = folded(g("mlp.lin1.weight"), g("mlp.lin1.bias"), g("norm2.weight"), g("norm2.bias"))
+        return out
+
+    @torch.no_grad()
     def _pack(self, dev):
         cfg = self.cfg
         h8_sites = self._h8_sites()
@@ -279,18 +311,12 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 and (3 * Da) % 128 == 0 and hidden_ % 128 == 0)
         pk["fold_ln"] = fold
 
-        def folded(w, bias, lnw, lnb, fmt):
-            """(planes of W o lnw, column sums of those planes as the kernel will read them, W lnb + bias)"""
-            pl = planes((w * lnw[None, :]).contiguous(), fmt=fmt)
-            cs = ops.planes_to_float(pl, cols=w.shape[1])[: w.shape[0]].double().sum(1).float().contiguous()
-            return pl, cs, (w.double() @ lnb.double()).float().add_(bias).contiguous()
         for i in range(cfg["depth"]):
             b = f"blocks.{i}."
-            qkv_w, qkv_bias = pad_head_rows(sd[b + "attn.qkv.weight"], 3), pad_head_rows(sd[b + "attn.qkv.bias"], 3)
-            proj_w = pad_head_rows(sd[b + "attn.proj.weight"].t(), 1).t().contiguous()    # zero COLUMNS for the pad channels
+            qkv_bias = pad_head_rows(sd[b + "attn.qkv.bias"], 3)
             pk["blocks"].append(dict(
                 n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
-                qkv=planes(qkv_w, fmt=vfmt), qkv_b=qkv_bias,
+                qkv_b=qkv_bias,
                 # k = v of pad tokens; with the fp16 P V of the attention kernels (the "attnv" site, a default; MMSA_H8 without it: bf16 hi/lo pairs) the v third
                 # of the qkv planes -- these bias rows and the qkv GEMM's output -- is h8-encoded (ops.Planes.split)
                 qkv_bp=(ops.split_planes_qkv(qkv_bias.reshape(1, -1).contiguous(), Da) if ("attnv" in h8_sites and Da % 32 == 0)
@@ -300,15 +326,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 qkv_bp16=(ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_H8) if "attnv" in h8_sites else None),
                 # ... and plain bf16 hi/lo planes for a block whose logit range rules fp16 operands out (attention_precision, _attn_mode)
                 qkv_bp_b3=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da),
-                proj=planes(proj_w, fmt=vfmt), proj_b=sd[b + "attn.proj.bias"],
-                lin1=planes(sd[b + "mlp.lin1.weight"], fmt=vfmt), lin1_b=sd[b + "mlp.lin1.bias"],
-                lin2=planes(sd[b + "mlp.lin2.weight"], fmt=vfmt), lin2_b=sd[b + "mlp.lin2.bias"],
+                proj_b=sd[b + "attn.proj.bias"], lin1_b=sd[b + "mlp.lin1.bias"], lin2_b=sd[b + "mlp.lin2.bias"],
                 rph=pad_cols(sd[b + "attn.rel_pos_h"]), rpw=pad_cols(sd[b + "attn.rel_pos_w"]),
                 ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"], index=i))
-            if fold:   # the consumers' weights carry their LayerNorm (the unfolded planes are not kept: the fold is all or nothing per model)
-                blk = pk["blocks"][-1]
-                blk["qkv"], blk["qkv_cs"], blk["qkv_bf"] = folded(qkv_w, qkv_bias, blk["n1w"], blk["n1b"], vfmt)
-                blk["lin1"], blk["lin1_cs"], blk["lin1_bf"] = folded(sd[b + "mlp.lin1.weight"], sd[b + "mlp.lin1.bias"], blk["n2w"], blk["n2b"], vfmt)
+            pk["blocks"][-1].update(self._block_gemm_planes(sd, i, vfmt, fold, dev))
         for blk in pk["blocks"]:   # windowed blocks with head_dim 64: rel-pos tables packed for the fused window kernel
             wsz = blk["ws"]
             if wsz and wsz <= 14 and hd_ == 64:
@@ -809,21 +830,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             bp["max_logit"] = mx
             mode = bp["amode"] = "f16" if mx <= self.ATTN_F16_MAX_LOGIT else "b3"
             if mode == "b3" and bp["qkv"].fmt == ops.FMT_H8:
-                # the projection that makes those logits must not lose them either: q and k with 2^-15.6 products turn a logit of 48
-                # into an error of ~1e-3 before the exponential.  This block's qkv GEMM moves to bf16 hi/lo operands (2^-17), repacked here.
-                sdw = self.state_dict()
-                i = bp["index"]
-                w = sdw[f"blocks.{i}.attn.qkv.weight"].to(x.device, torch.float32)
-                if self._hd_pad != self._hd_true:
-                    v = w.reshape(3, heads, self._hd_true, -1)
-                    wp_ = v.new_zeros(3, heads, hd, v.shape[-1])
-                    wp_[:, :, :self._hd_true] = v
-                    w = wp_.reshape(3 * Da, -1)
-                if self._packed["fold_ln"]:
-                    w = w * bp["n1w"][None, :]
-                bp["qkv"] = ops.split_planes(w.contiguous(), None, fmt=ops.FMT_B3)
-                if self._packed["fold_ln"]:
-                    bp["qkv_cs"] = ops.planes_to_float(bp["qkv"], cols=w.shape[1])[: w.shape[0]].double().sum(1).float().contiguous()
+                # the projections around those logits must not lose them either: q and k from 2^-15.6 products turn a logit of 48 into an
+                # error of ~1e-3 before the exponential, and what proj / lin1 / lin2 lose reaches the NEXT block's q and k.  The whole
+                # block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.
+                bp.update(self._block_gemm_planes(self.state_dict(), bp["index"], ops.FMT_B3, self._packed["fold_ln"], x.device))
         return mode
 
     # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)

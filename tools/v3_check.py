@@ -109,14 +109,17 @@ def check():
     return bad
 
 
+FLAVOURS = tuple(int(v) for v in os.environ.get("V3_CHECK_FLAVOURS", "8,3").split(","))   # mmsa_debug_gemm_flavour values timed against each other
+
+
 def time_worker():
     import torch
     import mmsa
     from mmsa import lib
     ops = mmsa.ops
     print(f"{'':12s}" + " ".join(f"{s[0]:>8s}" for s in SHAPES))
-    for h8 in (False, True):
-        rows = {8: [], 3: []}
+    for h8 in ((False,) if 4 in FLAVOURS else (False, True)):
+        rows = {fl: [] for fl in FLAVOURS}
         for (label, M, N, K, b, act, outk, resid, scale) in SHAPES:
             fmt = ops.FMT_H8 if h8 else ops.FMT_B3
             a, w, kw, r, *_ = _setup(ops, torch, M, N, K, b, act, outk, resid, scale, h8)
@@ -129,9 +132,9 @@ def time_worker():
                     call = lambda: ops.gemm(a, w, out=c, stride_c=M * N, resid=c, stride_r=M * N, beta=0.5, **kw)   # in place like the model (beta keeps it bounded)
                 else:
                     call = lambda: ops.gemm(a, w, out=c, stride_c=M * N, **kw)
-            best = {8: 1e9, 3: 1e9}
+            best = {fl: 1e9 for fl in FLAVOURS}
             for rnd in range(3):          # interleaved rounds, one process
-                for fl in (8, 3):
+                for fl in FLAVOURS:
                     lib.call("mmsa_debug_gemm_flavour", fl)
                     for _ in range(3):
                         call()
@@ -143,14 +146,15 @@ def time_worker():
                     torch.cuda.synchronize()
                     best[fl] = min(best[fl], (time.perf_counter() - t0) / reps * 1e6)
             lib.call("mmsa_debug_gemm_flavour", 0)
-            for fl in (8, 3):
+            for fl in FLAVOURS:
                 rows[fl].append(best[fl])
         tag = "h8" if h8 else "b3"
         flops = [2.0 * s[1] * s[2] * s[3] * s[4] for s in SHAPES]
-        for fl in (8, 3):
-            print(f"{tag} v{'2' if fl == 8 else '3'} us   " + " ".join(f"{u:8.1f}" for u in rows[fl]))
-        print(f"{tag} v3/v2     " + " ".join(f"{x / y:8.3f}" for x, y in zip(rows[3], rows[8])))
-        print(f"{tag} v3 TF/s   " + " ".join(f"{f / u / 1e6:8.1f}" for f, u in zip(flops, rows[3])), flush=True)
+        for fl in FLAVOURS:
+            print(f"{tag} fl{fl} us   " + " ".join(f"{u:8.1f}" for u in rows[fl]))
+        a_, b_ = FLAVOURS[0], FLAVOURS[1]
+        print(f"{tag} fl{b_}/fl{a_}   " + " ".join(f"{x / y:8.3f}" for x, y in zip(rows[b_], rows[a_])))
+        print(f"{tag} fl{b_} TF/s " + " ".join(f"{f / u / 1e6:8.1f}" for f, u in zip(flops, rows[b_])), flush=True)
 
 
 if __name__ == "__main__":
