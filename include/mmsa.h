@@ -44,6 +44,9 @@ int mmsa_debug_poison_lds(unsigned pattern, mmsa_stream_t stream);
 /* testing / A-B aid: force the workgroup flavour of mmsa_gemm_split3's LDS-DMA kernel (4 = 128-row tiles, two workgroups per CU;
  * 8 = 256-row ping-pong tiles; 3 = the 4-wave kernel whose epilogue runs inside the next k loop, gemm_v3.hip; 0 = automatic by shape).  Results are bit-identical either way (same k order per output element). */
 int mmsa_debug_gemm_flavour(int waves_per_workgroup);
+/* testing / A-B aid: 1 = mmsa_window_attention_planes runs its three-barrier persistent kernel also for v_fmt = 2 (the default there is the
+ * one-barrier kernel with double-buffered hi-only K / V images, csrc/wattn.hip); 0 = automatic.  Results are bit-identical. */
+int mmsa_debug_wattn_flavour(int flavour);
 int mmsa_event_create(void** ev);
 int mmsa_event_record(void* ev, mmsa_stream_t stream);
 int mmsa_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */

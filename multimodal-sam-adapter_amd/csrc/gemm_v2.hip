@@ -50,6 +50,7 @@ struct GemmV2Args {
   //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
   float* rs_out; int rs_strips;
   const float* rn_mr; const float* rn_cs;
+  int stagger; // MMSA_GEMM_STAGGER (timing experiment, see the kernel's head)
   int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
 };
 
@@ -133,6 +134,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   }
   const int my_tiles = (a.ntiles - rb + G - 1) / G;   // tiles rb, rb+G, ...
   if (my_tiles <= 0) return;
+  // EXPERIMENT (MMSA_GEMM_STAGGER = phases * 1000 + delay, delay in units of 64 * 127 cycles): workgroups of different phases start their
+  // first tile `delay` apart, so that the workgroups of a launch do not all reach their epilogue -- a chip-wide store burst -- together
+  if (a.stagger) {
+    const int ph = (blockIdx.x >> 3) % (a.stagger / 1000);
+    for (int i = 0; i < ph * (a.stagger % 1000); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   CLK_SAMPLE(0)
   const int total = my_tiles * nk;
 
@@ -970,6 +977,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.ntiles = a.nbm * a.nbn * batch;
   static const int dbg = getenv("MMSA_GEMM_DEBUG") ? atoi(getenv("MMSA_GEMM_DEBUG")) : 0;
   a.debug = dbg;
+  static const int stg = getenv("MMSA_GEMM_STAGGER") ? atoi(getenv("MMSA_GEMM_STAGGER")) : 0;
+  a.stagger = stg >= 2000 ? stg : 0;
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;

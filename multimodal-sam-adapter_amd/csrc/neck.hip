@@ -10,6 +10,7 @@
 //   gelu_gate      : gated-MLP  gelu(x1) * x2  (AM:129-130).
 //   pool_hw / ca_apply : CoordinateAttention pooling and gating (AM:187-201, 218-221).
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 #define GR_ROWS 1024   // rows of X/Y per workgroup (4 waves x 256)
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
 extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G,
                             int B, int P, int c, int nblk, hipStream_t stream) {
   MMSA_CHECK_ARG(X && Y && G && B > 0 && P > 0 && c > 0 && nblk > 0 && c % nblk == 0, "gram_tn: bad args");
-  if (hipMemsetAsync(G, 0, sizeof(double) * (size_t)B * c * c, stream) != hipSuccess) {
+  static const bool skip_zero = getenv("MMSA_SKIP_MEMSET") != nullptr;   // TIMING ablation only (wrong results): what the per-call memset node costs
+  if (!skip_zero && hipMemsetAsync(G, 0, sizeof(double) * (size_t)B * c * c, stream) != hipSuccess) {
     mmsa_set_error("gram_tn: memset failed");
     return MMSA_ERR_LAUNCH;
   }

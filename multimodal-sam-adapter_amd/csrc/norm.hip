@@ -202,7 +202,8 @@ extern "C" int mmsa_colstats(const float* x, long ldx, long strideB, const float
                              double* out, hipStream_t stream) {
   MMSA_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "colstats: bad args");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (strideB & 3) == 0 && (((uintptr_t)x) & 15) == 0, "colstats: C / ld must be multiples of 4, x 16-byte aligned");
-  if (hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)B * C, stream) != hipSuccess) {
+  static const bool skip_zero = getenv("MMSA_SKIP_MEMSET") != nullptr;   // TIMING ablation only (wrong results): what the per-call memset node costs
+  if (!skip_zero && hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)B * C, stream) != hipSuccess) {
     mmsa_set_error("colstats: memset failed");
     return MMSA_ERR_LAUNCH;
   }

@@ -649,6 +649,266 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT variant, all-fp16 form, ONE barrier per item (round 3).  With h8 planes the kernel above reads only the fp16 hi halves, yet
+// it still transferred K's lo halves and kept a V lo image: here a K row is [hi of channels 0..31 | hi of channels 32..63] (128 B, like a
+// V row), so K and V of an item are 26 KiB each and there is room for TWO of each.  K(i+1) and V(i+1) are requested right after the barrier
+// that opens item i and have the whole item to land; the barriers "#2" (K image free) and "#3" (V landed) of the kernel above are gone, and
+// with them the lockstep of the 13 waves through the S (matrix pipe) -> softmax (VALU) -> P V phases: between two barriers every wave runs
+// its whole item, so the 3-4 waves of a SIMD drift apart and one wave's softmax issues beside another's MFMAs.  Arithmetic, operand
+// order and rounding are those of wattn_persist_kernel<true>: results bit-identical (tests/test_bookkeeping_gpu.py compares them).
+#define WP2_KV_BYTES (WP_NKV * 128)
+#define WP2_LDS (4 * WP2_KV_BYTES + WA_E_BYTES + WP_R_BYTES + WA_WAVES * WA_B_BYTES)
+__global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist2_kernel(WAttnArgs a, int nWin, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* KV = smem;                              // [parity]{K, V}: K(p) at p * 2 * WP2_KV_BYTES, V(p) right behind it
+  unsigned char* Es = smem + 4 * WP2_KV_BYTES;
+  unsigned char* Rs = Es + WA_E_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Bw = reinterpret_cast<float*>(Rs + WP_R_BYTES + wave * WA_B_BYTES);
+  const int l15 = lane & 15, G = lane >> 4;
+  const int T = a.H * a.W, ws = a.ws, Nk = ws * ws;
+  const int dr = lane >> 3, slot = lane & 7;
+
+  int wi, wj, head, b;
+  const int nWh = nWin / a.nWw, nHB = a.heads * a.B;
+  auto decode = [&](int it) {   // same item order as wattn_persist_kernel: interior windows first, overhanging ones last
+    const int r = it / nHB;
+    const int hb = it - r * nHB;
+    head = hb % a.heads;
+    b = hb / a.heads;
+    const int nI = (nWh - 1) * (a.nWw - 1);
+    if (r < nI) {
+      wi = r / (a.nWw - 1);
+      wj = r - wi * (a.nWw - 1);
+    } else if (r - nI < nWh - 1) {
+      wi = r - nI;
+      wj = a.nWw - 1;
+    } else {
+      wi = nWh - 1;
+      wj = r - nI - (nWh - 1);
+    }
+  };
+  auto token_of = [&](int j) -> int {
+    if (j >= Nk) return -2;
+    const int r = (int)(__umul24(j, a.magic) >> 16), c = j - __umul24(r, ws);
+    const int hh = wi * ws + r, ww = wj * ws + c;
+    return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
+  };
+  // K and V of the CURRENT decode state into the buffer pair `kvb_`: per wave 16 keys, 2 + 2 LDS-DMA instructions (8 keys x 128 B each).
+  // Logical 16-byte chunk c of a row = hi values of channels 8c .. 8c+7 (c >> 2 = k-block, c & 3 = chunk of its 64-byte hi half);
+  // K: chunk c at slot c ^ ((key & 15) >> 1) (the GEMM image's swizzle: conflict-free fragment reads); V: as in the kernel above.
+#define WP2_ISSUE_KV(kvb_)                                                                                    \
+  {                                                                                                           \
+    int lo_ = lane;   /* opaque: keep the per-lane address parts inside the item loop (register budget) */    \
+    asm volatile("" : "+v"(lo_));                                                                             \
+    const int dr = lo_ >> 3, slot = lo_ & 7;                                                                  \
+    const unsigned short* pq_b_ = a.qp + (long)b * T * a.ldq;                                                 \
+    const int colk_ = a.D + head * 64, colv_ = 2 * a.D + head * 64;                                           \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
+      const int key = 16 * wave + 8 * half + dr;                                                              \
+      const int t_ = token_of(key);                                                                           \
+      const unsigned short* row = t_ >= 0 ? pq_b_ + (long)t_ * a.ldq : a.bp;                                  \
+      const int ck = slot ^ ((key & 15) >> 1);                                                                \
+      GLDS16(row + 2 * (colk_ + 32 * (ck >> 2)) + (ck & 3) * 8, (kvb_) + (16 * wave + 8 * half) * 128);       \
+      const int cv = slot ^ (((key >> 1) & 3) << 1);                                                          \
+      GLDS16(row + 2 * (colv_ + 32 * (cv >> 2)) + (cv & 3) * 8, (kvb_) + WP2_KV_BYTES + (16 * wave + 8 * half) * 128); \
+    }                                                                                                         \
+  }
+#define WP2_LOAD_Q()                                                                                          \
+  {                                                                                                           \
+    tq = token_of(16 * wave + l15);                                                                           \
+    const unsigned short* qrow = a.qp + ((long)b * T + (tq >= 0 ? tq : 0)) * a.ldq;                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+      qh[ks] = *reinterpret_cast<const bf16x8*>(qrow + 2 * (head * 64 + 32 * ks) + 8 * G);                    \
+  }
+
+  // ---- once per workgroup: selector tiles and the rel-pos table image
+  {
+    const int row = lane >> 2, ch = (lane & 3) ^ ((row >> 2) & 3);
+    GLDS16(a.sel + (16 * wave + row) * 32 + ch * 8, Es + 16 * wave * 64);
+#pragma unroll 1
+    for (int u = wave; u < 16; u += WA_WAVES) {
+      const int ks = u >> 3, r0 = 8 * (u & 7);
+      const int rrow = r0 + dr;
+      const int piece = slot ^ ((rrow & 15) >> 1);
+      GLDS16(a.relp + rrow * 128 + 64 * ks + piece * 8, Rs + (ks * 64 + r0) * 128);
+    }
+  }
+  int it = blockIdx.x;
+  if (it >= nitems) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+  decode(it);
+  bf16x8 qh[2];
+  int tq;
+  unsigned kv_off = 0;                                   // byte offset of the running item's buffer pair
+  WP2_ISSUE_KV(KV)
+  WP2_LOAD_Q()
+
+  const int fslot = G ^ ((l15 >> 1) & 7);
+  const int frag_hi = l15 * 128 + fslot * 16;            // rel-pos table image (GEMM layout); K: k-block ks at frag_hi ^ (64 ks)
+  const int frag_e = l15 * 64 + ((G ^ ((l15 >> 2) & 3)) << 4);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sc2 = a.scale * LOG2E, rscale = 1.0f / a.scale;
+
+#pragma unroll 1
+  for (;;) {
+    const int jq = 16 * wave + l15;
+    const bool live = tq >= 0;
+    const bool any_live = __builtin_amdgcn_readfirstlane(__any(live) ? 1 : 0) != 0;   // wave-uniform
+    const int tq_cur = tq;
+    const int head_cur = head, b_cur = b;
+    const unsigned char* Kc = KV + kv_off;
+    const unsigned char* Vc = Kc + WP2_KV_BYTES;
+    // ---- the item's only barrier: my K / V pieces and Q have landed (the table image too, first item) => everyone's have; everyone is
+    // past the previous item, whose buffers the next item's pieces may now overwrite
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int it_next = it + gridDim.x;
+    const bool has_next = it_next < nitems;
+    if (has_next) {
+      decode(it_next);
+      WP2_ISSUE_KV(KV + (kv_off ^ (2 * WP2_KV_BYTES)))
+    }
+    if (any_live) {
+      bf16x8 bqh = {0, 0, 0, 0, 0, 0, 0, 0}, bql = {0, 0, 0, 0, 0, 0, 0, 0};
+      {
+        // rel-pos terms T[i][q] = rel_pos[i] . q (table fragments from the LDS image), re-indexed per query by key coordinate
+        f32x4 tt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          tt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 rh_ = *reinterpret_cast<const bf16x8*>(Rs + (ks * 64 + 16 * t) * 128 + frag_hi);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[ks]), tt[t], 0, 0, 0);
+          }
+        }
+        int lane_o = lane;   // opaque copy: LICM would otherwise hoist ~20 per-lane addresses out of the item loop and spill them
+        asm volatile("" : "+v"(lane_o));
+        const int l15 = lane_o & 15, G = lane_o >> 4;
+        const int jqc = jq < Nk ? jq : 0;
+        const int qr = (int)(__umul24(jqc, a.magic) >> 16), qc = jqc - __umul24(qr, ws);
+        *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * (t & 1) + 4 * G + r;
+            const int kc = ((t >> 1) ? qc : qr) + (ws - 1) - i;
+            if (kc >= 0 && kc < ws) Bw[l15 * 32 + (t >> 1) * 14 + kc] = tt[t][r] * rscale;
+          }
+        const float4 b0 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G);
+        const float4 b1 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G + 4);
+        uint4 hh, ll;
+        split2_f16(b0.x, b0.y, hh.x, ll.x);
+        split2_f16(b0.z, b0.w, hh.y, ll.y);
+        split2_f16(b1.x, b1.y, hh.z, ll.z);
+        split2_f16(b1.z, b1.w, hh.w, ll.w);
+        bqh = __builtin_bit_cast(bf16x8, hh);
+        bql = __builtin_bit_cast(bf16x8, ll);
+      }
+      // S^T = sel Bq^T + K Q^T
+      f32x4 s[13];
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        const bf16x8 e_ = *reinterpret_cast<const bf16x8*>(Es + 16 * t * 64 + frag_e);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bql), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bqh), s[t], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(Kc + 16 * t * 128 + (frag_hi ^ (64 * ks)));
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[ks]), s[t], 0, 0, 0);
+        }
+        if (t & 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 13 tiles' fragment reads (spills at 128 VGPRs)
+      }
+      float mxs;
+      {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int G = lane_o >> 4;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+          s[t] *= sc2;
+          if (16 * t + 16 > Nk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * G + r) < Nk ? s[t][r] : -INFINITY;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mxs = mx;
+      }
+      int lane_o = lane;   // opaque copy: the 28 transposed-read addresses below must not be hoisted out of the item loop
+      asm volatile("" : "+v"(lane_o));
+      const int l15 = lane_o & 15, G = lane_o >> 4;
+      f32x4 o[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float psum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          if (2 * g + hf < 13) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
+              s[2 * g + hf][r] = p;
+              psum += p;
+            }
+          }
+        }
+        uint4 hh;
+        hh.x = pack_f16(s[2 * g][0], s[2 * g][1]);
+        hh.y = pack_f16(s[2 * g][2], s[2 * g][3]);
+        if (2 * g + 1 < 13) {
+          hh.z = pack_f16(s[2 * g + 1][0], s[2 * g + 1][1]);
+          hh.w = pack_f16(s[2 * g + 1][2], s[2 * g + 1][3]);
+        } else {
+          hh.z = hh.w = 0u;   // keys 208..223 do not exist
+        }
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, hh);
+        const int row0 = 32 * g + 4 * G + (l15 >> 2);
+        const int sw = (row0 >> 1) & 3;
+        const int second = (2 * g + 1 < 13) ? 16 * 128 : 0;   // no V rows beyond 207: re-read valid rows (their P is zero)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int voff = row0 * 128 + ((d ^ sw) << 5) + 8 * (l15 & 3);
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vc + voff));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vc + voff + second));
+          const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph), o[d], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      const float inv = 1.0f / psum;
+      unsigned short* orow = a.op + ((long)b_cur * T + (tq_cur >= 0 ? tq_cur : 0)) * a.ldo;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        store_planes8_pair<16>(orow, head_cur * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, tq_cur >= 0);
+    }
+    if (!has_next) break;
+    it = it_next;
+    kv_off ^= 2 * WP2_KV_BYTES;
+    WP2_LOAD_Q()
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int g_wattn_flavour = 0;   // testing / A-B aid: 1 = the three-barrier persistent kernel also for the all-fp16 form, 0 = automatic
+extern "C" int mmsa_debug_wattn_flavour(int flavour) {
+  g_wattn_flavour = flavour == 1 ? 1 : 0;
+  return MMSA_OK;
+}
+
 extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, long ldq, const unsigned short* bias_planes,
                                             const unsigned short* relpos_planes, const unsigned short* selector,
                                             unsigned short* out_planes, long ldo,
@@ -684,6 +944,7 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
     (void)hipFuncSetAttribute((const void*)wattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
     (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
     (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+    (void)hipFuncSetAttribute((const void*)wattn_persist2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WP2_LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -717,7 +978,10 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
     int grid = cdiv(nitems, rounds);
     const int grid_all = nitems < num_cus ? nitems : num_cus;
     if (schedule_cost(grid_all) < schedule_cost(grid) - 1e-9) grid = grid_all;
-    if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
+    static const bool three_barriers_env = getenv("MMSA_WATTN_P1") != nullptr;   // A/B aid: the three-barrier kernel for the all-fp16 form too
+    const bool three_barriers = three_barriers_env || g_wattn_flavour == 1;
+    if (v_fmt && !three_barriers) hipLaunchKernelGGL(wattn_persist2_kernel, dim3(grid), dim3(WA_WAVES * 64), WP2_LDS, stream, a, nWin, nitems);
+    else if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
     else hipLaunchKernelGGL(wattn_persist_kernel<false>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
   }
   MMSA_CHECK_LAUNCH("window_attention");

@@ -341,8 +341,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # --- TwinConvNeXt
         def cfmt(w2d):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path):
             # h8 operands for the pointwise convs whose two contraction lengths (C and 4C) are multiples of 64 and that do not run on the fused stage-0 kernel
+            # ("cnx2": stage 2 alone -- the selective variant of tools/cnx_h8_study.py, measured and left off: DESIGN.md section 4.2)
             c_ = min(w2d.shape)
-            return ops.FMT_H8 if ("cnx" in h8_sites and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_)) else ops.FMT_B3
+            on = "cnx" in h8_sites or ("cnx2" in h8_sites and c_ == self.channels[2])
+            return ops.FMT_H8 if (on and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_)) else ops.FMT_B3
         t = "spm.twin_conv."
         pk["twin"] = {}
         for s in ("x", "y"):

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mmsa_last_error": [],
     "mmsa_debug_poison_lds": [ctypes.c_uint, P],
     "mmsa_debug_gemm_flavour": [I],
+    "mmsa_debug_wattn_flavour": [I],
     "mmsa_event_create": [POINTER(c_void_p)],
     "mmsa_event_record": [P, P],
     "mmsa_event_elapsed_ms": [P, P, POINTER(c_float)],

@@ -1,0 +1,44 @@
+"""Same-box A/B of environment settings: each variant is bench.py in its own process, variants interleaved over several rounds.
+    python tools/ab_env.py [--rounds 2] [--steps 20] [--verify] name1:VAR=val,VAR2=val name2: ...
+(an empty setting list = the default build).  Prints ms/step per run and the per-variant minimum; with --verify also the golden probe
+error of the timed path (`verified.golden_max_rel`)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+args = sys.argv[1:]
+rounds, steps, verify = 2, 20, False
+while args and args[0].startswith("--"):
+    if args[0] == "--rounds":
+        rounds = int(args[1]); args = args[2:]
+    elif args[0] == "--steps":
+        steps = int(args[1]); args = args[2:]
+    elif args[0] == "--verify":
+        verify = True; args = args[1:]
+    else:
+        raise SystemExit(f"unknown flag {args[0]}")
+variants = []
+for a in args:
+    name, _, sets = a.partition(":")
+    env = dict(kv.split("=", 1) for kv in sets.split(",") if kv)
+    variants.append((name, env))
+best = {}
+for rnd in range(rounds):
+    for name, env in variants:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-roofline"]
+        if not verify:
+            cmd.append("--no-verify")
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env))
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            print(f"{name}: FAILED\n{r.stderr[-1500:]}", flush=True)
+            continue
+        extra = ""
+        if verify and isinstance(d.get("verified"), dict):
+            extra = "  " + " ".join(f"{k}={v}" for k, v in d["verified"].items() if "max_rel" in k)
+        print(f"round {rnd} {name:14s} {d['ms_per_step']:.3f} ms/step {d['value']:.2f} img/s  encoder-only {d.get('encoder_only')}{extra}", flush=True)
+        best[name] = min(best.get(name, 1e9), d["ms_per_step"])
+print("best: " + "  ".join(f"{k} {v:.3f}" for k, v in best.items()))

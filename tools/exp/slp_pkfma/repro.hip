@@ -1,0 +1,61 @@
+// Stress runner: the pair kernel built WITH the SLP vectoriser (v_pk_fma_f32 / v_pk_mul_f32 with op_sel lane swizzles) against the
+// same source built scalar, bitwise, while a second stream keeps the GPU busy with an unrelated kernel (the condition under which the
+// product kernel returned wrong upper halves in round 1).  Exit code 0 always; prints the mismatch counts.  See README.md.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+extern "C" void launch_slp_on(const float*, long, const float*, float*, long, int, int, int, int, hipStream_t);
+extern "C" void launch_slp_off(const float*, long, const float*, float*, long, int, int, int, int, hipStream_t);
+#define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 2; } } while (0)
+
+__global__ void busy_kernel(float* p, int n, int iters) {   // memory + packed-math traffic on the other stream
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float a = p[i % n], b = a + 1.f;
+  for (int k = 0; k < iters; ++k) { a = fmaf(a, 1.0000001f, b); b = fmaf(b, 0.9999999f, a); }
+  p[i % n] = a + b;
+}
+
+int main(int argc, char** argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 200;
+  const int B = 2, H = 128, W = 128, C = 288;          // the neck level-1 gated MLP of ViT-L (2C = 576 channels in, C out)
+  const long ldx = 2 * C, ldy = C, rows = (long)B * H * W;
+  std::vector<float> hx(rows * ldx), hw((size_t)9 * C * 4 * 2);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.f - 1.f; };
+  for (auto& v : hx) v = rnd();
+  for (auto& v : hw) v = rnd() * 0.3f;
+  float *x, *w, *y0, *y1, *junk;
+  CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&w, hw.size() * 4)); CK(hipMalloc(&y0, rows * ldy * 4)); CK(hipMalloc(&y1, rows * ldy * 4));
+  const int nj = 1 << 24;
+  CK(hipMalloc(&junk, (size_t)nj * 4)); CK(hipMemset(junk, 0, (size_t)nj * 4));
+  CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+  hipStream_t s0, s1;
+  CK(hipStreamCreate(&s0)); CK(hipStreamCreate(&s1));
+  std::vector<float> ref(rows * ldy), got(rows * ldy);
+  launch_slp_off(x, ldx, w, y0, ldy, B, H, W, C, s0);
+  CK(hipStreamSynchronize(s0));
+  CK(hipMemcpy(ref.data(), y0, ref.size() * 4, hipMemcpyDeviceToHost));
+  long bad_on_alone = 0, bad_on_busy = 0, bad_off_busy = 0, launches = 0;
+  for (int mode = 0; mode < 3; ++mode) {     // 0: SLP build alone; 1: SLP build beside the busy stream; 2: scalar build beside the busy stream
+    for (int r = 0; r < rounds; ++r) {
+      if (mode) hipLaunchKernelGGL(busy_kernel, dim3(nj / 256), dim3(256), 0, s1, junk, nj, 64);
+      CK(hipMemsetAsync(y1, 0xff, rows * ldy * 4, s0));
+      if (mode == 2) launch_slp_off(x, ldx, w, y1, ldy, B, H, W, C, s0); else launch_slp_on(x, ldx, w, y1, ldy, B, H, W, C, s0);
+      CK(hipStreamSynchronize(s0));
+      CK(hipMemcpy(got.data(), y1, got.size() * 4, hipMemcpyDeviceToHost));
+      long bad = 0;
+      for (size_t i = 0; i < got.size(); ++i) bad += memcmp(&got[i], &ref[i], 4) != 0;
+      if (bad && (bad_on_alone + bad_on_busy + bad_off_busy) == 0) {
+        for (size_t i = 0; i < got.size(); ++i) if (memcmp(&got[i], &ref[i], 4)) { printf("first mismatch: mode %d round %d element %zu (channel %zu) got %.9g want %.9g\n", mode, r, i, i % C, got[i], ref[i]); break; }
+      }
+      (mode == 0 ? bad_on_alone : mode == 1 ? bad_on_busy : bad_off_busy) += bad;
+      ++launches;
+    }
+    CK(hipDeviceSynchronize());
+  }
+  printf("launches %ld per mode %d | mismatching elements: SLP build alone %ld, SLP build beside a busy stream %ld, scalar build beside a busy stream %ld\n",
+         launches, rounds, bad_on_alone, bad_on_busy, bad_off_busy);
+  return 0;
+}
