@@ -44,8 +44,8 @@ int mmsa_debug_poison_lds(unsigned pattern, mmsa_stream_t stream);
 /* testing / A-B aid: force the workgroup flavour of mmsa_gemm_split3's LDS-DMA kernel (4 = 128-row tiles, two workgroups per CU;
  * 8 = 256-row ping-pong tiles; 3 = the 4-wave kernel whose epilogue runs inside the next k loop, gemm_v3.hip; 0 = automatic by shape).  Results are bit-identical either way (same k order per output element). */
 int mmsa_debug_gemm_flavour(int waves_per_workgroup);
-/* testing / A-B aid: 1 = mmsa_window_attention_planes runs its three-barrier persistent kernel also for v_fmt = 2 (the default there is the
- * one-barrier kernel with double-buffered hi-only K / V images, csrc/wattn.hip); 0 = automatic.  Results are bit-identical. */
+/* testing / A-B aid for mmsa_window_attention_planes with v_fmt = 2: 2 = the one-barrier persistent kernel (double-buffered hi-only K / V
+ * images; measured slower, opt-in), 1 = the three-barrier persistent kernel, 0 = automatic (= 1 today).  Results are bit-identical. */
 int mmsa_debug_wattn_flavour(int flavour);
 int mmsa_event_create(void** ev);
 int mmsa_event_record(void* ev, mmsa_stream_t stream);
@@ -176,7 +176,7 @@ int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b
 
 /* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
 int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C, double* out,
-                  mmsa_stream_t stream);
+                  int out_is_zero /* 1: the caller zeroed `out` on this stream; 0: the call zeroes it first */, mmsa_stream_t stream);
 
 /* GFFM LayerNorm(H*W) statistics + FFRM gate (AM:241,265 and AM:158-162), see csrc/norm.hip. */
 int mmsa_ffrm_finalize(const double* stats, int B, int HW, int C, float mean_w, float mean_b, const float* Wc,
@@ -210,7 +210,7 @@ int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, in
 
 /* --- modality-fusion neck pieces (AM:75-109, 234-267, 110-132, 176-221) ------------------------------------- */
 int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G /* [B,c,c] double: order-independent sum */, int B, int P, int c,
-                 int nblk, mmsa_stream_t stream);
+                 int nblk, int out_is_zero /* as for mmsa_colstats */, mmsa_stream_t stream);
 int mmsa_chanattn_build(const double* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
                         const float* temp, const float* Wp, uint16_t* planes /* [B,c,2*cpad] */, int B, int c, int cpad,
                         int heads, mmsa_stream_t stream);

@@ -50,7 +50,6 @@ struct GemmV2Args {
   //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
   float* rs_out; int rs_strips;
   const float* rn_mr; const float* rn_cs;
-  int stagger; // MMSA_GEMM_STAGGER (timing experiment, see the kernel's head)
   int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
 };
 
@@ -61,6 +60,9 @@ struct GemmV2Args {
 #define V2_LDS_BYTES(NW_) (((NW_) == 8 ? 3 : 2) * ((NW_) * 32 * 128 + V2_W_BYTES))
 #ifndef V2_FP8_FIRST
 #define V2_FP8_FIRST 1   // 0: fp8 and fp16 MFMAs interleaved per output tile (A/B timing)
+#endif
+#ifndef V2_FP8_SPLIT
+#define V2_FP8_SPLIT 0   // 1: h8, 4 of a pair's 16 fp8 MFMAs (sub-tiles mi, ni >= 2) are issued at the head of the NEXT k-tile's matrix phase (see MFMA_FP8_PENDING).  MEASURED SLOWER (profiles/r03_fp8_split_ab.txt: lin1 146 -> 154 us, K = 512 shapes 129 -> 195, step 33.9 -> 36.3 ms): off
 #endif
 #ifndef V2_EXP_NO_FP8
 #define V2_EXP_NO_FP8 0   // timing experiment: leave the fp8 cross-term MFMAs out (wrong results)
@@ -134,12 +136,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   }
   const int my_tiles = (a.ntiles - rb + G - 1) / G;   // tiles rb, rb+G, ...
   if (my_tiles <= 0) return;
-  // EXPERIMENT (MMSA_GEMM_STAGGER = phases * 1000 + delay, delay in units of 64 * 127 cycles): workgroups of different phases start their
-  // first tile `delay` apart, so that the workgroups of a launch do not all reach their epilogue -- a chip-wide store burst -- together
-  if (a.stagger) {
-    const int ph = (blockIdx.x >> 3) % (a.stagger / 1000);
-    for (int i = 0; i < ph * (a.stagger % 1000); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   CLK_SAMPLE(0)
   const int total = my_tiles * nk;
 
@@ -272,14 +268,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 // phase overwrites the fp8 operand tuples -- every fragment read of that phase then stalls until the queued fp8 MFMAs have read
 // them (interval stamps: the read phase after an fp8 burst took 1150-1400 cycles, the other one 600).  With the fp16 MFMAs at the
 // tail the registers still in use are the hi fragments of the finished k-tile, which the next read phase does not touch.
-#define MFMA_FP8_ALL(NI4_)                                                                                  \
+// The matrix pipe's share of a k-tile pair is then 16 fp16 MFMAs (256 cycles) in the first step and 16 fp8 + 16 fp16 (768) in the second,
+// beside read phases of ~700 cycles on the partner group (the L2 -> LDS operand stream): the second step's phase is matrix-bound, the
+// first one's read-bound, 3350 cycles per pair where 4 x 700 would do.  V2_FP8_SPLIT (an experiment, off: slower as measured) moves the four fp8 MFMAs of sub-tiles (mi, ni >= 2)
+// to the head of the NEXT k-tile's matrix phase (DEFER_ here, MFMA_FP8_PENDING there): 12 x 32 + 256 = 640 and 4 x 32 + 256 = 384
+// cycles, both under the read phase.  Those four need opA[2..3] / opW[2..3] of the finished pair while the read phase between has
+// already fetched the next pair's first 8-bit chunks for the same slots: that phase keeps them in the fragment registers (16 more live
+// registers) and MX_FILL_LATE moves them into the operand tuples once the pending MFMAs are queued.  Same products; sub-tiles
+// (mi, ni >= 2) add a pair's cross terms after, not before, the pair's second fp16 product (results equal to the unsplit order to
+// fp32 rounding, not bit for bit).  The last pair of an output tile defers nothing, the first step of a tile has nothing pending.
+#define MFMA_FP8_ALL(NI4_, DEFER_)                                                                          \
   if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
     if (MXPAR && V2_FP8_FIRST && !V2_EXP_NO_FP8) {                                                          \
       _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                      \
         if (ni < 3 || (NI4_)) {                                                                             \
           _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
+            if (!(V2_FP8_SPLIT && (DEFER_) && ni >= 2 && mi >= 2))                                          \
+              acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
         }                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }                                                                                                       \
+  }
+#define MFMA_FP8_PENDING(NI4_, PEND_)                                                                       \
+  if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
+    if (!MXPAR && V2_FP8_SPLIT && V2_FP8_FIRST && !V2_EXP_NO_FP8) {                                         \
+      if (PEND_) {                                                                                          \
+        _Pragma("unroll") for (int ni = 2; ni < 4; ++ni)                                                    \
+          if (ni < 3 || (NI4_)) {                                                                           \
+            _Pragma("unroll") for (int mi = 2; mi < 4; ++mi)                                                \
+              acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
+          }                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      }                                                                                                     \
+      _Pragma("unroll") for (int i = 2; i < 4; ++i) { MX_SET(opA[i], al[i], 0) MX_SET(opW[i], wl[i], 0) }    \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
     }                                                                                                       \
   }
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     if ((i_) == 4) GLDS16(SW(0, pko), pfb + V2_A_BYTES + lds_w);                                             \
     if ((i_) == 5) GLDS16(SW(1, pko), pfb + V2_A_BYTES + lds_w + 1024);                                      \
   }
-#define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } }
+#define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { if (MXPAR || i < 2 || !(V2_FP8_SPLIT && V2_FP8_FIRST && !V2_EXP_NO_FP8)) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } } }
 // k-loop ablation build (tools/build_variant.sh -DV2_KABL, timing only, results are garbage): MMSA_GEMM_DEBUG = 64 + a bit mask of what
 // to leave out -- 1 the MFMAs, 2 the fragment reads, 4 the LDS-DMA, 8 the barriers inside the k loop; all without the epilogue.
 #ifdef V2_KABL
@@ -429,7 +450,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     STAMP(5)                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (!KABL(6)) {                                                                                         \
-    MFMA_FP8_ALL(ni4)                                                                                       \
+    MFMA_FP8_PENDING(ni4, kt != 0)                                                                          \
+    MFMA_FP8_ALL(ni4, !last_k)                                                                              \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
     MFMA_CHUNK(2)                                                                                           \
@@ -496,7 +518,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     ISTAMP(0)                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (!KABL(6)) {                                                                                         \
-    MFMA_FP8_ALL(NI4_)                                                                                      \
+    MFMA_FP8_PENDING(NI4_, true)                                                                            \
+    MFMA_FP8_ALL(NI4_, true)                                                                                \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
     MFMA_CHUNK(2)                                                                                           \
@@ -977,8 +1000,6 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.ntiles = a.nbm * a.nbn * batch;
   static const int dbg = getenv("MMSA_GEMM_DEBUG") ? atoi(getenv("MMSA_GEMM_DEBUG")) : 0;
   a.debug = dbg;
-  static const int stg = getenv("MMSA_GEMM_STAGGER") ? atoi(getenv("MMSA_GEMM_STAGGER")) : 0;
-  a.stagger = stg >= 2000 ? stg : 0;
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;

@@ -68,11 +68,12 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
       }
 }
 
+// out_is_zero != 0: the caller has zeroed G on this stream already (backbone: ONE memset per neck level covers the six accumulator
+// buffers of the level, instead of one memset node per call: 24 -> 4 per forward)
 extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G,
-                            int B, int P, int c, int nblk, hipStream_t stream) {
+                            int B, int P, int c, int nblk, int out_is_zero, hipStream_t stream) {
   MMSA_CHECK_ARG(X && Y && G && B > 0 && P > 0 && c > 0 && nblk > 0 && c % nblk == 0, "gram_tn: bad args");
-  static const bool skip_zero = getenv("MMSA_SKIP_MEMSET") != nullptr;   // TIMING ablation only (wrong results): what the per-call memset node costs
-  if (!skip_zero && hipMemsetAsync(G, 0, sizeof(double) * (size_t)B * c * c, stream) != hipSuccess) {
+  if (!out_is_zero && hipMemsetAsync(G, 0, sizeof(double) * (size_t)B * c * c, stream) != hipSuccess) {
     mmsa_set_error("gram_tn: memset failed");
     return MMSA_ERR_LAUNCH;
   }

@@ -198,12 +198,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   }
 }
 
+// out_is_zero != 0: the caller has zeroed `out` on this stream already (see mmsa_gram_tn)
 extern "C" int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C,
-                             double* out, hipStream_t stream) {
+                             double* out, int out_is_zero, hipStream_t stream) {
   MMSA_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "colstats: bad args");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (strideB & 3) == 0 && (((uintptr_t)x) & 15) == 0, "colstats: C / ld must be multiples of 4, x 16-byte aligned");
-  static const bool skip_zero = getenv("MMSA_SKIP_MEMSET") != nullptr;   // TIMING ablation only (wrong results): what the per-call memset node costs
-  if (!skip_zero && hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)B * C, stream) != hipSuccess) {
+  if (!out_is_zero && hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)B * C, stream) != hipSuccess) {
     mmsa_set_error("colstats: memset failed");
     return MMSA_ERR_LAUNCH;
   }

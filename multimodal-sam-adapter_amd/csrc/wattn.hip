@@ -650,7 +650,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PERSISTENT variant, all-fp16 form, ONE barrier per item (round 3).  With h8 planes the kernel above reads only the fp16 hi halves, yet
+// PERSISTENT variant, all-fp16 form, ONE barrier per item (round 3; measured slower than the kernel above and NOT the default: see the launcher).  With h8 planes the kernel above reads only the fp16 hi halves, yet
 // it still transferred K's lo halves and kept a V lo image: here a K row is [hi of channels 0..31 | hi of channels 32..63] (128 B, like a
 // V row), so K and V of an item are 26 KiB each and there is room for TWO of each.  K(i+1) and V(i+1) are requested right after the barrier
 // that opens item i and have the whole item to land; the barriers "#2" (K image free) and "#3" (V landed) of the kernel above are gone, and
@@ -903,9 +903,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist2_kernel(WAttnArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-static int g_wattn_flavour = 0;   // testing / A-B aid: 1 = the three-barrier persistent kernel also for the all-fp16 form, 0 = automatic
+static int g_wattn_flavour = 0;   // testing / A-B aid: 1 = the three-barrier persistent kernel, 2 = the one-barrier kernel (all-fp16 form only), 0 = automatic
 extern "C" int mmsa_debug_wattn_flavour(int flavour) {
-  g_wattn_flavour = flavour == 1 ? 1 : 0;
+  g_wattn_flavour = (flavour == 1 || flavour == 2) ? flavour : 0;
   return MMSA_OK;
 }
 
@@ -978,9 +978,11 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
     int grid = cdiv(nitems, rounds);
     const int grid_all = nitems < num_cus ? nitems : num_cus;
     if (schedule_cost(grid_all) < schedule_cost(grid) - 1e-9) grid = grid_all;
-    static const bool three_barriers_env = getenv("MMSA_WATTN_P1") != nullptr;   // A/B aid: the three-barrier kernel for the all-fp16 form too
-    const bool three_barriers = three_barriers_env || g_wattn_flavour == 1;
-    if (v_fmt && !three_barriers) hipLaunchKernelGGL(wattn_persist2_kernel, dim3(grid), dim3(WA_WAVES * 64), WP2_LDS, stream, a, nWin, nitems);
+    // the one-barrier kernel measured SLOWER than the three-barrier one (ViT-L block of one / two images: 26.7 / 44.9 against 24.5 / 41.0 us,
+    // same process, profiles/r03_wattn_one_barrier.txt): opt-in only (MMSA_WATTN_P2=1 or mmsa_debug_wattn_flavour(2)), kept bit-identical by the tests
+    static const bool one_barrier_env = getenv("MMSA_WATTN_P2") != nullptr;
+    const bool one_barrier = (one_barrier_env || g_wattn_flavour == 2) && g_wattn_flavour != 1;
+    if (v_fmt && one_barrier) hipLaunchKernelGGL(wattn_persist2_kernel, dim3(grid), dim3(WA_WAVES * 64), WP2_LDS, stream, a, nWin, nitems);
     else if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
     else hipLaunchKernelGGL(wattn_persist_kernel<false>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
   }

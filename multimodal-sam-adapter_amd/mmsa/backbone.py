@@ -1023,6 +1023,17 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         pl_ok = tp is not None and c % 32 == 0
         gcat_p = ws.planes("nk_gp", P, C) if pl_ok else None
         lcat_p = ws.planes("nk_lp", P, C) if pl_ok else None
+        # the level's six double-precision accumulator buffers (column statistics and Grams: atomically summed row slices) are slices of
+        # ONE block zeroed by ONE memset at the head of the level -- a memset node per call was 24 per forward (0.1-0.2 ms per step)
+        n_st, n_g, n_st2 = B * 3 * 3 * c, B * c * c, B * 3 * C
+        acc_blk = ws.get("nk_acc", 1, 2 * (n_st + n_g) + n_g + n_st2, dtype=torch.float64)
+        acc_blk.zero_()
+        acc_off = [0]
+
+        def acc_buf(rows, cols):
+            o = acc_off[0]
+            acc_off[0] = o + rows * cols
+            return acc_blk[0, o:o + rows * cols].view(rows, cols)
         for m in range(2):
             X = t[:, m * c:(m + 1) * c]
             # GFE (AM:133-145, 75-109): x + LN(x) + proj(softmax(norm(q) norm(k)^T * temp) v) * scale2
@@ -1034,10 +1045,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             q2 = ws.get("nk_q2", P, 3 * c)
             ops.gconv(y, gp["q1"], None, q1, B, h, w, 32, c // 32, 3 * c // 32, 1)
             ops.gconv(q1, gp["q2"], None, q2, B, h, w, 32, 3 * c // 32, 3 * c // 32, 3)
-            st = ws.get("nk_st", B * 3, 3 * c, dtype=torch.float64)
-            ops.colstats(q2, HW * 3 * c, B, HW, st)
-            g = ws.get("nk_gram", B * c, c, dtype=torch.float64)
-            ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8)
+            st = acc_buf(B * 3, 3 * c)
+            ops.colstats(q2, HW * 3 * c, B, HW, st, out_is_zero=True)
+            g = acc_buf(B * c, c)
+            ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8, out_is_zero=True)
             cp = ops.pad32(c)
             pl = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
             base = st.data_ptr()
@@ -1059,8 +1070,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 ops.dwconv(h1, lp["dw"], None, h2, B, h, w, 3, act="relu6")
                 ops.gemm(h2, lp["w3"], lcat[:, m * c:(m + 1) * c], alpha=lp["scale"], resid=X)
         # GFFM (AM:242-267)
-        e = ws.get("nk_gram", B * c, c, dtype=torch.float64)
-        ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1)
+        e = acc_buf(B * c, c)
+        ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1, out_is_zero=True)
         cp = ops.pad32(c)
         px = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
         py = ops.Planes(ws.get(f"nk_pp2{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
@@ -1071,8 +1082,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ops.gemm(gcat_p.cols(0, c) if pl_ok else gcat[:, :c], py, fbuf[:, c:], alpha=lv["gy"], resid=gcat[:, c:], batch=B, m=HW,
                  stride_a=HW * C * (2 if pl_ok else 1), stride_w=c * 2 * cp, stride_r=HW * C, stride_c=HW * C)
         # LayerNorm over H*W (AM:265) + FFRM (AM:158-162), one apply pass
-        st = ws.get("nk_st", B * 3, C, dtype=torch.float64)
-        ops.colstats(fbuf, HW * C, B, HW, st, wrow=lv["lnw"])
+        st = acc_buf(B * 3, C)
+        ops.colstats(fbuf, HW * C, B, HW, st, wrow=lv["lnw"], out_is_zero=True)
         mean = ws.get("nk_mean", B, C)
         rstd = ws.get("nk_rstd", B, C)
         mult = ws.get("nk_mult", B, C)

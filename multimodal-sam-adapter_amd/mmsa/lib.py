@@ -51,7 +51,7 @@ SIGNATURES = {
     "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_relpos_bias_planes": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, I, L, L, I, I, P],
-    "mmsa_colstats": [P, L, L, P, I, I, I, P, P],
+    "mmsa_colstats": [P, L, L, P, I, I, I, P, I, P],
     "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P, P],
     "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
     "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, I, P],
@@ -59,7 +59,7 @@ SIGNATURES = {
     "mmsa_dwpair_gate": [P, L, P, P, L, P, L, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],
     "mmsa_im2col_nchw": [P, I, I, I, I, I, I, I, P, I, P],
-    "mmsa_gram_tn": [P, L, P, L, L, P, I, I, I, I, P],
+    "mmsa_gram_tn": [P, L, P, L, L, P, I, I, I, I, I, P],
     "mmsa_chanattn_build": [P, P, L, P, L, P, P, P, I, I, I, I, P],
     "mmsa_gffm_build": [P, P, P, I, I, I, P],
     "mmsa_gelu_gate": [P, L, P, L, L, I, P],

@@ -428,9 +428,10 @@ def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
     return out
 
 
-def colstats(x, stride_b, b, hw, out, wrow=None):
+def colstats(x, stride_b, b, hw, out, wrow=None, out_is_zero=False):
+    """out_is_zero: the caller has zeroed `out` on the current stream (one memset for several accumulator buffers)."""
     px, _, c, ldx = _mat(x, "x")
-    lib.call("mmsa_colstats", px, ldx, stride_b, _chk(wrow), b, hw, c, _chk(out, torch.float64), _stream())
+    lib.call("mmsa_colstats", px, ldx, stride_b, _chk(wrow), b, hw, c, _chk(out, torch.float64), int(out_is_zero), _stream())
     return out
 
 
@@ -508,11 +509,12 @@ def im2col_nchw(x, c0, cin, p, out):
     return out
 
 
-def gram_tn(x, y, stride_b, g, b, p, nblk=1):
-    """G[b] = X[b]^T Y[b] -> float64 [B*c, c] (the row slices are combined in double: run-to-run identical)."""
+def gram_tn(x, y, stride_b, g, b, p, nblk=1, out_is_zero=False):
+    """G[b] = X[b]^T Y[b] -> float64 [B*c, c] (the row slices are combined in double: run-to-run identical).
+    out_is_zero: as for colstats."""
     px, _, c, ldx = _mat(x, "X")
     py, _, _, ldy = _mat(y, "Y")
-    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g, torch.float64, "G"), b, p, c, nblk, _stream())
+    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g, torch.float64, "G"), b, p, c, nblk, int(out_is_zero), _stream())
     return g
 
 

@@ -174,11 +174,11 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
     assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws} vf={vf}")
     with pytest.raises(RuntimeError):
         ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, 15, hd ** -0.5)
-    if vf:   # the one-barrier kernel (double-buffered hi-only K / V images: the default for this form) and the three-barrier one agree bit for bit
+    if vf:   # the one-barrier kernel (double-buffered hi-only K / V images; opt-in) and the three-barrier one agree bit for bit
         from mmsa import lib
         ao3 = ops.alloc_planes(B * T, D, DEV)
         try:
-            lib.call("mmsa_debug_wattn_flavour", 1)
+            lib.call("mmsa_debug_wattn_flavour", 2)
             ops.window_attention(qkv, biasp, relp, ao3, B, H, W, heads, hd, ws, hd ** -0.5)
         finally:
             lib.call("mmsa_debug_wattn_flavour", 0)

@@ -1,5 +1,5 @@
 """Same-box A/B of environment settings: each variant is bench.py in its own process, variants interleaved over several rounds.
-    python tools/ab_env.py [--rounds 2] [--steps 20] [--verify] name1:VAR=val,VAR2=val name2: ...
+    python tools/ab_env.py [--rounds 2] [--steps 20] [--verify] name1:VAR=val+VAR2=val name2: ...
 (an empty setting list = the default build).  Prints ms/step per run and the per-variant minimum; with --verify also the golden probe
 error of the timed path (`verified.golden_max_rel`)."""
 import json
@@ -22,7 +22,7 @@ while args and args[0].startswith("--"):
 variants = []
 for a in args:
     name, _, sets = a.partition(":")
-    env = dict(kv.split("=", 1) for kv in sets.split(",") if kv)
+    env = dict(kv.split("=", 1) for kv in sets.split("+") if kv)
     variants.append((name, env))
 best = {}
 for rnd in range(rounds):

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 extern "C" void launch_slp_on(const float*, long, const float*, float*, long, int, int, int, int, hipStream_t);
 extern "C" void launch_slp_off(const float*, long, const float*, float*, long, int, int, int, int, hipStream_t);
@@ -33,10 +34,20 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
   hipStream_t s0, s1;
   CK(hipStreamCreate(&s0)); CK(hipStreamCreate(&s1));
-  std::vector<float> ref(rows * ldy), got(rows * ldy);
+  // each build is compared with ITS OWN first, undisturbed launch (the two builds round differently: the vectorised one contracts other
+  // multiply-add pairs), so a mismatch means a launch of the same code object on the same inputs returned different bits
+  std::vector<float> ref_on(rows * ldy), ref_off(rows * ldy), got(rows * ldy);
   launch_slp_off(x, ldx, w, y0, ldy, B, H, W, C, s0);
   CK(hipStreamSynchronize(s0));
-  CK(hipMemcpy(ref.data(), y0, ref.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(ref_off.data(), y0, ref_off.size() * 4, hipMemcpyDeviceToHost));
+  launch_slp_on(x, ldx, w, y0, ldy, B, H, W, C, s0);
+  CK(hipStreamSynchronize(s0));
+  CK(hipMemcpy(ref_on.data(), y0, ref_on.size() * 4, hipMemcpyDeviceToHost));
+  {
+    double md = 0;
+    for (size_t i = 0; i < ref_on.size(); ++i) { const double d = fabs((double)ref_on[i] - ref_off[i]); md = d > md ? d : md; }
+    printf("max |SLP build - scalar build| = %.3g (rounding only)\n", md);
+  }
   long bad_on_alone = 0, bad_on_busy = 0, bad_off_busy = 0, launches = 0;
   for (int mode = 0; mode < 3; ++mode) {     // 0: SLP build alone; 1: SLP build beside the busy stream; 2: scalar build beside the busy stream
     for (int r = 0; r < rounds; ++r) {
@@ -45,6 +56,7 @@ int main(int argc, char** argv) {
       if (mode == 2) launch_slp_off(x, ldx, w, y1, ldy, B, H, W, C, s0); else launch_slp_on(x, ldx, w, y1, ldy, B, H, W, C, s0);
       CK(hipStreamSynchronize(s0));
       CK(hipMemcpy(got.data(), y1, got.size() * 4, hipMemcpyDeviceToHost));
+      const std::vector<float>& ref = mode == 2 ? ref_off : ref_on;
       long bad = 0;
       for (size_t i = 0; i < got.size(); ++i) bad += memcmp(&got[i], &ref[i], 4) != 0;
       if (bad && (bad_on_alone + bad_on_busy + bad_off_busy) == 0) {

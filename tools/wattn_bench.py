@@ -19,8 +19,8 @@ from mmsa import lib
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 50
 best = {}
-for rnd in range(3):          # the two persistent kernels interleaved in one process (flavour 1 = three barriers per item)
-    for fl in ((0, 1) if vf else (0,)):
+for rnd in range(3):          # the two persistent kernels interleaved in one process (flavour 1 = three barriers per item, 2 = one)
+    for fl in ((2, 1) if vf else (0,)):
         lib.call("mmsa_debug_wattn_flavour", fl)
         for _ in range(3):
             ops.window_attention(qkv, bias, relp, out, B, H, W, heads, hd, ws, hd ** -0.5)
@@ -31,5 +31,5 @@ for rnd in range(3):          # the two persistent kernels interleaved in one pr
         e1.record(); torch.cuda.synchronize()
         best[fl] = min(best.get(fl, 1e9), e0.elapsed_time(e1) / n * 1e3)
 lib.call("mmsa_debug_wattn_flavour", 0)
-print(f"wattn B={B} vf={vf}: " + ", ".join(f"{'one barrier' if fl == 0 and vf else 'three barriers'} {us:.1f} us" for fl, us in best.items())
+print(f"wattn B={B} vf={vf}: " + ", ".join(f"{'one barrier' if fl == 2 else 'three barriers'} {us:.1f} us" for fl, us in best.items())
       + f" per launch (debug={os.environ.get('MMSA_WATTN_DEBUG', '0')})")
