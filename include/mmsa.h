@@ -209,8 +209,12 @@ int mmsa_im2col_nchw(const float* x, int B, int Ctot, int c0, int Cin, int H, in
                      mmsa_stream_t stream);
 
 /* --- modality-fusion neck pieces (AM:75-109, 234-267, 110-132, 176-221) ------------------------------------- */
-int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G /* [B,c,c] double: order-independent sum */, int B, int P, int c,
-                 int nblk, int out_is_zero /* as for mmsa_colstats */, mmsa_stream_t stream);
+/* G[b] = X[b]^T Y[b] over the P rows of each image: fp32 MFMA per 256-row slice, the slices summed in double in slice order (deterministic;
+ * G needs no zeroing).  nblk > 1: only the entries of the nblk diagonal head blocks (c / nblk channels each) are written.  `scratch`:
+ * caller-owned, >= mmsa_gram_tn_scratch_bytes(B, P, c) bytes, 16-byte aligned (the per-slice partial sums). */
+long mmsa_gram_tn_scratch_bytes(int B, int P, int c);
+int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G /* [B,c,c] */, int B, int P, int c,
+                 int nblk, void* scratch, long scratch_bytes, mmsa_stream_t stream);
 int mmsa_chanattn_build(const double* G, const double* sq, long sq_strideB, const double* sk, long sk_strideB,
                         const float* temp, const float* Wp, uint16_t* planes /* [B,c,2*cpad] */, int B, int c, int cpad,
                         int heads, mmsa_stream_t stream);

@@ -13,74 +13,143 @@
 #include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
-#define GR_ROWS 1024   // rows of X/Y per workgroup (4 waves x 256)
-__global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
-                                                      long strideB, double* __restrict__ G, int P, int c, int nblk) {
-  const int nt = (c + 31) / 32;
-  const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
-  if (nblk > 1) {  // only tiles that intersect a diagonal head block are needed
-    const int ch = c / nblk;
-    const int hi0 = (32 * ti) / ch, hi1 = min(c - 1, 32 * ti + 31) / ch;
-    const int hj0 = (32 * tj) / ch, hj1 = min(c - 1, 32 * tj + 31) / ch;
-    if (hi1 < hj0 || hj1 < hi0) return;
-  }
+// gram_tn, two kernels and no atomics (round 3).  The first version gave a workgroup one 32 x 32 output tile: X and Y were read c / 32
+// times each (3 x at c = 96 ... 24 x at c = 768) and every wave added its 1024 partial sums to G with double-precision atomics --
+// 2.4 M atomics per image at level 0, 61 us per launch on average, a memset per call in front.  Now:
+//   gram_part_kernel : a workgroup owns 256 rows (as a wave did before: the same fp32 partial sums) and a 96 x 96 block of G (36
+//                      accumulator tiles, 9 per wave): X and Y come from HBM c / 96 times; diagonal-head-block mode (nblk > 1) visits only
+//                      the blocks a head touches.  The tiles go to a scratch buffer in the MFMA's own lane layout (one float4 per lane
+//                      and tile).  (One wave per 96 x 96 block and slice -- 36 tiles, a quarter of the waves -- ran at 100 us per launch:
+//                      too few waves to cover the load latency.)
+//   gram_sum_kernel  : sums the row slices in DOUBLE, in slice order (16 groups of slices per workgroup, combined through LDS in
+//                      fixed order): deterministic by construction, G needs no zeroing.
+#define GR_ROWS 256    // rows of X / Y per wave
+#define GR_BLK 96      // columns of X / of Y per block
+#define GR_T 6         // 16-column tiles per block side
+__device__ __forceinline__ bool gram_block_needed(int bi, int bj, int c, int nblk) {
+  if (nblk <= 1) return true;
+  const int ch = c / nblk;
+  const int hi0 = (GR_BLK * bi) / ch, hi1 = min(c - 1, GR_BLK * bi + GR_BLK - 1) / ch;
+  const int hj0 = (GR_BLK * bj) / ch, hj1 = min(c - 1, GR_BLK * bj + GR_BLK - 1) / ch;
+  return !(hi1 < hj0 || hj1 < hi0);
+}
+// grid (nb * nb, nslice, B), 256 threads: the four waves of a workgroup share the slice's rows (the second reader of a row hits L1) and
+// own 3 x 3 of the block's 6 x 6 accumulator tiles each; part: [B][nb * nb][nslice][36][64] float4
+__global__ __launch_bounds__(256) void gram_part_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
+                                                        long strideB, float4* __restrict__ part, int P, int c, int nblk, int nslice) {
+  const int nb = (c + GR_BLK - 1) / GR_BLK;
+  const int bi = blockIdx.x / nb, bj = blockIdx.x % nb;
+  if (!gram_block_needed(bi, bj, c, nblk)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, kk = lane >> 4;
   const int b = blockIdx.z;
+  const int slice = blockIdx.y;
+  const int u0 = 3 * (wave >> 1), v0 = 3 * (wave & 1);
   const float* Xb = X + (long)b * strideB;
   const float* Yb = Y + (long)b * strideB;
-  const int i0 = 32 * ti + l15, i1 = i0 + 16;
-  const int j0 = 32 * tj + l15, j1 = j0 + 16;
-  const bool vi0 = i0 < c, vi1 = i1 < c, vj0 = j0 < c, vj1 = j1 < c;
-  f32x4 acc[2][2];
+  // columns beyond c / rows beyond the slice: the load goes to column c - 1 / the slice's first row (always valid) and the value is
+  // multiplied by 0 -- UNCONDITIONAL loads, so that 48 of them are in flight (with predicated loads, or a select the compiler may turn
+  // back into one, every load sat behind its own exec-masked branch and a full wait: 40 us per launch at every size, pure latency)
+  float mi[3], mj[3];
+  int ci[3], cj[3];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int v = 0; v < 2; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int pbeg = blockIdx.y * GR_ROWS + wave * (GR_ROWS / 4);
-  const int pend = min(P, pbeg + GR_ROWS / 4);
-  // unrolled x8 so that 32 independent loads are in flight per lane (rolled, every iteration waited for its own 4 loads)
-#pragma unroll 8
-  for (int pb = pbeg; pb < pend; pb += 4) {   // wave-uniform trip count (MFMA needs full EXEC)
-    const int p = pb + kk;
-    const bool vp = p < pend;  // pend - pbeg may not be a multiple of 4
-    const float* xr = Xb + (long)(vp ? p : pbeg) * ldx;
-    const float* yr = Yb + (long)(vp ? p : pbeg) * ldy;
-    const float a0 = (vp && vi0) ? xr[i0] : 0.f;
-    const float a1 = (vp && vi1) ? xr[i1] : 0.f;
-    const float b0 = (vp && vj0) ? yr[j0] : 0.f;
-    const float b1 = (vp && vj1) ? yr[j1] : 0.f;
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+  for (int u = 0; u < 3; ++u) {
+    const int i_ = GR_BLK * bi + 16 * (u0 + u) + l15, j_ = GR_BLK * bj + 16 * (v0 + u) + l15;
+    mi[u] = i_ < c ? 1.f : 0.f; mj[u] = j_ < c ? 1.f : 0.f;
+    ci[u] = min(i_, c - 1); cj[u] = min(j_, c - 1);
   }
-  double* Gb = G + (long)b * c * c;
+  f32x4 acc[3][3];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < 3; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < 3; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int pbeg = slice * GR_ROWS;
+  const int pend = min(P, pbeg + GR_ROWS);
+  // 32 rows per trip: the 48 loads of eight MFMA k-steps are issued before the first MFMA (a `#pragma unroll 8` on the 4-row loop was not
+  // honoured: runtime trip count), and the loads of trip i + 1 before the MFMAs of trip i (two register sets)
+#define GR_LOADS(av_, bv_, pb_)                                                                   \
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                 \
+    const int p = (pb_) + 4 * t + kk;                                                             \
+    const long pr = p < pend ? p : pbeg;   /* pend - pbeg may not be a multiple of 32 */          \
+    const float* xr = Xb + pr * ldx;                                                              \
+    const float* yr = Yb + pr * ldy;                                                              \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u) { av_[t][u] = xr[ci[u]]; bv_[t][u] = yr[cj[u]]; } \
+  }
+#define GR_MFMAS(av_, bv_, pb_)                                                                   \
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                 \
+    const float mp = ((pb_) + 4 * t + kk) < pend ? 1.f : 0.f;                                     \
+    /* value * {1, 0}: a select would let the compiler sink the load back under its condition */  \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u) { av_[t][u] *= mp * mi[u]; bv_[t][u] *= mp * mj[u]; } \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u)                                                 \
+      _Pragma("unroll") for (int v = 0; v < 3; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[t][u], bv_[t][v], acc[u][v], 0, 0, 0); \
+  }
+  float a0[8][3], b0[8][3], a1[8][3], b1[8][3];
+  GR_LOADS(a0, b0, pbeg)
+#pragma unroll 1
+  for (int pb = pbeg; pb < pend; pb += 64) {   // wave-uniform trip count (MFMA needs full EXEC); rows beyond pend are masked to zero
+    __builtin_amdgcn_sched_barrier(0);
+    GR_LOADS(a1, b1, pb + 32)
+    __builtin_amdgcn_sched_barrier(0);   // loads before the first use (the scheduler otherwise sinks them to their uses: 2-5 in flight)
+    GR_MFMAS(a0, b0, pb)
+    __builtin_amdgcn_sched_barrier(0);
+    GR_LOADS(a0, b0, pb + 64)
+    __builtin_amdgcn_sched_barrier(0);
+    GR_MFMAS(a1, b1, pb + 32)
+  }
+#undef GR_LOADS
+#undef GR_MFMAS
+  float4* dst = part + ((((long)b * nb * nb + blockIdx.x) * nslice + slice) * (GR_T * GR_T)) * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 32 * ti + 16 * u + 4 * kk + r;   // D row = 4*(lane>>4) + r
-        const int j = 32 * tj + 16 * v + l15;          // D col = lane & 15
-        if (i < c && j < c) atomicAdd(Gb + (long)i * c + j, (double)acc[u][v][r]);
-      }
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) dst[((u0 + u) * GR_T + v0 + v) * 64] = make_float4(acc[u][v][0], acc[u][v][1], acc[u][v][2], acc[u][v][3]);
+}
+// grid (36, nb * nb, B), 1024 threads: wave q sums slices q, q + 16, ... of one tile; the 16 sums are then added in order q = 0..15
+__global__ __launch_bounds__(1024) void gram_sum_kernel(const float4* __restrict__ part, double* __restrict__ G, int c, int nblk, int nslice) {
+  __shared__ double red[16][64][4];
+  const int nb = (c + GR_BLK - 1) / GR_BLK;
+  const int bi = blockIdx.y / nb, bj = blockIdx.y % nb;
+  if (!gram_block_needed(bi, bj, c, nblk)) return;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int tile = blockIdx.x, b = blockIdx.z;
+  const float4* src = part + (((long)b * nb * nb + blockIdx.y) * nslice * (GR_T * GR_T) + tile) * 64 + lane;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 4
+  for (int sl = q; sl < nslice; sl += 16) {
+    const float4 v = src[(long)sl * (GR_T * GR_T) * 64];
+    s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+  }
+  red[q][lane][0] = s0; red[q][lane][1] = s1; red[q][lane][2] = s2; red[q][lane][3] = s3;
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int ln = threadIdx.x >> 2, r = threadIdx.x & 3;
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][ln][r];
+    const int u = tile / GR_T, v = tile % GR_T;
+    const int i = GR_BLK * bi + 16 * u + 4 * (ln >> 4) + r;   // D row = 4 * (lane >> 4) + r
+    const int j = GR_BLK * bj + 16 * v + (ln & 15);          // D col = lane & 15
+    if (i < c && j < c) G[((long)b * c + i) * c + j] = t;
+  }
 }
 
-// out_is_zero != 0: the caller has zeroed G on this stream already (backbone: ONE memset per neck level covers the six accumulator
-// buffers of the level, instead of one memset node per call: 24 -> 4 per forward)
+extern "C" long mmsa_gram_tn_scratch_bytes(int B, int P, int c) {
+  if (B <= 0 || P <= 0 || c <= 0) return 0;
+  const long nb = cdiv(c, GR_BLK);
+  return (long)B * nb * nb * cdiv(P, GR_ROWS) * (GR_T * GR_T) * 64 * (long)sizeof(float4);
+}
+
 extern "C" int mmsa_gram_tn(const float* X, long ldx, const float* Y, long ldy, long strideB, double* G,
-                            int B, int P, int c, int nblk, int out_is_zero, hipStream_t stream) {
-  MMSA_CHECK_ARG(X && Y && G && B > 0 && P > 0 && c > 0 && nblk > 0 && c % nblk == 0, "gram_tn: bad args");
-  if (!out_is_zero && hipMemsetAsync(G, 0, sizeof(double) * (size_t)B * c * c, stream) != hipSuccess) {
-    mmsa_set_error("gram_tn: memset failed");
-    return MMSA_ERR_LAUNCH;
-  }
-  const int nt = cdiv(c, 32);
-  dim3 grid(nt * nt, cdiv(P, GR_ROWS), B);
-  hipLaunchKernelGGL(gram_tn_kernel, grid, dim3(256), 0, stream, X, ldx, Y, ldy, strideB, G, P, c, nblk);
+                            int B, int P, int c, int nblk, void* scratch, long scratch_bytes, hipStream_t stream) {
+  MMSA_CHECK_ARG(X && Y && G && scratch && B > 0 && P > 0 && c > 0 && nblk > 0 && c % nblk == 0, "gram_tn: bad args");
+  MMSA_CHECK_ARG(scratch_bytes >= mmsa_gram_tn_scratch_bytes(B, P, c) && (((uintptr_t)scratch) & 15) == 0,
+                 "gram_tn: scratch of %ld bytes, %ld needed (mmsa_gram_tn_scratch_bytes), 16-byte aligned", scratch_bytes, mmsa_gram_tn_scratch_bytes(B, P, c));
+  const int nb = cdiv(c, GR_BLK), nslice = cdiv(P, GR_ROWS);
+  hipLaunchKernelGGL(gram_part_kernel, dim3(nb * nb, nslice, B), dim3(256), 0, stream, X, ldx, Y, ldy, strideB,
+                     reinterpret_cast<float4*>(scratch), P, c, nblk, nslice);
   MMSA_CHECK_LAUNCH("gram_tn");
+  hipLaunchKernelGGL(gram_sum_kernel, dim3(GR_T * GR_T, nb * nb, B), dim3(1024), 0, stream, reinterpret_cast<const float4*>(scratch), G, c, nblk, nslice);
+  MMSA_CHECK_LAUNCH("gram_tn (slice sum)");
   return MMSA_OK;
 }
 

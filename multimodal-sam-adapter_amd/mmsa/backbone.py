@@ -1023,16 +1023,17 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         pl_ok = tp is not None and c % 32 == 0
         gcat_p = ws.planes("nk_gp", P, C) if pl_ok else None
         lcat_p = ws.planes("nk_lp", P, C) if pl_ok else None
-        # the level's six double-precision accumulator buffers (column statistics and Grams: atomically summed row slices) are slices of
-        # ONE block zeroed by ONE memset at the head of the level -- a memset node per call was 24 per forward (0.1-0.2 ms per step)
+        # the level's three double-precision column-statistics buffers (atomically summed row slices) are slices of ONE block zeroed by
+        # ONE memset at the head of the level -- a memset node per call was 24 per forward (0.1-0.2 ms per step; the Grams need none)
         n_st, n_g, n_st2 = B * 3 * 3 * c, B * c * c, B * 3 * C
         acc_blk = ws.get("nk_acc", 1, 2 * (n_st + n_g) + n_g + n_st2, dtype=torch.float64)
-        acc_blk.zero_()
-        acc_off = [0]
+        acc_blk[0, :2 * n_st + n_st2].zero_()
+        gram_scr = ws.get("nk_gscr", 1, (ops.gram_tn_scratch_bytes(B, HW, c) + 3) // 4)
+        acc_off = [0, 2 * n_st + n_st2]
 
-        def acc_buf(rows, cols):
-            o = acc_off[0]
-            acc_off[0] = o + rows * cols
+        def acc_buf(rows, cols, gram=False):   # statistics from the zeroed head of the block, Grams behind it
+            o = acc_off[int(gram)]
+            acc_off[int(gram)] = o + rows * cols
             return acc_blk[0, o:o + rows * cols].view(rows, cols)
         for m in range(2):
             X = t[:, m * c:(m + 1) * c]
@@ -1047,8 +1048,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.gconv(q1, gp["q2"], None, q2, B, h, w, 32, 3 * c // 32, 3 * c // 32, 3)
             st = acc_buf(B * 3, 3 * c)
             ops.colstats(q2, HW * 3 * c, B, HW, st, out_is_zero=True)
-            g = acc_buf(B * c, c)
-            ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8, out_is_zero=True)
+            g = acc_buf(B * c, c, gram=True)
+            ops.gram_tn(q2[:, :c], q2[:, c:2 * c], HW * 3 * c, g, B, HW, nblk=8, scratch=gram_scr)
             cp = ops.pad32(c)
             pl = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
             base = st.data_ptr()
@@ -1070,8 +1071,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 ops.dwconv(h1, lp["dw"], None, h2, B, h, w, 3, act="relu6")
                 ops.gemm(h2, lp["w3"], lcat[:, m * c:(m + 1) * c], alpha=lp["scale"], resid=X)
         # GFFM (AM:242-267)
-        e = acc_buf(B * c, c)
-        ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1, out_is_zero=True)
+        e = acc_buf(B * c, c, gram=True)
+        ops.gram_tn(gcat[:, :c], gcat[:, c:], HW * C, e, B, HW, nblk=1, scratch=gram_scr)
         cp = ops.pad32(c)
         px = ops.Planes(ws.get(f"nk_pp{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)
         py = ops.Planes(ws.get(f"nk_pp2{c}", B * c, 2 * cp, dtype=torch.int16, zero=True), c, c, cp)

@@ -59,7 +59,8 @@ SIGNATURES = {
     "mmsa_dwpair_gate": [P, L, P, P, L, P, L, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],
     "mmsa_im2col_nchw": [P, I, I, I, I, I, I, I, P, I, P],
-    "mmsa_gram_tn": [P, L, P, L, L, P, I, I, I, I, I, P],
+    "mmsa_gram_tn": [P, L, P, L, L, P, I, I, I, I, P, L, P],
+    "mmsa_gram_tn_scratch_bytes": [I, I, I],
     "mmsa_chanattn_build": [P, P, L, P, L, P, P, P, I, I, I, I, P],
     "mmsa_gffm_build": [P, P, P, I, I, I, P],
     "mmsa_gelu_gate": [P, L, P, L, L, I, P],
@@ -77,7 +78,7 @@ SIGNATURES = {
     "mmsa_crop_batch_nchw": [P, I, I, I, I, P, I, P, I, I, P],
     "mmsa_slide_argmax": [P, I, I, I, I, P, P, I, I, I, I, I, P, P],
 }
-_RESTYPES = {"mmsa_last_error": c_char_p}
+_RESTYPES = {"mmsa_last_error": c_char_p, "mmsa_gram_tn_scratch_bytes": c_long}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch

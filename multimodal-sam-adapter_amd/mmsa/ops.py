@@ -509,12 +509,23 @@ def im2col_nchw(x, c0, cin, p, out):
     return out
 
 
-def gram_tn(x, y, stride_b, g, b, p, nblk=1, out_is_zero=False):
-    """G[b] = X[b]^T Y[b] -> float64 [B*c, c] (the row slices are combined in double: run-to-run identical).
-    out_is_zero: as for colstats."""
+def gram_tn_scratch_bytes(b, p, c):
+    return int(lib.raw.mmsa_gram_tn_scratch_bytes(b, p, c))
+
+
+def gram_tn(x, y, stride_b, g, b, p, nblk=1, scratch=None):
+    """G[b] = X[b]^T Y[b] -> float64 [B*c, c]: fp32 MFMA per 256-row slice, the slices summed in double in slice order (run-to-run
+    identical, no zeroing of G needed).  scratch: a float32 / uint8 buffer of >= gram_tn_scratch_bytes(b, p, c) bytes (allocated here
+    when None -- the backbone passes a workspace buffer)."""
     px, _, c, ldx = _mat(x, "X")
     py, _, _, ldy = _mat(y, "Y")
-    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g, torch.float64, "G"), b, p, c, nblk, int(out_is_zero), _stream())
+    need = gram_tn_scratch_bytes(b, p, c)
+    if scratch is None:
+        scratch = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    if not scratch.is_cuda or not scratch.is_contiguous():
+        raise RuntimeError("gram_tn: scratch must be a contiguous device tensor")
+    lib.call("mmsa_gram_tn", px, ldx, py, ldy, stride_b, _chk(g, torch.float64, "G"), b, p, c, nblk, scratch.data_ptr(),
+             scratch.numel() * scratch.element_size(), _stream())
     return g
 
 

@@ -3,7 +3,9 @@
 TAG=${1:-r02_c}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^E    .*tensor(\[" | tail -5 > gpurun_out/$TAG/tests.txt
+# (verbose, straight into a file under gpurun_out/: a run that prints nothing for 7 minutes is taken to be hung)
+timeout -k 10 1500 python -m pytest tests -x -v -m gpu --durations=10 > gpurun_out/$TAG/tests_full.txt 2>&1
+grep -v "^E    .*tensor(\[" gpurun_out/$TAG/tests_full.txt | tail -16 > gpurun_out/$TAG/tests.txt
 cat gpurun_out/$TAG/tests.txt
 timeout 600 python bench.py 2> gpurun_out/$TAG/bench.err | tail -1 > gpurun_out/$TAG/bench.json
 cat gpurun_out/$TAG/bench.json | cut -c1-1200; tail -2 gpurun_out/$TAG/bench.err
