@@ -466,6 +466,11 @@ def main():
         headline = a.config == "vitl1024" and not STUB
         size = cfg["kwargs"]["img_size"] if not STUB else 0
         arch = {"vitl1024": "ViT-L", "vith1024": "ViT-H", "vitb512": "ViT-B", "tiny256": "tiny fixture model"}[a.config]
+        attn_blocks = None
+        if model is not None and getattr(model, "_packed", None):   # operand precision each ViT block's attention ran at (backbone._attn_mode)
+            modes = [b.get("amode") for b in model._packed["blocks"]]
+            logits = [b.get("max_logit") for b in model._packed["blocks"] if b.get("max_logit") is not None]
+            attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3"), "max_logit": round(max(logits), 2) if logits else None}
         hbm = None
         hfile = latest_profile("hbm_kernels.json")
         if hfile and headline and not a.no_roofline:
@@ -476,14 +481,14 @@ def main():
             "metric": f"images/sec encoder fwd @{size}x{size} RGB+LiDAR {arch}" if not STUB else "stub (no GPU): control path of the N > 1 bench",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) where the 'attnv' site is on; fp32 accumulate, fp32 activations", "data": "synthetic",
+            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, bf16 hi/lo (and bf16 hi/lo block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else
                                 "encoder forward + SegformerHead logits [B,25,H/4,W/4] + all-gather of logits across ranks",
                        "weights": "default init" if a.default_init else "seeded live generator (tests/weights.py), every parameter / buffer non-trivial",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graphed),
-                       "chains_per_gpu": nch, "chains_probe_ms": chain_probe,
+                       "chains_per_gpu": nch, "chains_probe_ms": chain_probe, "attention_blocks": attn_blocks,
                        "collective": ("one RCCL all_gather_into_tensor of the logits per step" if (head is not None and use_dist)
                                       else "none (single rank)" if head is not None else "none (encoder only)")},
             "verified": verified,
