@@ -252,28 +252,28 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
   const int skey = (tid & 7) + 8 * (tid >> 5), squart = (tid >> 3) & 3;
   float4 rk[NF4], rv[NF4];
   uint4 rkh[NU], rkl[NU], rvh[NU], rvl[NU];
+  unsigned kv_keep = 0xffffffffu;   // 0 for a key beyond Nk: its staged registers hold a valid row's bytes and are zeroed on the way into LDS
+  auto and4 = [](uint4 v, unsigned m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); };
 #define LOAD_KV(kb_)                                                                         \
   do {                                                                                       \
     const int tk_ = token_of((kb_) * 64 + skey);                                             \
     if constexpr (PL) {                                                                      \
+      /* ONE unconditional load per register: a token row, or the qkv bias row for a pad token (tk_ == -1) and -- as a valid   \
+         address only -- for a key that does not exist (tk_ == -2: zeroed afterwards).  The three-way `if` around the loads      \
+         compiled to exec-masked loads into the same registers with a full vmcnt wait between them (write-after-write): two       \
+         exposed memory round trips per key block, ~3 of the 4.6 us a block took */                                            \
+      const unsigned short* rowp_ = tk_ >= 0 ? pq_b + (long)tk_ * a.ldq : a.bp;                                                \
+      const unsigned keep_ = tk_ == -2 ? 0u : 0xffffffffu;                                                                     \
       _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                       \
         const int c = squart * (HD / 4) + 8 * i;                                             \
-        if (tk_ >= 0) {                                                                      \
-          const unsigned short* kr_ = pq_b + (long)tk_ * a.ldq + ilv(colk + c);              \
-          const unsigned short* vr_ = pq_b + (long)tk_ * a.ldq + ilv(colv + c);              \
-          rkh[i] = *reinterpret_cast<const uint4*>(kr_);                                     \
-          if constexpr (VF != 2) rkl[i] = *reinterpret_cast<const uint4*>(kr_ + 32);         \
-          rvh[i] = *reinterpret_cast<const uint4*>(vr_);                                     \
-          if constexpr (VF == 0) rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);         \
-        } else if (tk_ == -1) {                                                              \
-          rkh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c));                    \
-          if constexpr (VF != 2) rkl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colk + c) + 32); \
-          rvh[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c));                    \
-          if constexpr (VF == 0) rvl[i] = *reinterpret_cast<const uint4*>(a.bp + ilv(colv + c) + 32); \
-        } else {                                                                             \
-          rkh[i] = make_uint4(0u, 0u, 0u, 0u); rkl[i] = rkh[i]; rvh[i] = rkh[i]; rvl[i] = rkh[i]; \
-        }                                                                                    \
+        const unsigned short* kr_ = rowp_ + ilv(colk + c);                                   \
+        const unsigned short* vr_ = rowp_ + ilv(colv + c);                                   \
+        rkh[i] = *reinterpret_cast<const uint4*>(kr_);                                       \
+        if constexpr (VF != 2) rkl[i] = *reinterpret_cast<const uint4*>(kr_ + 32);           \
+        rvh[i] = *reinterpret_cast<const uint4*>(vr_);                                       \
+        if constexpr (VF == 0) rvl[i] = *reinterpret_cast<const uint4*>(vr_ + 32);           \
       }                                                                                      \
+      kv_keep = keep_;                                                                       \
     } else {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
         const int c = squart * (HD / 4) + 4 * i;                                             \
@@ -297,11 +297,11 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                       \
         const int c = squart * (HD / 4) + 8 * i;                                             \
         const int ko = (c >> 3) * (64 * 16) + skey * 16;                                     \
-        *reinterpret_cast<uint4*>(Khi + ko) = rkh[i];                                        \
-        if constexpr (VF != 2) *reinterpret_cast<uint4*>(Klo + ko) = rkl[i];                 \
+        *reinterpret_cast<uint4*>(Khi + ko) = and4(rkh[i], kv_keep);                         \
+        if constexpr (VF != 2) *reinterpret_cast<uint4*>(Klo + ko) = and4(rkl[i], kv_keep);  \
         const int vo = skey * VSTR + c * 2;                                                  \
-        *reinterpret_cast<uint4*>(Vhi + vo) = rvh[i];                                        \
-        if constexpr (VF == 0) *reinterpret_cast<uint4*>(Vlo + vo) = rvl[i];                 \
+        *reinterpret_cast<uint4*>(Vhi + vo) = and4(rvh[i], kv_keep);                         \
+        if constexpr (VF == 0) *reinterpret_cast<uint4*>(Vlo + vo) = and4(rvl[i], kv_keep);  \
       }                                                                                      \
     } else {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
