@@ -94,21 +94,38 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
   const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int p = 0; p < 4; ++p) acc[p] = bv;
-#pragma unroll 1
-  for (int kh = 0; kh < 7; ++kh) {   // not unrolled: 7 weight vectors live at a time instead of 49 (occupancy)
-    float4 in[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) in[i] = *reinterpret_cast<const float4*>(tile + ((oy + kh) * TW + ox0 + i) * CB + cv * 4);
-#pragma unroll
-    for (int kw = 0; kw < 7; ++kw) {
-      const float4 f = *reinterpret_cast<const float4*>(w + (long)(kh * 7 + kw) * C + c);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        acc[p].x += in[p + kw].x * f.x; acc[p].y += in[p + kw].y * f.y;
-        acc[p].z += in[p + kw].z * f.z; acc[p].w += in[p + kw].w * f.w;
-      }
-    }
+  // The 49 tap weights come from global memory (L1 / L2 hits), one kernel row = 7 vectors at a time (all 49 would cost occupancy).  Loaded
+  // inside the row's loop they were seven dependent load batches per workgroup; now row kh + 1 is requested before row kh is computed
+  // (two register sets, the row loop unrolled by two).
+  float4 fa[7], fb[7];
+#define DW7_LOADW(f_, kh_) _Pragma("unroll") for (int kw = 0; kw < 7; ++kw) f_[kw] = *reinterpret_cast<const float4*>(w + (long)((kh_) * 7 + kw) * C + c);
+#define DW7_ROW(f_, kh_)                                                                                                          \
+  {                                                                                                                               \
+    float4 in[10];                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 10; ++i) in[i] = *reinterpret_cast<const float4*>(tile + ((oy + (kh_)) * TW + ox0 + i) * CB + cv * 4); \
+    _Pragma("unroll") for (int kw = 0; kw < 7; ++kw) {                                                                            \
+      const float4 f = f_[kw];                                                                                                    \
+      _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                             \
+        acc[p].x += in[p + kw].x * f.x; acc[p].y += in[p + kw].y * f.y;                                                           \
+        acc[p].z += in[p + kw].z * f.z; acc[p].w += in[p + kw].w * f.w;                                                           \
+      }                                                                                                                           \
+    }                                                                                                                             \
   }
+  DW7_LOADW(fa, 0)
+#pragma unroll 1
+  for (int kh = 0; kh < 6; kh += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    DW7_LOADW(fb, kh + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    DW7_ROW(fa, kh)
+    __builtin_amdgcn_sched_barrier(0);
+    DW7_LOADW(fa, kh + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    DW7_ROW(fb, kh + 1)
+  }
+  DW7_ROW(fa, 6)
+#undef DW7_LOADW
+#undef DW7_ROW
   const int gy = ty0 + oy;
   if (gy >= H) return;
 #pragma unroll
@@ -116,6 +133,44 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
     const int gx = tx0 + ox0 + p;
     if (gx < W) *reinterpret_cast<float4*>(y + (long)b * ystrideB + ((long)gy * W + gx) * ldy + c) = acc[p];
   }
+}
+
+// 3 x 3 (the ConvFFN's depthwise conv, AM:446-471): the generic kernel above walks its taps with runtime loops and `continue`s -- two
+// dependent loads per tap, nine round trips per thread, 28 us per launch for maps that stream in 7.  Here the nine taps are unrolled,
+// every tap's input vector is loaded UNCONDITIONALLY from a clamped position and bit-masked to +0 where the tap lies outside the map
+// (fma(+0, f, acc) == acc: the same sum of the same terms in the same order), so the 18 loads of a thread are in flight together.
+__global__ __launch_bounds__(256) void dwconv3_nhwc_kernel(const float* __restrict__ x, long ldx, long xstrideB,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long ldy, long ystrideB,
+                                                           unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
+                                                           int B, int H, int W, int C, int act) {
+  const int c4n = C >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= W * c4n) return;
+  const int ww = idx / c4n;
+  const int c = (idx - ww * c4n) * 4;
+  const int hh = blockIdx.y % H, b = blockIdx.y / H;
+  const float* xb = x + (long)b * xstrideB + c;
+  float4 v[9], f[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ih = min(max(hh + t / 3 - 1, 0), H - 1), iw = min(max(ww + t % 3 - 1, 0), W - 1);
+    v[t] = *reinterpret_cast<const float4*>(xb + ((long)ih * W + iw) * ldx);
+    f[t] = *reinterpret_cast<const float4*>(w + (long)t * C + c);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // all 18 loads before the first use
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ih = hh + t / 3 - 1, iw = ww + t % 3 - 1;
+    const unsigned m = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? 0xffffffffu : 0u;
+    acc.x += __uint_as_float(__float_as_uint(v[t].x) & m) * f[t].x; acc.y += __uint_as_float(__float_as_uint(v[t].y) & m) * f[t].y;
+    acc.z += __uint_as_float(__float_as_uint(v[t].z) & m) * f[t].z; acc.w += __uint_as_float(__float_as_uint(v[t].w) & m) * f[t].w;
+  }
+  acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+  const long oo = (long)b * ystrideB + ((long)hh * W + ww) * ldy + c;
+  if (y) *reinterpret_cast<float4*>(y + oo) = acc;
+  if (yp) store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);   // operand planes, either format
 }
 
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
@@ -136,7 +191,11 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   }
   MMSA_CHECK_ARG(imgs_per_group == 0 || imgs_per_group == B, "dwconv_nhwc: image groups are implemented by the tiled 7x7 kernel only");
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
-  hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, k, act);
+  static const bool generic3 = getenv("MMSA_DWCONV3_GENERIC") != nullptr;   // A/B aid
+  if (k == 3 && !generic3 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
+    hipLaunchKernelGGL(dwconv3_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act);
+  else
+    hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, k, act);
   MMSA_CHECK_LAUNCH("dwconv_nhwc");
   return MMSA_OK;
 }
