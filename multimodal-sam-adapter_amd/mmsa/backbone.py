@@ -829,6 +829,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 kh = k[h_]
                 for r0 in range(0, rows, 8192):
                     mx = max(mx, float((q[h_, r0:r0 + 8192] @ kh.t()).abs().max()) * scale)
+            mx = max(mx, bp.get("max_logit", 0.0))   # calibrate_attention: the largest value over every batch shown so far
             bp["max_logit"] = mx
             mode = bp["amode"] = "f16" if mx <= self.ATTN_F16_MAX_LOGIT else "b3"
             if mode == "b3" and bp["qkv"].fmt == ops.FMT_H8:
@@ -837,6 +838,23 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.
                 bp.update(self._block_gemm_planes(self.state_dict(), bp["index"], ops.FMT_B3, self._packed["fold_ln"], x.device))
         return mode
+
+    def calibrate_attention(self, x):
+        """Show the model one more batch for the per-block attention-precision decision (`attention_precision = "auto"`): every block
+        measures its logit range again on `x` (eager forward) and keeps the LARGEST value over all batches it has been shown, so a block
+        only ever moves from fp16 to bf16 hi/lo operands.  The first forward after packing calibrates by itself; call this with a few
+        batches that are representative of the deployment data (the decision is frozen afterwards: later forwards and captured graphs do
+        not measure).  Returns [] when no block changed its mode, else the new list of modes -- graphs captured before the call must then be
+        captured again."""
+        if self._packed is None:
+            self(x)
+            return [b.get("amode") for b in self._packed["blocks"]]
+        before = [b.get("amode") for b in self._packed["blocks"]]
+        for b in self._packed["blocks"]:
+            b.pop("amode", None)
+        self(x)
+        after = [b.get("amode") for b in self._packed["blocks"]]
+        return after if after != before else []
 
     # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)
     def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None, stream_out=None):

@@ -347,6 +347,13 @@ def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_di
     assert all(b["amode"] == "f16" and b["max_logit"] < 8.0 for b in blocks), [(b.get("amode"), b.get("max_logit")) for b in blocks]
     assert all(torch.equal(a, b) for a, b in zip(outs["auto"], outs["f16"]))
     assert not all(torch.equal(a, b) for a, b in zip(outs["b3"], outs["f16"]))
+    # a further calibration batch with the same statistics changes nothing (no block moves, results bit-identical)
+    m.attention_precision = "auto"
+    logits_before = [b["max_logit"] for b in blocks]
+    assert m.calibrate_attention(x.to(DEV)) == []
+    assert [b["max_logit"] for b in blocks] == logits_before and all(b["amode"] == "f16" for b in blocks)
+    fs, _ = m(x.to(DEV))
+    assert all(torch.equal(a, b) for a, b in zip(fs, outs["auto"]))
     # peaky attention: logits x 9
     sd = seeded_state_dict(orc, seed=cfg["seed"])
     D = cfg["kwargs"]["embed_dim"]
