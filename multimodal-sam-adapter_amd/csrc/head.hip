@@ -126,26 +126,40 @@ __global__ __launch_bounds__(256) void head_fuse_kernel(const float* __restrict_
       o01[i] = (base + (long)h0 * lv.W[i] + w1) * ld;
       o10[i] = (base + (long)h1 * lv.W[i] + w0) * ld;
       o11[i] = (base + (long)h1 * lv.W[i] + w1) * ld;
+    } else {
+      o00[i] = o01[i] = o10[i] = o11[i] = 0; lh[i] = lw[i] = 0.f;
     }
   }
   for (int c = lane * 8; c < C; c += 512) {
     float v[8];
-    {
-      const float4 a = *reinterpret_cast<const float4*>(z0 + pixg * ld + c);
-      const float4 d = *reinterpret_cast<const float4*>(z0 + pixg * ld + c + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+    // every load of the pass first (2 + 24 + 4 vectors; a level beyond nlv re-reads level 0's taps and is not added): the per-level `if`
+    // around the loads made each level a separate, fully awaited batch
+    float4 t[3][2][4];
+    const float4 a = *reinterpret_cast<const float4*>(z0 + pixg * ld + c);
+    const float4 d = *reinterpret_cast<const float4*>(z0 + pixg * ld + c + 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int il = i < nlv ? i : 0;
+      const float* zi = (nlv > 0 ? lv.z[il] : z0 + pixg * ld) + c;   // (no level at all: any valid address)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        t[i][hh][0] = *reinterpret_cast<const float4*>(zi + o00[il] + 4 * hh);
+        t[i][hh][1] = *reinterpret_cast<const float4*>(zi + o01[il] + 4 * hh);
+        t[i][hh][2] = *reinterpret_cast<const float4*>(zi + o10[il] + 4 * hh);
+        t[i][hh][3] = *reinterpret_cast<const float4*>(zi + o11[il] + 4 * hh);
+      }
     }
+    const float4 s0 = *reinterpret_cast<const float4*>(bn_scale + c), s1 = *reinterpret_cast<const float4*>(bn_scale + c + 4);
+    const float4 f0 = *reinterpret_cast<const float4*>(bn_shift + c), f1 = *reinterpret_cast<const float4*>(bn_shift + c + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (i < nlv) {
-        const float* zi = lv.z[i] + c;
         const float w00 = (1.f - lh[i]) * (1.f - lw[i]), w01 = (1.f - lh[i]) * lw[i], w10 = lh[i] * (1.f - lw[i]), w11 = lh[i] * lw[i];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const float4 t00 = *reinterpret_cast<const float4*>(zi + o00[i] + 4 * hh);
-          const float4 t01 = *reinterpret_cast<const float4*>(zi + o01[i] + 4 * hh);
-          const float4 t10 = *reinterpret_cast<const float4*>(zi + o10[i] + 4 * hh);
-          const float4 t11 = *reinterpret_cast<const float4*>(zi + o11[i] + 4 * hh);
+          const float4 t00 = t[i][hh][0], t01 = t[i][hh][1], t10 = t[i][hh][2], t11 = t[i][hh][3];
           v[4 * hh + 0] += w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x;
           v[4 * hh + 1] += w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y;
           v[4 * hh + 2] += w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z;
@@ -153,8 +167,9 @@ __global__ __launch_bounds__(256) void head_fuse_kernel(const float* __restrict_
         }
       }
     }
+    const float bs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, bf[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] * bn_scale[c + j] + bn_shift[c + j], act);
+    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] * bs[j] + bf[j], act);
     if (out32) {
       *reinterpret_cast<float4*>(out32 + pixg * ldo + c) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(out32 + pixg * ldo + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -176,6 +191,7 @@ extern "C" int mmsa_head_fuse(const float* z0, const float* z1, int H1, int W1, 
                               int H3, int W3, long ld, const float* bn_scale, const float* bn_shift, uint16_t* planes, long ldp,
                               float* out32, long ldo, int B, int H, int W, int C, int act, hipStream_t stream) {
   MMSA_CHECK_ARG(z0 && bn_scale && bn_shift && (planes || out32), "head_fuse: null pointer");
+  MMSA_CHECK_ARG(((((uintptr_t)bn_scale) | ((uintptr_t)bn_shift) | ((uintptr_t)z0)) & 15) == 0, "head_fuse: z0 / bn_scale / bn_shift must be 16-byte aligned");
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "head_fuse: bad shape (C=%d must be a multiple of 8)", C);
   MMSA_CHECK_ARG(ld >= C && ld % 4 == 0, "head_fuse: row stride %ld", ld);
   MMSA_CHECK_ARG(!planes || (ldp >= 2L * ((C + 31) / 32 * 32) && ldp % 64 == 0 && (reinterpret_cast<uintptr_t>(planes) & 127) == 0),
