@@ -161,41 +161,80 @@ __global__ __launch_bounds__(256) void chanattn_build_kernel(const double* __res
                                                              const float* __restrict__ temp, const float* __restrict__ Wp,
                                                              unsigned short* __restrict__ planes,
                                                              int c, int cpad, int heads) {
-  extern __shared__ float attn[];  // [ch][ch+1]
+  extern __shared__ float attn[];  // [ch][ch+1] logits / softmax, then nq[ch], nk[ch], then this workgroup's weight rows [o_per][ch]
   const int h = blockIdx.x, b = blockIdx.y;
   const int ch = c / heads;
   const int st = ch + 1;
   const double* Gb = G + (long)b * c * c;
   const float t = temp[h];
+  // (1) the L2 norms of this head's q and k channels, (2) every logit of the ch x ch block by all 256 threads, (3) the row softmax by
+  // one thread per row out of LDS.  Element by element the same expressions as the first version (one thread per ROW doing all three
+  // steps: ch dependent double loads per row, 62 us per launch at ch = 96) -- bit-identical results.
+  float* nq = attn + ch * st;   // [ch] | nk [ch] behind the logits
+  float* nk = nq + ch;
   for (int i = threadIdx.x; i < ch; i += 256) {
-    const int gi = h * ch + i;
-    const float nq = fmaxf((float)sqrt(sq[(long)b * sq_strideB + gi]), 1e-12f);
-    float mx = -INFINITY;
-    for (int j = 0; j < ch; ++j) {
-      const int gj = h * ch + j;
-      const float nk = fmaxf((float)sqrt(sk[(long)b * sk_strideB + gj]), 1e-12f);
-      const float v = (float)Gb[(long)gi * c + gj] / (nq * nk) * t;
-      attn[i * st + j] = v;
-      mx = fmaxf(mx, v);
+    nq[i] = fmaxf((float)sqrt(sq[(long)b * sq_strideB + h * ch + i]), 1e-12f);
+    nk[i] = fmaxf((float)sqrt(sk[(long)b * sk_strideB + h * ch + i]), 1e-12f);
+  }
+  __syncthreads();
+  for (int idx0 = threadIdx.x; idx0 < ch * ch; idx0 += 256 * 4) {   // four independent double loads in flight per lane
+    double gv[4];
+    int ii[4], jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(idx0 + 256 * u, ch * ch - 1);
+      ii[u] = idx / ch; jj[u] = idx - ii[u] * ch;
+      gv[u] = Gb[(long)(h * ch + ii[u]) * c + h * ch + jj[u]];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (idx0 + 256 * u < ch * ch) attn[ii[u] * st + jj[u]] = (float)gv[u] / (nq[ii[u]] * nk[jj[u]]) * t;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ch; i += 256) {
+    float mx = -INFINITY;
+#pragma unroll 8
+    for (int j = 0; j < ch; ++j) mx = fmaxf(mx, attn[i * st + j]);
     float s = 0.f;
+#pragma unroll 4
     for (int j = 0; j < ch; ++j) {
       const float e = expf(attn[i * st + j] - mx);
       attn[i * st + j] = e;
       s += e;
     }
     const float inv = 1.0f / s;
+#pragma unroll 8
     for (int j = 0; j < ch; ++j) attn[i * st + j] *= inv;
   }
   __syncthreads();
   // output rows are split over gridDim.z workgroups (each recomputes the small softmax block above)
   const int o_per = (c + gridDim.z - 1) / gridDim.z;
   const int o_beg = blockIdx.z * o_per, o_end = min(c, o_beg + o_per);
+  // this workgroup's rows of the projection weight (columns of head h) go to LDS first: the product loop then runs out of LDS
+  // (it read one weight per iteration from global memory: 70 us per launch at ch = 96); the sum over i keeps its order
+  float* wl = nk + ch;   // [o_per][ch]
+  {
+    const int nw = (o_end - o_beg) * ch;
+    for (int idx0 = threadIdx.x; idx0 < nw; idx0 += 256 * 4) {   // four independent loads in flight per lane
+      float wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(idx0 + 256 * u, nw - 1);
+        const int o = idx / ch, i = idx - o * ch;
+        wv[u] = Wp[(long)(o_beg + o) * c + h * ch + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (idx0 + 256 * u < nw) wl[idx0 + 256 * u] = wv[u];
+    }
+  }
+  __syncthreads();
   for (int idx = o_beg * ch + threadIdx.x; idx < o_end * ch; idx += 256) {
     const int o = idx / ch, j = idx - o * ch;
-    const float* wrow = Wp + (long)o * c + h * ch;
+    const float* wrow = wl + (o - o_beg) * ch;
     float acc = 0.f;
-    for (int i = 0; i < ch; ++i) acc += wrow[i] * attn[i * st + j];
+#pragma unroll 8
+    for (int i = 0; i < ch; ++i) acc += wrow[i] * attn[i * st + j];   // (unrolled: the LDS reads of eight steps in flight; same sum order)
     unsigned short hh, ll;
     split_bf16(acc, hh, ll);
     unsigned short* q_ = planes + ((long)b * c + o) * 2 * cpad + ilv(h * ch + j);   // ilv planes [B, c, 2*cpad]
@@ -210,9 +249,10 @@ extern "C" int mmsa_chanattn_build(const double* G, const double* sq, long sq_st
   MMSA_CHECK_ARG(G && sq && sk && temp && Wp && planes, "chanattn_build: null pointer");
   MMSA_CHECK_ARG(c % heads == 0 && cpad >= c, "chanattn_build: bad channel split");
   const int ch = c / heads;
-  const size_t smem = (size_t)ch * (ch + 1) * sizeof(float);
+  const int nz = c >= 192 ? 16 : 4;
+  const size_t smem = ((size_t)ch * (ch + 1) + 2 * (size_t)ch + (size_t)cdiv(c, nz) * ch) * sizeof(float);   // logits block + the two norm vectors + the workgroup's weight rows
   MMSA_CHECK_ARG(smem <= 64 * 1024, "chanattn_build: head block too large");
-  hipLaunchKernelGGL(chanattn_build_kernel, dim3(heads, B, c >= 192 ? 16 : 4), dim3(256), smem, stream, G, sq, sq_strideB, sk, sk_strideB, temp, Wp, planes, c, cpad, heads);
+  hipLaunchKernelGGL(chanattn_build_kernel, dim3(heads, B, nz), dim3(256), smem, stream, G, sq, sq_strideB, sk, sk_strideB, temp, Wp, planes, c, cpad, heads);
   MMSA_CHECK_LAUNCH("chanattn_build");
   return MMSA_OK;
 }
@@ -290,27 +330,53 @@ extern "C" int mmsa_gelu_gate(const float* x, long ldx, float* y, long ldy, long
 
 // ---------------------------------------------------------------------------------------------
 // out[b][r][c], r < H: mean_w z[b,r,w,c];  r >= H: mean_h z[b,h,r-H,c]     (cat of pool_h and pool_w, AM:190-192)
+// One workgroup per output row (mean over W) or column (mean over H), a lane per 4 channels.  The sums run in the order of the first
+// version (element after element: same rounding), but eight rows / columns are LOADED at a time as float4 -- the scalar, one-load-per-
+// iteration loop was a chain of up to 256 dependent memory round trips (49-83 us for maps that stream in 5-20).
+template <bool VEC>
 __global__ __launch_bounds__(256) void pool_hw_kernel(const float* __restrict__ z, long ldz, float* __restrict__ out, long ldo,
                                                       int H, int W, int C) {
   const int r = blockIdx.x, b = blockIdx.y;
   const float* zb = z + (long)b * H * W * ldz;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    if (r < H) {
-      for (int w = 0; w < W; ++w) s += zb[((long)r * W + w) * ldz + c];
-      s /= (float)W;
-    } else {
-      const int w = r - H;
-      for (int h = 0; h < H; ++h) s += zb[((long)h * W + w) * ldz + c];
-      s /= (float)H;
+  const bool row = r < H;
+  const int n = row ? W : H;                                   // elements to average
+  const long step = row ? ldz : (long)W * ldz;                  // distance between them
+  const float* base = zb + (row ? (long)r * W * ldz : (long)(r - H) * ldz);
+  constexpr int V = VEC ? 4 : 1;
+  for (int c = threadIdx.x * V; c < C; c += 256 * V) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      float v[8][4];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if constexpr (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(base + (long)(i + k) * step + c);
+          v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+        } else {
+          v[k][0] = base[(long)(i + k) * step + c];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < V; ++q) s[q] += v[k][q];
     }
-    out[((long)b * (H + W) + r) * ldo + c] = s;
+    for (; i < n; ++i)
+#pragma unroll
+      for (int q = 0; q < V; ++q) s[q] += base[(long)i * step + c + q];
+    float* o = out + ((long)b * (H + W) + r) * ldo + c;
+#pragma unroll
+    for (int q = 0; q < V; ++q) o[q] = s[q] / (float)n;
   }
 }
 
 extern "C" int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int B, int H, int W, int C, hipStream_t stream) {
   MMSA_CHECK_ARG(z && out && B > 0 && H > 0 && W > 0 && C > 0, "pool_hw: bad args");
-  hipLaunchKernelGGL(pool_hw_kernel, dim3(H + W, B), dim3(256), 0, stream, z, ldz, out, ldo, H, W, C);
+  if ((C & 3) == 0 && (ldz & 3) == 0 && (ldo & 3) == 0 && ((((uintptr_t)z) | ((uintptr_t)out)) & 15) == 0)
+    hipLaunchKernelGGL(pool_hw_kernel<true>, dim3(H + W, B), dim3(256), 0, stream, z, ldz, out, ldo, H, W, C);
+  else
+    hipLaunchKernelGGL(pool_hw_kernel<false>, dim3(H + W, B), dim3(256), 0, stream, z, ldz, out, ldo, H, W, C);
   MMSA_CHECK_LAUNCH("pool_hw");
   return MMSA_OK;
 }
