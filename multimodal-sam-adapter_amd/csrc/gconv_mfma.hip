@@ -32,52 +32,46 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // The channel chunks are software-pipelined: the global loads of chunk i + 1 (halo + weights, 11 + <= 23 registers) are issued before
-  // the MFMAs of chunk i and written to LDS after them -- a chunk's load latency used to be exposed between two barriers, once per chunk
-  // (2 to 9 chunks per workgroup).
-  constexpr int NIT = (TW * TW * CCH + 255) / 256;   // 11
-  constexpr int WN = 9 * CCH * NT * 16;
-  constexpr int WIT = (WN + 255) / 256;
-  float v[NIT], wv[WIT];
-#define GC3_LOAD(ci0_)                                                                                                        \
-  {                                                                                                                           \
-    const int nch_ = min(CCH, cin_g - (ci0_));                                                                                \
-    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                                      \
-      const int i = threadIdx.x + it * 256;                                                                                   \
-      const int ci = i & (CCH - 1), pos = i >> 3;                                                                             \
-      const int ly = pos / TW, lx = pos - ly * TW;                                                                            \
-      const int iy = ty0 + ly - 1, ix = tx0 + lx - 1;                                                                         \
-      v[it] = 0.f;                                                                                                            \
-      if (pos < TW * TW && ci < nch_ && iy >= 0 && iy < H && ix >= 0 && ix < W) v[it] = xb[((long)iy * W + ix) * ldx + (ci0_) + ci]; \
-    }                                                                                                                         \
-    /* weights of the chunk: [9][CCH][NTW], zero beyond nch channels / cout_g outputs */                                      \
-    _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                                      \
-      const int i = threadIdx.x + it * 256;                                                                                   \
-      const int co = i % (NT * 16), r = i / (NT * 16);       /* r = tap * CCH + ci */                                         \
-      const int ci = r & (CCH - 1), tap = r >> 3;                                                                             \
-      wv[it] = 0.f;                                                                                                           \
-      if (i < WN && ci < nch_ && co < cout_g) wv[it] = wg[((long)tap * cin_g + (ci0_) + ci) * cout_g + co];                   \
-    }                                                                                                                         \
-  }
-#define GC3_STORE()                                                                                                           \
-  {                                                                                                                           \
-    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                                      \
-      const int i = threadIdx.x + it * 256;                                                                                   \
-      const int ci = i & (CCH - 1), pos = i >> 3;                                                                             \
-      if (pos < TW * TW) halo[ci * CST + pos] = v[it];                                                                        \
-    }                                                                                                                         \
-    _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                                      \
-      const int i = threadIdx.x + it * 256;                                                                                   \
-      const int co = i % (NT * 16), r = i / (NT * 16);                                                                        \
-      if (i < WN) wch[r * NTW + co] = wv[it];                                                                                 \
-    }                                                                                                                         \
-  }
-  GC3_LOAD(0)
   for (int ci0 = 0; ci0 < cin_g; ci0 += CCH) {
     const int nch = min(CCH, cin_g - ci0);
     __syncthreads();   // the previous chunk is fully consumed
-    GC3_STORE()
-    if (ci0 + CCH < cin_g) GC3_LOAD(ci0 + CCH)   // in flight under this chunk's MFMAs
+    {
+      constexpr int NIT = (TW * TW * CCH + 255) / 256;   // 11
+      float v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int ci = i & (CCH - 1), pos = i >> 3;
+        const int ly = pos / TW, lx = pos - ly * TW;
+        const int iy = ty0 + ly - 1, ix = tx0 + lx - 1;
+        v[it] = 0.f;
+        if (pos < TW * TW && ci < nch && iy >= 0 && iy < H && ix >= 0 && ix < W) v[it] = xb[((long)iy * W + ix) * ldx + ci0 + ci];
+      }
+      // weights of the chunk: [9][CCH][NTW], zero beyond nch channels / cout_g outputs
+      constexpr int WN = 9 * CCH * NT * 16;
+      constexpr int WIT = (WN + 255) / 256;
+      float wv[WIT];
+#pragma unroll
+      for (int it = 0; it < WIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int co = i % (NT * 16), r = i / (NT * 16);       // r = tap * CCH + ci
+        const int ci = r & (CCH - 1), tap = r >> 3;
+        wv[it] = 0.f;
+        if (i < WN && ci < nch && co < cout_g) wv[it] = wg[((long)tap * cin_g + ci0 + ci) * cout_g + co];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int ci = i & (CCH - 1), pos = i >> 3;
+        if (pos < TW * TW) halo[ci * CST + pos] = v[it];
+      }
+#pragma unroll
+      for (int it = 0; it < WIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int co = i % (NT * 16), r = i / (NT * 16);
+        if (i < WN) wch[r * NTW + co] = wv[it];
+      }
+    }
     __syncthreads();
     const int nks = (nch + 3) >> 2;
 #pragma unroll
@@ -114,9 +108,6 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
     }
   }
 }
-
-#undef GC3_LOAD
-#undef GC3_STORE
 
 // internal launcher used by mmsa_gconv_nhwc (conv.hip); returns false when the shape is not covered
 bool mmsa_gconv3_mfma_launch(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W, int G, int cin_g,
