@@ -316,6 +316,14 @@ def test_gram_tn(ops):
     out = torch.empty(B * c, c, device=DEV, dtype=torch.float64)
     ops.gram_tn(xd[:, :c], xd[:, c:], P * 2 * c, out, B, P, nblk=1)
     assert_close(out.view(B, c, c).float(), ref, tol=1e-5, what="gram full")
+    # the per-slice scratch is the caller's: too small a buffer is refused; a sufficient one gives the same bits as the op's own
+    need = ops.gram_tn_scratch_bytes(B, P, c)
+    assert need == B * 1 * ((P + 255) // 256) * 36 * 64 * 16
+    with pytest.raises(RuntimeError):
+        ops.gram_tn(xd[:, :c], xd[:, c:], P * 2 * c, out.clone(), B, P, nblk=1, scratch=torch.empty(need // 4 - 64, device=DEV))
+    out2 = torch.full_like(out, float("nan"))
+    ops.gram_tn(xd[:, :c], xd[:, c:], P * 2 * c, out2, B, P, nblk=1, scratch=torch.empty(need // 4 + 5, device=DEV))
+    assert torch.equal(out2, out)
     ops.gram_tn(xd[:, :c], xd[:, c:], P * 2 * c, out, B, P, nblk=8)  # only diagonal head blocks are defined
     ch = c // 8
     for h in range(8):
