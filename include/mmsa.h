@@ -225,7 +225,8 @@ int mmsa_pool_hw(const float* z, long ldz, float* out, long ldo, int B, int H, i
 int mmsa_ca_apply(const float* z, long ldz, const float* att, long lda, float* out, long ldo,
                   uint16_t* out_planes, long ldp /* optional interleaved planes */, int B, int H, int W, int C, mmsa_stream_t stream);
 
-/* --- tail (BK:316-337): out NCHW [B,C,Hc,Wc] = (cmap + bilinear(xtok)) * bn_scale + bn_shift; cmap image b starts at b*cstrideB --- */
+/* --- tail (BK:316-337): out NCHW [B,C,Hc,Wc] = (cmap + bilinear(xtok)) * bn_scale + bn_shift; cmap image b starts at b*cstrideB;
+ * xtok == NULL: no ViT feature is added (add_vit_feature = False, BK:326) --- */
 int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok, long ldx, const float* bn_scale,
                    const float* bn_shift, float* out, uint16_t* out_planes /* optional: the same map token-major
                    [B*Hc*Wc, 2*C] as interleaved planes, for the decode head's first 1x1 conv */, long ldp,

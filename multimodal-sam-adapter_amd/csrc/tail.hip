@@ -35,11 +35,14 @@ __global__ __launch_bounds__(256) void tail_fuse_kernel(const float* __restrict_
       const int h0 = (int)sh, w0 = (int)sw;
       const int h1 = h0 + (h0 < Hx - 1 ? 1 : 0), w1 = w0 + (w0 < Wx - 1 ? 1 : 0);
       const float lh = sh - (float)h0, lw = sw - (float)w0;
-      const float* xb = xtok + (long)b * Hx * Wx * ldx + c;
-      const float v00 = xb[((long)h0 * Wx + w0) * ldx], v01 = xb[((long)h0 * Wx + w1) * ldx];
-      const float v10 = xb[((long)h1 * Wx + w0) * ldx], v11 = xb[((long)h1 * Wx + w1) * ldx];
-      const float r = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
-      v = (v + r) * bn_scale[c] + bn_shift[c];
+      if (xtok) {   // kernel-uniform; nullptr: add_vit_feature = False (BK:326), the map alone goes through the norm
+        const float* xb = xtok + (long)b * Hx * Wx * ldx + c;
+        const float v00 = xb[((long)h0 * Wx + w0) * ldx], v01 = xb[((long)h0 * Wx + w1) * ldx];
+        const float v10 = xb[((long)h1 * Wx + w0) * ldx], v11 = xb[((long)h1 * Wx + w1) * ldx];
+        const float r = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+        v = v + r;
+      }
+      v = v * bn_scale[c] + bn_shift[c];
       if (outp) {   // the same map token-major as interleaved planes: the A operand of the decode head's first 1x1 conv
         unsigned short hh, ll;
         split_bf16(v, hh, ll);
@@ -96,11 +99,15 @@ __global__ __launch_bounds__(256) void tail_fuse64_kernel(const float* __restric
       const int h0 = (int)sh, w0 = (int)sw;
       const int h1 = h0 + (h0 < Hx - 1 ? 1 : 0), w1 = w0 + (w0 < Wx - 1 ? 1 : 0);
       const float lh = sh - (float)h0, lw = sw - (float)w0;
-      const float4 v00 = *reinterpret_cast<const float4*>(xb + ((long)h0 * Wx + w0) * ldx), v01 = *reinterpret_cast<const float4*>(xb + ((long)h0 * Wx + w1) * ldx);
-      const float4 v10 = *reinterpret_cast<const float4*>(xb + ((long)h1 * Wx + w0) * ldx), v11 = *reinterpret_cast<const float4*>(xb + ((long)h1 * Wx + w1) * ldx);
+      if (xtok) {   // kernel-uniform; nullptr: add_vit_feature = False (BK:326)
+        const float4 v00 = *reinterpret_cast<const float4*>(xb + ((long)h0 * Wx + w0) * ldx), v01 = *reinterpret_cast<const float4*>(xb + ((long)h0 * Wx + w1) * ldx);
+        const float4 v10 = *reinterpret_cast<const float4*>(xb + ((long)h1 * Wx + w0) * ldx), v11 = *reinterpret_cast<const float4*>(xb + ((long)h1 * Wx + w1) * ldx);
 #define TF_ONE(f_) { const float r_ = (1.f - lh) * ((1.f - lw) * v00.f_ + lw * v01.f_) + lh * ((1.f - lw) * v10.f_ + lw * v11.f_); v.f_ = (v.f_ + r_) * sc.f_ + sf.f_; }
-      TF_ONE(x) TF_ONE(y) TF_ONE(z) TF_ONE(w)
+        TF_ONE(x) TF_ONE(y) TF_ONE(z) TF_ONE(w)
 #undef TF_ONE
+      } else {
+        v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+      }
     }
     if (outp) {   // planes, token-major: the lane pair (cg even | odd) holds 8 consecutive channels = one 16-byte hi chunk + one 16-byte lo chunk
       unsigned short* row = outp + ((long)b * npix + min(pix, npix - 1)) * ldp;
@@ -132,13 +139,13 @@ __global__ __launch_bounds__(256) void tail_fuse64_kernel(const float* __restric
 extern "C" int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok, long ldx, const float* bn_scale,
                               const float* bn_shift, float* out, unsigned short* out_planes, long ldp, int B, int Hc, int Wc,
                               int Hx, int Wx, int C, hipStream_t stream) {
-  MMSA_CHECK_ARG(cmap && xtok && bn_scale && bn_shift && out, "tail_fuse: null pointer");
+  MMSA_CHECK_ARG(cmap && bn_scale && bn_shift && out, "tail_fuse: null pointer");   // xtok may be null: no ViT feature added (BK:326)
   MMSA_CHECK_ARG(B > 0 && Hc > 0 && Wc > 0 && Hx > 0 && Wx > 0 && C > 0, "tail_fuse: bad shape");
   MMSA_CHECK_ARG(!out_planes || ((C & 31) == 0 && ldp >= 2L * C), "tail_fuse: planes output needs C % 32 == 0 and ldp >= 2C");
   // scale_factor s = Hc/Hx is what the reference passes (4, 2, 1, 0.5); PyTorch uses 1/s as the source step
   const float rh = (float)Hx / (float)Hc, rw = (float)Wx / (float)Wc;
   static const bool old_tiles = getenv("MMSA_TAIL32") != nullptr;   // A/B aid
-  const bool wide = !old_tiles && (C & 3) == 0 && (ldc & 3) == 0 && (ldx & 3) == 0 && (cstrideB & 3) == 0 &&
+  const bool wide = !old_tiles && (C & 3) == 0 && (ldc & 3) == 0 && (!xtok || (ldx & 3) == 0) && (cstrideB & 3) == 0 &&
                     ((((uintptr_t)cmap) | ((uintptr_t)xtok) | ((uintptr_t)bn_scale) | ((uintptr_t)bn_shift) | ((uintptr_t)out)) & 15) == 0 &&
                     (!out_planes || ((C & 7) == 0 && (ldp & 7) == 0 && (((uintptr_t)out_planes) & 15) == 0));
   if (wide) {

@@ -104,9 +104,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                                       f"got modalities_name={modalities_name}")
         if list(modalities_ch) != [3, 3]:
             raise NotImplementedError("mmsa: TwinConvNeXt takes two 3-channel streams (TC:296-316)")
-        if not (with_cffn and use_extra_extractor and add_vit_feature and vit["use_rel_pos"] and vit["use_abs_pos"] and vit["qkv_bias"]):
-            raise NotImplementedError("mmsa: only the shipped configuration family (cffn, extra extractors, vit features, "
-                                      "abs+rel pos, qkv bias) is implemented")
+        if not (vit["use_rel_pos"] and vit["use_abs_pos"] and vit["qkv_bias"]):
+            raise NotImplementedError("mmsa: the SAM ViT is implemented with absolute + relative position embeddings and a qkv bias "
+                                      "(every shipped configuration; IE:188-276)")
         if interaction_indexes is None:
             raise ValueError("interaction_indexes is required")
         D = vit["embed_dim"]
@@ -116,7 +116,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                         conv_inplane=conv_inplane, n_points=n_points, deform_num_heads=deform_num_heads,
                         init_values=init_values, interaction_indexes=[list(i) for i in interaction_indexes],
                         cffn_ratio=cffn_ratio, deform_ratio=deform_ratio, arch=arch,
-                        use_extra_extractor=use_extra_extractor)
+                        use_extra_extractor=bool(use_extra_extractor), with_cffn=bool(with_cffn), add_vit_feature=bool(add_vit_feature))
         a = CONVNEXT_ARCH[arch] if isinstance(arch, str) else arch
         self.depths, self.channels = list(a["depths"]), list(a["channels"])
         if [2 * c for c in self.channels] != [conv_inplane * m for m in (4, 8, 16, 32)]:
@@ -470,14 +470,16 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                         out=iplanes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
 
         def pack_extractor(b, fold_c=False):
-            dw = sd[b + "ffn.dwconv.dwconv.weight"]
-            return dict(qnw=sd[b + "query_norm.weight"], qnb=sd[b + "query_norm.bias"], fnw=sd[b + "feat_norm.weight"],
-                        fnb=sd[b + "feat_norm.bias"], fold_c=fold_c,
-                        attn=pack_msda(b + "attn.", fold_oa=(sd[b + "query_norm.weight"], sd[b + "query_norm.bias"]) if fold_c else None),
-                        fc1=iplanes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
-                        dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
-                        fc2=iplanes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
-                        ffw=sd[b + "ffn_norm.weight"], ffb=sd[b + "ffn_norm.bias"])
+            ep = dict(qnw=sd[b + "query_norm.weight"], qnb=sd[b + "query_norm.bias"], fnw=sd[b + "feat_norm.weight"],
+                      fnb=sd[b + "feat_norm.bias"], fold_c=fold_c, cffn=self.cfg["with_cffn"],
+                      attn=pack_msda(b + "attn.", fold_oa=(sd[b + "query_norm.weight"], sd[b + "query_norm.bias"]) if fold_c else None))
+            if self.cfg["with_cffn"]:   # AM:485-488, 499-500
+                dw = sd[b + "ffn.dwconv.dwconv.weight"]
+                ep.update(fc1=iplanes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
+                          dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
+                          fc2=iplanes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
+                          ffw=sd[b + "ffn_norm.weight"], ffb=sd[b + "ffn_norm.bias"])
+            return ep
 
         pk["inter"] = []
         n_int = len(self.interaction_indexes)
@@ -488,7 +490,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                                fnb=sd[b + "injector.feat_norm.bias"], fold_c=share_c,
                                attn=pack_msda(b + "injector.attn.", fold_val=(sd[b + "injector.feat_norm.weight"], sd[b + "injector.feat_norm.bias"]) if share_c else None)),
                       ext=[pack_extractor(b + "extractor.", fold_c=share_c)])
-            if i == n_int - 1:
+            if i == n_int - 1 and self.cfg["use_extra_extractor"]:   # BK:91-92
                 it["ext"] += [pack_extractor(b + "extra_extractors.0."), pack_extractor(b + "extra_extractors.1.")]
             it["inj"]["first_block"] = self.interaction_indexes[i][0]   # whose qkv GEMM reads the stream planes the injector writes (LayerNorm fold)
             pk["inter"].append(it)
@@ -711,7 +713,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                                                   (cbuf[n2:], Nc * D, (Hp, Wp)), (cbuf[n2 + n3:], Nc * D, (H // 32, W // 32)))):
             f = torch.empty(B, D, hh, wwd, device=dev)
             fpl = ws.planes(f"f{k + 1}_out", B * hh * wwd, D) if emit else None
-            ops.tail_fuse(src, cs, xs[k + 1], *pk["bn"][k], f, B, hh, wwd, Hp, Wp, out_planes=fpl)
+            ops.tail_fuse(src, cs, xs[k + 1] if self.cfg["add_vit_feature"] else None, *pk["bn"][k], f, B, hh, wwd, Hp, Wp, out_planes=fpl)   # BK:326-331
             if emit:
                 f._mmsa_planes = fpl.stamp(pgen)
             outs.append(f)
@@ -894,6 +896,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
         ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, out_planes=fn)
         self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
+        if not ep["cffn"]:   # AM:499-500
+            return
         qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["fc1"].fmt)
         ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, out_planes=qn)
         hid = ep["fc1"].n

@@ -566,8 +566,11 @@ def ca_apply(z, att, out, b, h, w, out_planes=None):
 
 
 def tail_fuse(cmap, cstride_b, xtok, bn_scale, bn_shift, out, b, hc, wc, hx, wx, out_planes=None):
+    """f = BatchNorm_eval(cmap + bilinear_resize(xtok)) as NCHW; xtok None = no ViT feature added (add_vit_feature=False, BK:326)."""
     pc, _, c, ldc = _mat(cmap, "cmap")
-    px, _, _, ldx = _mat(xtok, "xtok")
+    px, ldx = None, 0
+    if xtok is not None:
+        px, _, _, ldx = _mat(xtok, "xtok")
     pp, ldp = (out_planes.p.data_ptr(), 2 * out_planes.kpad) if out_planes is not None else (None, 0)
     lib.call("mmsa_tail_fuse", pc, ldc, cstride_b, px, ldx, _chk(bn_scale), _chk(bn_shift), _chk(out), pp, ldp, b, hc, wc, hx, wx, c, _stream())
     return out

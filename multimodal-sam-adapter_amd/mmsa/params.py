@@ -154,10 +154,11 @@ def param_spec(cfg):
         P(b + "query_norm.weight", D); P(b + "query_norm.bias", D)
         P(b + "feat_norm.weight", D); P(b + "feat_norm.bias", D)
         msda(b + "attn.", 1)
-        P(b + "ffn.fc1.weight", hid, D); P(b + "ffn.fc1.bias", hid)
-        P(b + "ffn.dwconv.dwconv.weight", hid, 1, 3, 3); P(b + "ffn.dwconv.dwconv.bias", hid)
-        P(b + "ffn.fc2.weight", D, hid); P(b + "ffn.fc2.bias", D)
-        P(b + "ffn_norm.weight", D); P(b + "ffn_norm.bias", D)
+        if cfg.get("with_cffn", True):   # AM:485-488: registered only then
+            P(b + "ffn.fc1.weight", hid, D); P(b + "ffn.fc1.bias", hid)
+            P(b + "ffn.dwconv.dwconv.weight", hid, 1, 3, 3); P(b + "ffn.dwconv.dwconv.bias", hid)
+            P(b + "ffn.fc2.weight", D, hid); P(b + "ffn.fc2.bias", D)
+            P(b + "ffn_norm.weight", D); P(b + "ffn_norm.bias", D)
 
     n_int = len(cfg["interaction_indexes"])
     for i in range(n_int):

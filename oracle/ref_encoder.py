@@ -573,16 +573,20 @@ class ConvFFN(nn.Module):  # AM:434-471
 
 
 class Extractor(nn.Module):  # AM:474-511
-    def __init__(self, dim, heads, n_points, ratio, cffn_ratio):
+    def __init__(self, dim, heads, n_points, ratio, cffn_ratio, with_cffn=True):
         super().__init__()
         self.query_norm = nn.LayerNorm(dim, eps=1e-6)
         self.feat_norm = nn.LayerNorm(dim, eps=1e-6)
         self.attn = MSDeformAttn(dim, 1, heads, n_points, ratio)
-        self.ffn = ConvFFN(dim, int(dim * cffn_ratio))
-        self.ffn_norm = nn.LayerNorm(dim, eps=1e-6)
+        self.with_cffn = with_cffn
+        if with_cffn:   # AM:485-488: the ConvFFN and its norm exist only then
+            self.ffn = ConvFFN(dim, int(dim * cffn_ratio))
+            self.ffn_norm = nn.LayerNorm(dim, eps=1e-6)
 
     def forward(self, query, ref, feat, ss, lsi, H, W):
         query = query + self.attn(self.query_norm(query), ref, self.feat_norm(feat), ss, lsi)
+        if not self.with_cffn:   # AM:499-500
+            return query
         return query + self.ffn(self.ffn_norm(query), H, W)
 
 
@@ -599,11 +603,11 @@ class Injector(nn.Module):  # AM:514-542
 
 
 class InteractionBlock(nn.Module):  # AM:545-581
-    def __init__(self, dim, heads, n_points, ratio, cffn_ratio, init_values, extra):
+    def __init__(self, dim, heads, n_points, ratio, cffn_ratio, init_values, extra, with_cffn=True):
         super().__init__()
         self.injector = Injector(dim, heads, n_points, ratio, init_values)
-        self.extractor = Extractor(dim, heads, n_points, ratio, cffn_ratio)
-        self.extra_extractors = nn.Sequential(*[Extractor(dim, heads, n_points, ratio, cffn_ratio) for _ in range(2)]) if extra else None
+        self.extractor = Extractor(dim, heads, n_points, ratio, cffn_ratio, with_cffn)
+        self.extra_extractors = nn.Sequential(*[Extractor(dim, heads, n_points, ratio, cffn_ratio, with_cffn) for _ in range(2)]) if extra else None
 
     def forward(self, x, c, blocks, d1, d2, H, W):
         x = self.injector(x, d1[0], c, d1[1], d1[2])
@@ -623,9 +627,11 @@ class OracleEncoder(nn.Module):
     def __init__(self, img_size=1024, patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4.0,
                  window_size=14, global_attn_indexes=(5, 11, 17, 23), pretrained_size=1024,
                  conv_inplane=48, n_points=4, deform_num_heads=16, init_values=1e-6, interaction_indexes=None,
-                 cffn_ratio=0.25, deform_ratio=0.5, arch="small", **_ignored):
+                 cffn_ratio=0.25, deform_ratio=0.5, arch="small", with_cffn=True, use_extra_extractor=True, add_vit_feature=True,
+                 **_ignored):
         super().__init__()
         self.img_size, self.embed_dim = img_size, embed_dim
+        self.add_vit_feature = add_vit_feature   # BK:33,44,326
         self.interaction_indexes = interaction_indexes
         grid = pretrained_size // patch_size
         # registration order follows IE:235-276 then BK:54-99 so that state_dict ordering matches
@@ -639,7 +645,8 @@ class OracleEncoder(nn.Module):
         self.level_embed = nn.Parameter(torch.zeros(3, embed_dim))
         n = len(interaction_indexes)
         self.interactions = nn.Sequential(*[
-            InteractionBlock(embed_dim, deform_num_heads, n_points, deform_ratio, cffn_ratio, init_values, i == n - 1)
+            InteractionBlock(embed_dim, deform_num_heads, n_points, deform_ratio, cffn_ratio, init_values,
+                             i == n - 1 and use_extra_extractor, with_cffn)   # BK:86-94
             for i in range(n)])
         self.norm1 = nn.BatchNorm2d(embed_dim)
         self.norm2 = nn.BatchNorm2d(embed_dim)
@@ -680,8 +687,9 @@ class OracleEncoder(nn.Module):
         c3 = c[:, n2:n2 + n3].transpose(1, 2).view(bs, dim, H, W).contiguous()
         c4 = c[:, n2 + n3:].transpose(1, 2).view(bs, dim, H // 2, W // 2).contiguous()
         c1 = self.up(c2) + c1
-        x1 = F.interpolate(outs[0], scale_factor=4, mode="bilinear", align_corners=False)
-        x2 = F.interpolate(outs[1], scale_factor=2, mode="bilinear", align_corners=False)
-        x4 = F.interpolate(outs[3], scale_factor=0.5, mode="bilinear", align_corners=False)
-        c1, c2, c3, c4 = c1 + x1, c2 + x2, c3 + outs[2], c4 + x4
+        if self.add_vit_feature:   # BK:326-331
+            x1 = F.interpolate(outs[0], scale_factor=4, mode="bilinear", align_corners=False)
+            x2 = F.interpolate(outs[1], scale_factor=2, mode="bilinear", align_corners=False)
+            x4 = F.interpolate(outs[3], scale_factor=0.5, mode="bilinear", align_corners=False)
+            c1, c2, c3, c4 = c1 + x1, c2 + x2, c3 + outs[2], c4 + x4
         return [self.norm1(c1), self.norm2(c2), self.norm3(c3), self.norm4(c4)], None

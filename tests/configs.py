@@ -35,6 +35,10 @@ CONFIGS = {
     "tiny224": dict(kwargs=dict(_TINY, img_size=224), batch=1, seed=1, in_seed=5),
     "tiny256": dict(kwargs=dict(_TINY, img_size=256), batch=1, seed=2, in_seed=6),
     "tiny320": dict(kwargs=dict(_TINY, img_size=320), batch=1, seed=3, in_seed=7),
+    # the constructor switches no shipped config turns off (BK:32-34): extractors without ConvFFN (AM:485-488), no extra extractors in
+    # the last interaction (BK:91-92), no ViT feature added in the tail (BK:326)
+    "tiny256_plain": dict(kwargs=dict(_TINY, img_size=256, with_cffn=False, use_extra_extractor=False, add_vit_feature=False),
+                          batch=1, seed=21, in_seed=22),
     "vitb512": dict(kwargs=_VITB, batch=1, seed=4, in_seed=8),
     "vitl1024": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9),
     "vith1024": dict(kwargs=_VITH, batch=1, seed=17, in_seed=18),

@@ -28,7 +28,7 @@ def _build(name):
     return cfg, orc, m
 
 
-@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320"])
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain"])
 def test_tiny_models_vs_golden_and_oracle(golden_dir, name):
     cfg, orc, m = _build(name)
     g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
@@ -42,6 +42,26 @@ def test_tiny_models_vs_golden_and_oracle(golden_dir, name):
         gold = torch.from_numpy(g[f"f{i+1}"])
         got = f.cpu() if gold.shape == f.shape else f.cpu()[..., ::2, ::2]
         assert_close(got, gold, what=f"{name} f{i+1} vs golden")
+
+
+@pytest.mark.parametrize("flag", ["with_cffn", "use_extra_extractor", "add_vit_feature"])
+def test_constructor_switches_one_at_a_time(flag):
+    """Each of the three switches alone (tiny256_plain pins all three off together against the reference's golden; the oracle's
+    branches are the same code): extractors without ConvFFN, no extra extractors, no ViT feature in the tail."""
+    import mmsa
+    cfg = CONFIGS["tiny256"]
+    kw = dict(cfg["kwargs"], **{flag: False})
+    torch.manual_seed(0)
+    orc = R.OracleEncoder(**kw)
+    sd = seeded_state_dict(orc, seed=31)
+    orc.load_state_dict(sd)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **kw))
+    m.load_state_dict(sd, strict=True)
+    x = make_input(cfg)
+    fs, _ = m(x.to(DEV))
+    ref, _ = orc(x)
+    for i, (f, r) in enumerate(zip(fs, ref)):
+        assert_close(f, r, what=f"{flag}=False f{i+1} vs oracle")
 
 
 def test_batch_and_determinism():

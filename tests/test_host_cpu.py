@@ -22,6 +22,18 @@ def test_library_exports_every_declared_symbol():
     assert mmsa.lib.version() >= 100
 
 
+def test_state_dict_contract_with_the_constructor_switches_off(golden_dir):
+    """with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34): the parameter tree of the reference built that way."""
+    import mmsa
+    from tests.configs import CONFIGS
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **CONFIGS["tiny256_plain"]["kwargs"]))
+    lines = [l.rstrip("\n").split(" ", 1) for l in open(os.path.join(golden_dir, "state_dict_keys_tiny_plain.txt"))]
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _ in lines]
+    assert all(list(sd[k].shape) == eval(s) for k, s in lines)
+    assert not any(".ffn" in k or "extra_extractors" in k for k in sd)
+
+
 def test_plugin_registry_and_state_dict_contract(golden_dir):
     import mmsa
     from tests.configs import CONFIGS

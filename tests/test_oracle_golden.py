@@ -86,9 +86,10 @@ def _check_model(golden_dir, name, full):
             assert (got_full - ref_full).abs().max().item() <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320"])
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain"])
 def test_oracle_tiny_models(golden_dir, name):
-    """224: window padding 14->14 none, rel-pos interpolation (pretrained 256); 256: pad 16->28; 320: pad 20->28."""
+    """224: window padding 14->14 none, rel-pos interpolation (pretrained 256); 256: pad 16->28; 320: pad 20->28; 256_plain: the
+    constructor switches off -- with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34, AM:485-500, BK:91-92, BK:326)."""
     _check_model(golden_dir, name, full=True)
 
 
@@ -101,9 +102,10 @@ def test_oracle_vitl1024(golden_dir):
     _check_model(golden_dir, "vitl1024", full=False)
 
 
-def test_state_dict_keys_match_reference(golden_dir):
-    m = R.OracleEncoder(**CONFIGS["tiny224"]["kwargs"])
-    want = [l.split(" ")[0] for l in open(os.path.join(golden_dir, "state_dict_keys_tiny.txt"))]
+@pytest.mark.parametrize("name,keys", [("tiny224", "state_dict_keys_tiny.txt"), ("tiny256_plain", "state_dict_keys_tiny_plain.txt")])
+def test_state_dict_keys_match_reference(golden_dir, name, keys):
+    m = R.OracleEncoder(**CONFIGS[name]["kwargs"])
+    want = [l.split(" ")[0] for l in open(os.path.join(golden_dir, keys))]
     assert list(m.state_dict().keys()) == want
 
 

@@ -131,6 +131,10 @@ def gen_model(name, full):
         if full:
             out[f"f{i+1}"] = f.numpy() if i > 0 or f.shape[-1] <= 56 else f[..., ::2, ::2].contiguous().numpy()
     np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **out)
+    if name == "tiny256_plain":
+        with open(os.path.join(OUT, "state_dict_keys_tiny_plain.txt"), "w") as fh:
+            for k, s in zip(keys, shapes):
+                fh.write(f"{k} {s}\n")
     if name == "tiny224":
         with open(os.path.join(OUT, "state_dict_keys_tiny.txt"), "w") as fh:
             for k, s in zip(keys, shapes):
@@ -296,14 +300,15 @@ def main():
     torch.set_num_threads(8)
     if a.only:
         if a.only.startswith("model:"):
-            gen_model(a.only.split(":", 1)[1], full=False)
+            n = a.only.split(":", 1)[1]
+            gen_model(n, full=n.startswith("tiny"))
         else:
             globals()["gen_" + a.only]()
         return
     gen_msda_bwd()
     gen_msda()
     gen_bookkeeping()
-    for n in ("tiny224", "tiny256", "tiny320"):
+    for n in ("tiny224", "tiny256", "tiny320", "tiny256_plain"):
         gen_model(n, full=True)
     gen_slide()
     gen_whole_dim()
