@@ -104,9 +104,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                                       f"got modalities_name={modalities_name}")
         if list(modalities_ch) != [3, 3]:
             raise NotImplementedError("mmsa: TwinConvNeXt takes two 3-channel streams (TC:296-316)")
-        if not (vit["use_rel_pos"] and vit["use_abs_pos"] and vit["qkv_bias"]):
-            raise NotImplementedError("mmsa: the SAM ViT is implemented with absolute + relative position embeddings and a qkv bias "
-                                      "(every shipped configuration; IE:188-276)")
+        if not vit["use_abs_pos"]:
+            raise NotImplementedError("mmsa: use_abs_pos=False is not a working configuration of the reference either (its forward interpolates "
+                                      "self.pos_embed unconditionally, BK:276, which is None then: IE:113-114)")
         if interaction_indexes is None:
             raise ValueError("interaction_indexes is required")
         D = vit["embed_dim"]
@@ -116,7 +116,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                         conv_inplane=conv_inplane, n_points=n_points, deform_num_heads=deform_num_heads,
                         init_values=init_values, interaction_indexes=[list(i) for i in interaction_indexes],
                         cffn_ratio=cffn_ratio, deform_ratio=deform_ratio, arch=arch,
-                        use_extra_extractor=bool(use_extra_extractor), with_cffn=bool(with_cffn), add_vit_feature=bool(add_vit_feature))
+                        use_extra_extractor=bool(use_extra_extractor), with_cffn=bool(with_cffn), add_vit_feature=bool(add_vit_feature),
+                        use_rel_pos=bool(vit["use_rel_pos"]), qkv_bias=bool(vit["qkv_bias"]))
         a = CONVNEXT_ARCH[arch] if isinstance(arch, str) else arch
         self.depths, self.channels = list(a["depths"]), list(a["channels"])
         if [2 * c for c in self.channels] != [conv_inplane * m for m in (4, 8, 16, 32)]:
@@ -256,11 +257,29 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             out["lin1"], out["lin1_cs"], out["lin1_bf"] = folded(g("mlp.lin1.weight"), g("mlp.lin1.bias"), g("norm2.weight"), g("norm2.bias"))
         return out
 
+    def _pack_state_dict(self, dev):
+        """The float parameters on `dev`, plus ZERO stand-ins for the tensors a ViT built with qkv_bias=False / use_rel_pos=False does not
+        have (IE:317,320-327): a zero qkv bias and zero rel-pos tables make the kernels compute exactly what the reference computes
+        without them (the pad tokens' k / v = bias = 0; rel_pos . q = 0 added to the logits)."""
+        sd = {k: v.detach().to(dev, torch.float32) for k, v in self.state_dict().items() if v.dtype.is_floating_point}
+        cfg = self.cfg
+        D, hd = cfg["embed_dim"], cfg["embed_dim"] // cfg["num_heads"]
+        grid = cfg["pretrained_size"] // cfg["patch_size"]
+        for i in range(cfg["depth"]):
+            b = f"blocks.{i}.attn."
+            if not cfg["qkv_bias"]:
+                sd[b + "qkv.bias"] = torch.zeros(3 * D, device=dev)
+            if not cfg["use_rel_pos"]:
+                L = 2 * (grid if i in cfg["global_attn_indexes"] else cfg["window_size"]) - 1
+                sd[b + "rel_pos_h"] = torch.zeros(L, hd, device=dev)
+                sd[b + "rel_pos_w"] = torch.zeros(L, hd, device=dev)
+        return sd
+
     @torch.no_grad()
     def _pack(self, dev):
         cfg = self.cfg
         h8_sites = self._h8_sites()
-        sd = {k: v.detach().to(dev, torch.float32) for k, v in self.state_dict().items() if v.dtype.is_floating_point}
+        sd = self._pack_state_dict(dev)
         pk = {"h8_sites": h8_sites}
         D = cfg["embed_dim"]
 
@@ -838,7 +857,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # the projections around those logits must not lose them either: q and k from 2^-15.6 products turn a logit of 48 into an
                 # error of ~1e-3 before the exponential, and what proj / lin1 / lin2 lose reaches the NEXT block's q and k.  The whole
                 # block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.
-                bp.update(self._block_gemm_planes(self.state_dict(), bp["index"], ops.FMT_B3, self._packed["fold_ln"], x.device))
+                bp.update(self._block_gemm_planes(self._pack_state_dict(x.device), bp["index"], ops.FMT_B3, self._packed["fold_ln"], x.device))
         return mode
 
     def calibrate_attention(self, x):

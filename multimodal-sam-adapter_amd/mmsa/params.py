@@ -59,8 +59,11 @@ def param_spec(cfg):
         L = 2 * (grid if i in cfg["global_attn_indexes"] else ws) - 1
         b = f"blocks.{i}."
         P(b + "norm1.weight", D); P(b + "norm1.bias", D)
-        P(b + "attn.rel_pos_h", L, hd); P(b + "attn.rel_pos_w", L, hd)
-        P(b + "attn.qkv.weight", 3 * D, D); P(b + "attn.qkv.bias", 3 * D)
+        if cfg.get("use_rel_pos", True):
+            P(b + "attn.rel_pos_h", L, hd); P(b + "attn.rel_pos_w", L, hd)
+        P(b + "attn.qkv.weight", 3 * D, D)
+        if cfg.get("qkv_bias", True):      # IE:317
+            P(b + "attn.qkv.bias", 3 * D)
         P(b + "attn.proj.weight", D, D); P(b + "attn.proj.bias", D)
         P(b + "norm2.weight", D); P(b + "norm2.bias", D)
         P(b + "mlp.lin1.weight", hidden, D); P(b + "mlp.lin1.bias", hidden)

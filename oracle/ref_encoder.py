@@ -179,22 +179,25 @@ def add_decomposed_rel_pos(attn, q, rph, rpw, q_size, k_size):  # IE:587-623
 
 
 class Attention(nn.Module):  # IE:426-501
-    def __init__(self, dim, num_heads, input_size):
+    def __init__(self, dim, num_heads, input_size, qkv_bias=True, use_rel_pos=True):
         super().__init__()
         self.num_heads = num_heads
         hd = dim // num_heads
         self.scale = hd ** -0.5
-        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)   # IE:317
         self.proj = nn.Linear(dim, dim)
-        self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, hd))
-        self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, hd))
+        self.use_rel_pos = use_rel_pos
+        if use_rel_pos:   # IE:320-327: the tables exist only then
+            self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, hd))
+            self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, hd))
 
     def forward(self, x):
         B, H, W, _ = x.shape
         qkv = self.qkv(x).reshape(B, H * W, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.reshape(3, B * self.num_heads, H * W, -1).unbind(0)
         attn = (q * self.scale) @ k.transpose(-2, -1)
-        attn = add_decomposed_rel_pos(attn, q, self.rel_pos_h, self.rel_pos_w, (H, W), (H, W))
+        if self.use_rel_pos:
+            attn = add_decomposed_rel_pos(attn, q, self.rel_pos_h, self.rel_pos_w, (H, W), (H, W))
         attn = attn.softmax(dim=-1)
         x = (attn @ v).view(B, self.num_heads, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
         return self.proj(x)
@@ -211,10 +214,10 @@ class MLPBlock(nn.Module):  # IE:154-167
 
 
 class Block(nn.Module):  # IE:331-423
-    def __init__(self, dim, num_heads, mlp_ratio, window_size, input_size):
+    def __init__(self, dim, num_heads, mlp_ratio, window_size, input_size, qkv_bias=True, use_rel_pos=True):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
-        self.attn = Attention(dim, num_heads, input_size if window_size == 0 else (window_size, window_size))
+        self.attn = Attention(dim, num_heads, input_size if window_size == 0 else (window_size, window_size), qkv_bias, use_rel_pos)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = MLPBlock(dim, int(dim * mlp_ratio))
         self.window_size = window_size
@@ -628,7 +631,7 @@ class OracleEncoder(nn.Module):
                  window_size=14, global_attn_indexes=(5, 11, 17, 23), pretrained_size=1024,
                  conv_inplane=48, n_points=4, deform_num_heads=16, init_values=1e-6, interaction_indexes=None,
                  cffn_ratio=0.25, deform_ratio=0.5, arch="small", with_cffn=True, use_extra_extractor=True, add_vit_feature=True,
-                 **_ignored):
+                 qkv_bias=True, use_rel_pos=True, **_ignored):
         super().__init__()
         self.img_size, self.embed_dim = img_size, embed_dim
         self.add_vit_feature = add_vit_feature   # BK:33,44,326
@@ -638,7 +641,7 @@ class OracleEncoder(nn.Module):
         self.patch_embed = PatchEmbed(patch_size, 3, embed_dim)
         self.pos_embed = nn.Parameter(torch.zeros(1, grid, grid, embed_dim))
         self.blocks = nn.ModuleList([
-            Block(embed_dim, num_heads, mlp_ratio, window_size if i not in global_attn_indexes else 0, (grid, grid))
+            Block(embed_dim, num_heads, mlp_ratio, window_size if i not in global_attn_indexes else 0, (grid, grid), qkv_bias, use_rel_pos)
             for i in range(depth)])
         self.spm = SpatialPriorModuleBimodal(conv_inplane, embed_dim, img_size, arch)
         self.up = nn.ConvTranspose2d(embed_dim, embed_dim, 2, 2)

@@ -37,6 +37,8 @@ CONFIGS = {
     "tiny320": dict(kwargs=dict(_TINY, img_size=320), batch=1, seed=3, in_seed=7),
     # the constructor switches no shipped config turns off (BK:32-34): extractors without ConvFFN (AM:485-488), no extra extractors in
     # the last interaction (BK:91-92), no ViT feature added in the tail (BK:326)
+    # a ViT without relative position tables and without a qkv bias (IE:317,320-327): the kernels run on zero stand-ins
+    "tiny256_norel": dict(kwargs=dict(_TINY, img_size=256, use_rel_pos=False, qkv_bias=False), batch=1, seed=23, in_seed=24),
     "tiny256_plain": dict(kwargs=dict(_TINY, img_size=256, with_cffn=False, use_extra_extractor=False, add_vit_feature=False),
                           batch=1, seed=21, in_seed=22),
     "vitb512": dict(kwargs=_VITB, batch=1, seed=4, in_seed=8),

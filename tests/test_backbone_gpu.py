@@ -28,7 +28,7 @@ def _build(name):
     return cfg, orc, m
 
 
-@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain"])
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel"])
 def test_tiny_models_vs_golden_and_oracle(golden_dir, name):
     cfg, orc, m = _build(name)
     g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))

@@ -32,6 +32,15 @@ def test_state_dict_contract_with_the_constructor_switches_off(golden_dir):
     assert list(sd.keys()) == [k for k, _ in lines]
     assert all(list(sd[k].shape) == eval(s) for k, s in lines)
     assert not any(".ffn" in k or "extra_extractors" in k for k in sd)
+    # ... and of a ViT without rel-pos tables / qkv bias (IE:317,320-327); use_abs_pos=False is refused (the reference's forward fails on it, BK:276)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **CONFIGS["tiny256_norel"]["kwargs"]))
+    lines = [l.rstrip("\n").split(" ", 1) for l in open(os.path.join(golden_dir, "state_dict_keys_tiny_norel.txt"))]
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _ in lines]
+    assert all(list(sd[k].shape) == eval(s) for k, s in lines)
+    assert not any("rel_pos" in k or k.endswith("qkv.bias") for k in sd)
+    with pytest.raises(NotImplementedError):
+        mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **dict(CONFIGS["tiny256"]["kwargs"], use_abs_pos=False)))
 
 
 def test_plugin_registry_and_state_dict_contract(golden_dir):

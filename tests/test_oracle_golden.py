@@ -86,10 +86,10 @@ def _check_model(golden_dir, name, full):
             assert (got_full - ref_full).abs().max().item() <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain"])
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel"])
 def test_oracle_tiny_models(golden_dir, name):
     """224: window padding 14->14 none, rel-pos interpolation (pretrained 256); 256: pad 16->28; 320: pad 20->28; 256_plain: the
-    constructor switches off -- with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34, AM:485-500, BK:91-92, BK:326)."""
+    constructor switches off -- with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34, AM:485-500, BK:91-92, BK:326); 256_norel: use_rel_pos = qkv_bias = False (IE:317,320-327)."""
     _check_model(golden_dir, name, full=True)
 
 
@@ -102,7 +102,8 @@ def test_oracle_vitl1024(golden_dir):
     _check_model(golden_dir, "vitl1024", full=False)
 
 
-@pytest.mark.parametrize("name,keys", [("tiny224", "state_dict_keys_tiny.txt"), ("tiny256_plain", "state_dict_keys_tiny_plain.txt")])
+@pytest.mark.parametrize("name,keys", [("tiny224", "state_dict_keys_tiny.txt"), ("tiny256_plain", "state_dict_keys_tiny_plain.txt"),
+                                       ("tiny256_norel", "state_dict_keys_tiny_norel.txt")])
 def test_state_dict_keys_match_reference(golden_dir, name, keys):
     m = R.OracleEncoder(**CONFIGS[name]["kwargs"])
     want = [l.split(" ")[0] for l in open(os.path.join(golden_dir, keys))]

@@ -131,8 +131,8 @@ def gen_model(name, full):
         if full:
             out[f"f{i+1}"] = f.numpy() if i > 0 or f.shape[-1] <= 56 else f[..., ::2, ::2].contiguous().numpy()
     np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **out)
-    if name == "tiny256_plain":
-        with open(os.path.join(OUT, "state_dict_keys_tiny_plain.txt"), "w") as fh:
+    if name in ("tiny256_plain", "tiny256_norel"):
+        with open(os.path.join(OUT, f"state_dict_keys_{name.replace('256', '')}.txt"), "w") as fh:
             for k, s in zip(keys, shapes):
                 fh.write(f"{k} {s}\n")
     if name == "tiny224":
@@ -308,7 +308,7 @@ def main():
     gen_msda_bwd()
     gen_msda()
     gen_bookkeeping()
-    for n in ("tiny224", "tiny256", "tiny320", "tiny256_plain"):
+    for n in ("tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel"):
         gen_model(n, full=True)
     gen_slide()
     gen_whole_dim()
