@@ -192,7 +192,10 @@ int mmsa_lnhw_apply(const float* x, long ldx, const float* mean, const float* rs
 int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias, float* y, long ldy,
                      long ystrideB, uint16_t* y_planes, long ldp, long pstrideB /* optional operand planes */, int planes_fmt /* MMSA_FMT_* */,
                      int B, int H, int W, int C, int k, int act,
-                     int imgs_per_group /* > 0: image group g = b / imgs_per_group uses w + g*k*k*C, bias + g*C */, mmsa_stream_t stream);
+                     int imgs_per_group /* > 0: image group g = b / imgs_per_group uses w + g*k*k*C, bias + g*C */,
+                     float* rowstats /* optional, 7x7 only (C % 64 == 0, H, W % 8 == 0): per pixel and 64-channel chunk (sum, sum of squares) of the
+                                        output, [B*H*W][C/64][2]: the strip sums of the LayerNorm fold (mmsa_rowstats_finalize) */,
+                     mmsa_stream_t stream);
 /* ConvNeXt block front half fused: 7x7 depthwise conv (TC:69-70,102) + LayerNorm over channels (TC:103-106, eps as given) ->
    interleaved planes [B*H*W, 2*C] (the A operand of pointwise_conv1).  C: multiple of 64, <= 384.  Weights tap-major [49][C];
    imgs_per_group > 0: image group g = b / imgs_per_group uses w + g*49*C and bias / ln_w / ln_b + g*C. */

@@ -48,9 +48,15 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
 // The 14 x 14 x 64 input halo tile is staged once in LDS (50 KiB, channel-contiguous so a 16-lane group reads 256
 // contiguous bytes: conflict free); each lane owns a 1 x 4 pixel strip of one 4-channel vector and, per kernel row,
 // reads 10 input vectors once for 7 taps x 4 outputs (70 LDS reads instead of 196 global/L1 reads per 4 outputs).
+// yp / rs (round 3, the ConvNeXt LayerNorm fold): the conv output also -- or only -- as operand planes (whole-line stores through the
+// lane-pair exchange) plus, per pixel and 64-channel chunk, (sum, sum of squares) of the values stored: rs[((img * H * W + pixel) *
+// rs_strips + chunk) * 2 + {0, 1}], the strip sums mmsa_rowstats_finalize turns into (mean, rstd) for a row-normalising GEMM epilogue.
+// Requires C % 64 == 0, H % 8 == 0, W % 8 == 0 (every lane of the workgroup stays active: checked by the launcher).
 __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restrict__ x, long ldx, long xstrideB,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ y, long ldy, long ystrideB,
+                                                            unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
+                                                            float* __restrict__ rs, int rs_strips,
                                                             int H, int W, int C, int tilesX, int imgs_per_group, long w_gstride) {
   constexpr int TW = 14, CB = 64;
   if (imgs_per_group > 0) {   // image groups (the two ConvNeXt streams stacked along the batch) with their own weights
@@ -131,7 +137,18 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int gx = tx0 + ox0 + p;
-    if (gx < W) *reinterpret_cast<float4*>(y + (long)b * ystrideB + ((long)gy * W + gx) * ldy + c) = acc[p];
+    if (y && gx < W) *reinterpret_cast<float4*>(y + (long)b * ystrideB + ((long)gy * W + gx) * ldy + c) = acc[p];
+    if (yp || rs) {   // kernel-uniform; the launcher guarantees full tiles and full 64-channel chunks here
+      const long pix = (long)gy * W + gx;
+      if (yp) store_planes8_pair<1>(yp + (long)b * pstrideB + pix * ldp, c & ~7, acc[p], yp_fmt, (cv & 1) != 0, true);
+      if (rs) {     // the 16 lanes cv = 0..15 of this strip hold the pixel's 64 channels of the chunk
+        float s1 = (acc[p].x + acc[p].y) + (acc[p].z + acc[p].w);
+        float s2 = fmaf(acc[p].x, acc[p].x, acc[p].y * acc[p].y) + fmaf(acc[p].z, acc[p].z, acc[p].w * acc[p].w);
+#pragma unroll
+        for (int sh = 8; sh > 0; sh >>= 1) { s1 += __shfl_xor(s1, sh, 64); s2 += __shfl_xor(s2, sh, 64); }
+        if (cv == 0) *reinterpret_cast<float2*>(rs + (((long)b * H * W + pix) * rs_strips + blockIdx.y) * 2) = make_float2(s1, s2);
+      }
+    }
   }
 }
 
@@ -175,20 +192,25 @@ __global__ __launch_bounds__(256) void dwconv3_nhwc_kernel(const float* __restri
 
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
                                 float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB, int yp_fmt,
-                                int B, int H, int W, int C, int k, int act, int imgs_per_group, hipStream_t stream) {
+                                int B, int H, int W, int C, int k, int act, int imgs_per_group, float* rowstats, hipStream_t stream) {
   MMSA_CHECK_ARG(yp_fmt == MMSA_FMT_B3 || yp_fmt == MMSA_FMT_H8, "dwconv_nhwc: bad output plane format %d", yp_fmt);
   MMSA_CHECK_ARG(x && w && (y || yp) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
   MMSA_CHECK_ARG(imgs_per_group >= 0 && (imgs_per_group == 0 || B % imgs_per_group == 0), "dwconv_nhwc: bad image grouping");
   MMSA_CHECK_ARG(!yp || ((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0 && (pstrideB & 63) == 0), "dwconv_nhwc: bad output planes");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "dwconv_nhwc: odd kernel <= 7 expected, got %d", k);
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (xstrideB & 3) == 0 && (ystrideB & 3) == 0, "dwconv_nhwc: C/ld must be multiples of 4");
-  if (k == 7 && y && !yp && act == ACT_NONE && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)bias)) & 15) == 0) {
+  const bool extras = yp || rowstats;   // planes / strip-sum outputs exist on the tiled 7 x 7 kernel only, on full tiles and chunks
+  MMSA_CHECK_ARG(!rowstats || (k == 7 && act == ACT_NONE), "dwconv_nhwc: rowstats are written by the 7x7 kernel without activation only");
+  if (k == 7 && (y || yp) && act == ACT_NONE && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)bias)) & 15) == 0 &&
+      (!extras || ((C & 63) == 0 && (H & 7) == 0 && (W & 7) == 0))) {
     const int tx = cdiv(W, 8), ty = cdiv(H, 8);
     dim3 grid(tx * ty, cdiv(C, 64), B);
-    hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, H, W, C, tx, imgs_per_group, (long)k * k * C);
+    hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB,
+                       yp, ldp, pstrideB, yp_fmt, rowstats, C >> 6, H, W, C, tx, imgs_per_group, (long)k * k * C);
     MMSA_CHECK_LAUNCH("dwconv_nhwc(7x7 tiled)");
     return MMSA_OK;
   }
+  MMSA_CHECK_ARG(!rowstats, "dwconv_nhwc: rowstats need the tiled 7x7 kernel (C %% 64 == 0, H, W %% 8 == 0, 16-byte aligned pointers)");
   MMSA_CHECK_ARG(imgs_per_group == 0 || imgs_per_group == B, "dwconv_nhwc: image groups are implemented by the tiled 7x7 kernel only");
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
   static const bool generic3 = getenv("MMSA_DWCONV3_GENERIC") != nullptr;   // A/B aid

@@ -364,6 +364,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             c_ = min(w2d.shape)
             on = "cnx" in h8_sites or ("cnx2" in h8_sites and c_ == self.channels[2])
             return ops.FMT_H8 if (on and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_)) else ops.FMT_B3
+        # ConvNeXt LayerNorm fold (round 3): OPT-IN (`model.fold_convnext_ln = True` or MMSA_FOLD_CNX_LN=1).  Built, tested, and measured at
+        # ViT-L 1024^2: step -0.17 ms, golden probes 2.9e-4 -> 4.6e-4 (the chain's error is amplified ~15 x by GFFM, DESIGN.md sections 2 and 4.2):
+        # not worth the margin.  Applies to the stages that run pointwise_conv1 as a GEMM (not the fused stage-0 pair), 64-channel chunks.
+        want_cnx = bool(getattr(self, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
+
+        def fold_cnx(c_):
+            return want_cnx and c_ % 64 == 0 and (4 * c_) % 128 == 0 and not ops.convnext_mlp_fused_supported(c_)
+        pk["fold_cnx_ln"] = want_cnx
         t = "spm.twin_conv."
         pk["twin"] = {}
         for s in ("x", "y"):
@@ -379,11 +387,20 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 for j in range(self.depths[i]):
                     b = t + f"stages_{s}.{i}.{j}."
                     dw = sd[b + "depthwise_conv.weight"]  # [C,1,7,7] -> tap-major [49, C]
-                    blks.append(dict(dw=dw.reshape(dw.shape[0], 49).t().contiguous(), dw_b=sd[b + "depthwise_conv.bias"],
-                                     nw=sd[b + "norm.weight"], nb=sd[b + "norm.bias"],
-                                     pw1=planes(sd[b + "pointwise_conv1.weight"], fmt=cfmt(sd[b + "pointwise_conv1.weight"])), pw1_b=sd[b + "pointwise_conv1.bias"],
-                                     pw2=planes(sd[b + "pointwise_conv2.weight"], fmt=cfmt(sd[b + "pointwise_conv2.weight"])), pw2_b=sd[b + "pointwise_conv2.bias"],
-                                     gamma=sd[b + "gamma"]))
+                    blk = dict(dw=dw.reshape(dw.shape[0], 49).t().contiguous(), dw_b=sd[b + "depthwise_conv.bias"],
+                               nw=sd[b + "norm.weight"], nb=sd[b + "norm.bias"],
+                               pw1=planes(sd[b + "pointwise_conv1.weight"], fmt=cfmt(sd[b + "pointwise_conv1.weight"])), pw1_b=sd[b + "pointwise_conv1.bias"],
+                               pw2=planes(sd[b + "pointwise_conv2.weight"], fmt=cfmt(sd[b + "pointwise_conv2.weight"])), pw2_b=sd[b + "pointwise_conv2.bias"],
+                               gamma=sd[b + "gamma"])
+                    if fold_cnx(self.channels[i]):
+                        # the block's LayerNorm (TC:103-106) folded into pointwise_conv1: W o w as planes, their column sums as the kernel
+                        # reads them, W b + bias (the depthwise conv writes the RAW planes + strip sums, _spm)
+                        w1 = sd[b + "pointwise_conv1.weight"]
+                        pl = planes(w1 * sd[b + "norm.weight"][None, :], fmt=cfmt(w1))
+                        blk["pw1f"] = pl
+                        blk["pw1_cs"] = ops.planes_to_float(pl, cols=w1.shape[1])[: w1.shape[0]].double().sum(1).float().contiguous()
+                        blk["pw1_bf"] = (w1.double() @ sd[b + "norm.bias"].double()).float().add_(sd[b + "pointwise_conv1.bias"]).contiguous()
+                    blks.append(blk)
                 st["stages"].append(blks)
                 st["out_norm"].append((sd[t + f"norm_{s}{i}.weight"], sd[t + f"norm_{s}{i}.bias"]))
             pk["twin"][s] = st
@@ -1028,7 +1045,22 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             fused = ops.dwconv7_ln_supported(c) and getattr(self, "fuse_dwconv_ln", False)
             # narrow stages (C = 96 / 192): the pointwise pair as ONE kernel that keeps the 4C hidden tensor in LDS (csrc/mlp_fused.hip)
             fuse_mlp = ops.convnext_mlp_fused_supported(c) and bool(getattr(self, "fuse_convnext_mlp", True)) and os.environ.get("MMSA_FUSE_MLP", "1") != "0"
+            fold = "pw1f" in st["stages"][i][0] and not fused and not fuse_mlp and hh % 8 == 0 and wwd % 8 == 0 and P >= 128
+            if fold:
+                rs = ws.get(t + "rs", 2 * P, 2 * (c // 64))
+                mr = ws.get(t + "mr", 2 * P, 2)
             for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
+                if fold:
+                    # LayerNorm folded (like the ViT blocks'): the depthwise conv writes its RAW output as planes + per pixel and
+                    # 64-channel chunk (sum, sum of squares); pointwise_conv1 runs on W o w and normalises in its epilogue
+                    ops.dwconv(cur, blk["dw"], blk["dw_b"], None, 2 * B, hh, wwd, 7, imgs_per_group=B, out_planes=n, rowstats_out=rs)
+                    ops.rowstats_finalize(rs, 2 * P, c, 1e-6, mr)
+                    ops.gemm(n, blk["pw1f"], bias=blk["pw1_bf"], act="gelu", out_planes=hbuf, row_norm=(mr, blk["pw1_cs"]), batch=2, m=P,
+                             stride_a=P * 2 * n.kpad, stride_w=blk["pw1f"].n * 2 * blk["pw1f"].kpad, stride_bias=4 * c, stride_cp=P * 2 * hbuf.kpad)
+                    ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur, batch=2, m=P,
+                             stride_a=P * 2 * hbuf.kpad, stride_w=blk["pw2"].n * 2 * blk["pw2"].kpad, stride_bias=c,
+                             stride_r=P * c, stride_c=P * c)
+                    continue
                 if fused:   # depthwise conv + LayerNorm in one kernel: the conv output never goes to memory
                     ops.dwconv7_ln(cur, blk["dw"], blk["dw_b"], blk["nw"], blk["nb"], 1e-6, n, 2 * B, hh, wwd, imgs_per_group=B)
                 else:

@@ -54,7 +54,7 @@ SIGNATURES = {
     "mmsa_colstats": [P, L, L, P, I, I, I, P, I, P],
     "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P, P],
     "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
-    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, I, P],
+    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, I, P, P],
     "mmsa_dwconv7_ln": [P, L, L, P, P, P, P, F, P, L, L, I, I, I, I, I, P],
     "mmsa_dwpair_gate": [P, L, P, P, L, P, L, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],

@@ -448,8 +448,9 @@ def lnhw_apply(x, mean, rstd, mult, w, bias, out, b, hw):
 
 
 def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=None, out_planes=None, pstride_b=None,
-           imgs_per_group=0):
-    """Depthwise conv; result to fp32 `out` and/or interleaved `out_planes`."""
+           imgs_per_group=0, rowstats_out=None):
+    """Depthwise conv; result to fp32 `out` and/or interleaved `out_planes`.  rowstats_out (7 x 7 only): fp32 [b*h*wd, 2*(C/64)] strip
+    sums of the output for a row-normalising consumer GEMM (the ConvNeXt LayerNorm fold)."""
     px, _, c, ldx = _mat(x, "x")
     po, ldo = None, 0
     if out is not None:
@@ -461,7 +462,7 @@ def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=N
     ys = h * wd * ldo if ystride_b is None else ystride_b
     ps = h * wd * ldp if pstride_b is None else pstride_b
     lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, out_planes.fmt if out_planes is not None else FMT_B3,
-             b, h, wd, c, k, ACT[act], imgs_per_group, _stream())
+             b, h, wd, c, k, ACT[act], imgs_per_group, _chk(rowstats_out), _stream())
     return out if out is not None else out_planes
 
 

@@ -64,6 +64,24 @@ def test_constructor_switches_one_at_a_time(flag):
         assert_close(f, r, what=f"{flag}=False f{i+1} vs oracle")
 
 
+def test_convnext_layernorm_fold_opt_in(golden_dir):
+    """`fold_convnext_ln` (opt-in: at ViT-L it costs more error than its 0.17 ms are worth): the ConvNeXt blocks' LayerNorm
+    folded into pointwise_conv1 at the stages where the shapes allow it; within the gate against the golden, and not bit-equal to the default."""
+    import mmsa
+    cfg, orc, m = _build("tiny320")
+    x = make_input(cfg)
+    base, _ = m(x.to(DEV))
+    m2 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m2.load_state_dict(m.state_dict())
+    m2.fold_convnext_ln = True
+    fs, _ = m2(x.to(DEV))
+    assert m2._packed["fold_cnx_ln"] and any("pw1f" in blk for st in m2._packed["twin2"]["stages"] for blk in st)
+    ref, _ = orc(x)
+    for i, (f, r) in enumerate(zip(fs, ref)):
+        assert_close(f, r, what=f"ConvNeXt LN fold f{i+1} vs oracle")
+    assert not all(torch.equal(a, b) for a, b in zip(fs, base))
+
+
 def test_batch_and_determinism():
     cfg, orc, m = _build("tiny256")
     x = make_input(cfg, batch=3, seed=77)

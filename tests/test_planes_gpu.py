@@ -559,6 +559,52 @@ def test_layernorm_h8_planes(ops, rows, C):
     assert torch.equal(p.p[:, :2 * ops.pad32(C)].cpu().view(torch.uint8).view(rows, -1, 128)[:, :C // 32], p2.p.cpu().view(torch.uint8).view(rows, -1, 128)[:, :C // 32])
 
 
+def test_convnext_block_layernorm_fold(ops):
+    """The ConvNeXt block's front half with its LayerNorm folded (TC:102-111): the 7 x 7 depthwise conv writes the RAW output as planes plus
+    per pixel and 64-channel chunk (sum, sum of squares); mmsa_rowstats_finalize -> (mean, rstd); pointwise_conv1 on W o w normalises in
+    its epilogue.  Two image groups with their own weights (the two TwinConvNeXt streams), batched GEMM.  Against float64."""
+    H, W, C = 16, 24, 128      # one image per group
+    N = 4 * C
+    x = torch.randn(2, H * W, C, generator=g(301)) * 1.3 + 0.2
+    dw = torch.randn(2, C, 7, 7, generator=g(302)) * 0.1
+    dwb = torch.randn(2, C, generator=g(303)) * 0.1
+    lnw, lnb = 1.0 + 0.1 * torch.randn(2, C, generator=g(304)), 0.05 * torch.randn(2, C, generator=g(305))
+    w1 = torch.randn(2, N, C, generator=g(306)) / C ** 0.5
+    b1 = torch.randn(2, N, generator=g(307)) * 0.1
+    d64, ref = [], []
+    for s_ in range(2):
+        xi = x[s_].double().t().reshape(1, C, H, W)
+        d = F.conv2d(xi, dw[s_].double().unsqueeze(1), dwb[s_].double(), padding=3, groups=C)[0].reshape(C, H * W).t()
+        d64.append(d)
+        ref.append(F.gelu(F.layer_norm(d, (C,), lnw[s_].double(), lnb[s_].double(), 1e-6) @ w1[s_].double().t() + b1[s_].double()))
+    d64, ref = torch.cat(d64), torch.cat(ref)
+    P = H * W
+    xd = x.reshape(2 * P, C).contiguous().to(DEV)
+    wt = dw.reshape(2, C, 49).permute(0, 2, 1).contiguous().to(DEV)       # [group][49][C] tap-major
+    n = ops.alloc_planes(2 * P, C, DEV)
+    rs = torch.full((2 * P, 2 * (C // 64)), float("nan"), device=DEV)
+    ops.dwconv(xd, wt, dwb.to(DEV).contiguous(), None, 2, H, W, 7, imgs_per_group=1, out_planes=n, rowstats_out=rs)
+    assert_close(planes_to_float(n), d64.float(), tol=2e-5, what="depthwise conv planes")
+    want = torch.stack([d64.view(2 * P, C // 64, 64).sum(-1), (d64 ** 2).view(2 * P, C // 64, 64).sum(-1)], -1).view(2 * P, -1)
+    assert_close(rs, want.float(), tol=2e-5, what="strip sums of the conv output")
+    mr = torch.empty(2 * P, 2, device=DEV)
+    ops.rowstats_finalize(rs, 2 * P, C, 1e-6, mr)
+    wps = [ops.split_planes((w1[s_] * lnw[s_][None, :]).to(DEV).contiguous()) for s_ in range(2)]
+    buf = torch.cat([wps[0].p, wps[1].p], 0).contiguous()
+    wp = ops.Planes(buf[:N], N, C, wps[0].kpad, wps[0].fmt, wps[0].weight)
+    wp.full = buf
+    cs = torch.cat([planes_to_float(wps[s_])[:N, :C].double().sum(1).float() for s_ in range(2)]).contiguous()
+    bf = torch.cat([(w1[s_].double() @ lnb[s_].double()).float().add(b1[s_]) for s_ in range(2)]).to(DEV).contiguous()
+    out = ops.alloc_planes(2 * P, N, DEV)
+    ops.gemm(n, wp, bias=bf, act="gelu", out_planes=out, row_norm=(mr, cs), batch=2, m=P, stride_a=P * 2 * n.kpad,
+             stride_w=N * 2 * wp.kpad, stride_bias=N, stride_cp=P * 2 * out.kpad)
+    assert_close(planes_to_float(out), ref.float(), tol=4e-5, what="dwconv -> folded LayerNorm -> pointwise_conv1 -> GELU")
+    # without the strip sums the conv is the plain one; and the strip sums need the tiled kernel's shapes
+    with pytest.raises(RuntimeError):
+        ops.dwconv(xd[:, :96].contiguous(), wt[:, :, :96].contiguous(), dwb[:, :96].to(DEV).contiguous(), None, 2, H, W, 7, imgs_per_group=1,
+                   out_planes=ops.alloc_planes(2 * P, 96, DEV), rowstats_out=rs)
+
+
 @pytest.mark.parametrize("fmt_name,act", [("b3", "none"), ("h8", "gelu")])
 def test_gemm_layernorm_fold(ops, fmt_name, act):
     """LayerNorm folded into a producer / consumer pair of GEMMs (IE:396-421; include/mmsa.h mmsa_gemm_next_extras): the producer writes
