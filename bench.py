@@ -33,9 +33,17 @@ Extra objects:
                   the launch stream), against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline -- the CPU oracle (oracle/ref_encoder.py, a PyTorch-CPU restatement validated against the reference)
                   timed on this box's physical host cores on ONE 1024x1024 image (rank 0, N=1 only): one small warm-up
-                  forward, then the median of 3 runs (120 s budget), plus the ViT-B 512x512 line of SURVEY 8(d) (median of 5).
+                  forward, then the median of 3 runs, plus the ViT-B 512x512 line of SURVEY 8(d) (median of 5).
   hbm_kernels  -- GB/s of the HBM-bound kernels of the step against 8 TB/s, from the committed counter passes
                   (profiles/rNN_hbm_kernels.json, tools/pmc_all.sh).
+  replay_ms    -- the same step replayed 20 more times after the timed region, every replay between its own pair of events:
+                  median / min / max (SURVEY 8d asks for the median of >= 20 iterations; `value` stays the contract's K-step total).
+  attention_guard -- the per-block logit guard words read back after the timed region (backbone.check_attention_guard): the largest
+                  |logit| any attention block scored and whether every block stayed inside its operand precision's range.
+  worst_case_precision -- the same step with EVERY GEMM and attention operand in the bf16 hi/lo format (MMSA_H8=none, attention 'b3'):
+                  what a checkpoint whose logits leave the fp16 range in every block would run.
+Counter-derived fields (roofline.traffic, roofline.mfma_counters, hbm_kernels) come from committed profiles and carry the digest of the
+kernel sources they were measured on; a profile whose digest is not that of the sources in the tree is reported as stale, not attached.
 
 MMSA_BENCH_STUB=1 (tests only): no GPU -- gloo on CPU tensors, the device step replaced by a stand-in of known duration; exercises
 rank spawning, sharding, the barrier / max-over-ranks timing, the logits all-gather and the JSON assembly of the N > 1 path.
@@ -155,9 +163,18 @@ def physical_cores():
 
 
 def latest_profile(pattern):
-    """Newest profiles/rNN_<pattern> (round number order)."""
+    """(newest profiles/rNN_<pattern> in round-number order or None, its json or None, note).  The json is returned only when the profile
+    was measured on the kernel sources that are in the tree now (`source_digest` written by tools/pmc_*.py == build.source_digest())."""
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{pattern}")))
-    return fs[-1] if fs else None
+    if not fs:
+        return None, None, "no profile committed"
+    import build as _b   # multimodal-sam-adapter_amd/build.py
+    j = json.load(open(fs[-1]))
+    name = os.path.basename(fs[-1])
+    have, want = j.get("source_digest"), _b.source_digest()
+    if have != want:
+        return fs[-1], None, f"profiles/{name} is STALE: measured on kernel sources {str(have)[:12]}, the tree holds {want[:12]} -- not attached (tools/pmc_all.sh)"
+    return fs[-1], j, f"profiles/{name} (kernel sources {want[:12]}, commit {j.get('commit', 'n/a')})"
 
 
 def main():
@@ -202,8 +219,6 @@ def main():
     if model is not None and not a.default_init:
         model.load_state_dict(seeded_state_dict(model, seed=cfg["seed"]))
     x = make_input(cfg if not STUB else CONFIGS["tiny256"], batch=a.batch, seed=1234 + rank).to(dev)
-    if os.environ.get("MMSA_FUSE_DWLN") == "1":   # A/B aid: ConvNeXt depthwise conv + LayerNorm as one kernel (slower: csrc/conv_ln.hip)
-        model.fuse_dwconv_ln = True
 
     head = None
     stub_logits = torch.full((a.batch, 25, 8, 8), float(rank)) if STUB else None
@@ -321,6 +336,26 @@ def main():
     elif chains is None:
         replay, local_out, graphed = capture(local_step)
         graph_feats = feats[0]                 # the four output maps the captured graph writes (fixed addresses)
+    # ---- attention logit guard: the step has replayed on this input -- every block must have stayed inside its operand precision's range
+    # (a block that did not is moved to bf16 hi/lo operands and the graphs are captured again: mmsa.Chains.check_guard / a second capture)
+    guard_rerouted = []
+    if model is not None:
+        torch.cuda.synchronize()
+        for _ in range(cfg["kwargs"]["depth"] + 1):
+            moved = model.check_attention_guard()
+            if not moved:
+                break
+            guard_rerouted += moved
+            if chains is not None:
+                chains.capture(x)
+                replay = chains.replay
+                if head is not None:
+                    local_out = chains.logits
+            else:
+                replay, local_out, graphed = capture(local_step)
+                graph_feats = feats[0]
+            replay()
+            torch.cuda.synchronize()
     gathered = [None]
 
     def run():
@@ -331,6 +366,27 @@ def main():
     dt = timed(run)
     imgs = a.batch * world * a.steps
     value = imgs / dt
+    replay_ms = None
+    if not STUB:   # median of >= 20 iterations, each between its own events (untimed by the contract's clock)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(20, a.steps))]
+        for e0, e1 in evs:
+            e0.record()
+            run()
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        replay_ms = {"n": len(ts), "median": round(statistics.median(ts), 3), "min": round(ts[0], 3), "max": round(ts[-1], 3),
+                     "images_per_s_at_median": round(a.batch * world / (statistics.median(ts) * 1e-3), 3),
+                     "note": "this rank's step (+ the all-gather at N > 1) replayed after the timed region, one event pair per replay"}
+    guard = None
+    if model is not None:
+        still = model.check_attention_guard(reroute=False)
+        ml = [lg for _, lg in model.attention_modes()]
+        guard = {"threshold_fp16": model.ATTN_F16_MAX_LOGIT, "max_abs_logit": round(max(ml), 3) if ml else None,
+                 "blocks_rerouted_before_timing": sorted(set(guard_rerouted)), "blocks_out_of_range_in_timed_region": still,
+                 "note": "max |scale*q.k + rel-pos| per ViT block, folded into one device word per block by the attention kernels on every replay"}
+        if still:
+            raise SystemExit(f"[bench] attention blocks {still} ran fp16 attention beyond its logit range inside the timed region")
     if (head is not None or STUB) and use_dist and rank == 0:
         assert gathered[0].shape[0] == world * a.batch
         if STUB:    # every rank's shard arrived, in rank order
@@ -411,20 +467,18 @@ def main():
         model.multistream = True
         flops, ms = mmsa.ops.collect_gemm_profile(prof)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, tnote = None, "not measured"
-        tfile = latest_profile("gemm_traffic.json")   # written by tools/pmc_traffic.sh (rocprofv3 --pmc passes)
-        if tfile and a.config == "vitl1024":
-            tj = json.load(open(tfile))
+        traffic = None
+        _, tj, tnote = latest_profile("gemm_traffic.json")   # written by tools/pmc_traffic.sh (rocprofv3 --pmc passes)
+        if tj and a.config == "vitl1024":
             traffic = round(tj["traffic_bytes_per_launch"])
-            tnote = (f"HBM-side bytes per launch (average over the step's GEMM launches) from profiles/{os.path.basename(tfile)}: rocprofv3 "
-                     "--pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes of this workload")
-        mfile = latest_profile("mfma_util.json")   # written by tools/pmc_mfma.sh (rocprofv3 --pmc MfmaUtil / MOPS passes)
-        mfma = None
-        if mfile and a.config == "vitl1024":
-            mj = json.load(open(mfile))
+            tnote = ("HBM-side bytes per launch (average over the step's GEMM launches): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, "
+                     "separate passes of this workload; " + tnote)
+        _, mj, mnote = latest_profile("mfma_util.json")   # written by tools/pmc_mfma.sh (rocprofv3 --pmc MfmaUtil / MOPS passes)
+        mfma = {"source": mnote}
+        if mj and a.config == "vitl1024":
             mfma = {"gemm_family_mfma_util_pct": round(mj["gemm_family"]["mfma_util_pct"], 1), "gemm_family_mfma_tflops_counted": round(mj["gemm_family"]["mfma_tflops"], 1),
                     "whole_step_mfma_util_pct": round(mj["whole_step"]["mfma_util_pct"], 1), "whole_step_mfma_tflops_counted": round(mj["whole_step"]["mfma_tflops"], 1),
-                    "source": f"profiles/{os.path.basename(mfile)}: rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{{BF16,F16,F8,F32}} passes of this workload"}
+                    "source": "rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{BF16,F16,F8,F32} passes of this workload; " + mnote}
         roofline = {"bound": "mfma", "kernel": "split-operand GEMM (gemm_v2_kernel bf16 hi/lo and h8 flavours + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                     "compulsory_bytes_per_launch": round(mmsa.ops.collect_gemm_profile.bytes / max(len(prof), 1)),
@@ -434,6 +488,33 @@ def main():
                     "note": "algorithmic 2*M*N*K FLOPs against the dense bf16/fp16 MFMA peak; for fp32-level parity every operand is a hi + lo pair: bf16 hi/lo "
                             "sites issue 3 bf16 MFMAs per algorithmic product, h8 sites 1 fp16 MFMA + the two cross terms on one block-scaled fp8 MFMA at "
                             "twice the rate (2 units)"}
+
+    worst = None
+    if model is not None and world == 1 and not a.no_roofline and os.environ.get("MMSA_H8") is None and os.environ.get("MMSA_ATTN") is None:
+        # every operand of every GEMM and attention kernel as a bf16 hi/lo pair: the operand formats a checkpoint with peaky attention in every
+        # block falls back to.  Re-packs the weights (the graphs captured above are dead from here on: nothing replays them again).
+        del replay, chains
+        keep_sites, keep_prec = getattr(model, "h8_sites", None), model.attention_precision
+        model.h8_sites, model.attention_precision = (), "b3"
+        try:
+            model(x[:1])     # packs
+            torch.cuda.synchronize()
+            if nch > 1:
+                wch = mmsa.Chains(model, head, n=nch).capture(x)
+                wrep = wch.replay
+            else:
+                wrep, _, _ = capture(local_step)
+            wdt = timed(wrep)
+            worst = {"value": round(a.batch * a.steps / wdt, 3), "unit": "images/s", "ms_per_step": round(wdt / a.steps * 1e3, 3),
+                     "formats": "every GEMM and attention operand bf16 hi/lo (h8_sites = (), attention_precision = 'b3'); same step, same graphs / chains form",
+                     "vs_value": round(a.batch * a.steps / wdt / value, 4)}
+            del wrep
+        finally:
+            if keep_sites is None:
+                del model.h8_sites
+            else:
+                model.h8_sites = keep_sites
+            model.attention_precision = keep_prec
 
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.config == "vitl1024":
@@ -454,7 +535,7 @@ def main():
                 times.append(time.perf_counter() - tc)
             return statistics.median(times), times
 
-        tcpu, times = cpu_line("vitl1024", 3, 120.0)
+        tcpu, times = cpu_line("vitl1024", 3, 240.0)
         tb, times_b = cpu_line("vitb512", 5, 40.0)
         cpu = {"value": round(1.0 / tcpu, 4), "unit": "images/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model,
                "sample": f"1 image 1024x1024 ViT-L RGB+LiDAR, fp32 PyTorch-CPU oracle, {ncores} threads (physical cores), tiny warm-up forward then "
@@ -469,16 +550,16 @@ def main():
         size = cfg["kwargs"]["img_size"] if not STUB else 0
         arch = {"vitl1024": "ViT-L", "vith1024": "ViT-H", "vitb512": "ViT-B", "tiny256": "tiny fixture model"}[a.config]
         attn_blocks = None
-        if model is not None and getattr(model, "_packed", None):   # operand precision each ViT block's attention ran at (backbone._attn_mode)
-            modes = [b.get("amode") for b in model._packed["blocks"]]
-            logits = [b.get("max_logit") for b in model._packed["blocks"] if b.get("max_logit") is not None]
-            attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3"), "max_logit": round(max(logits), 2) if logits else None}
+        if model is not None and getattr(model, "_packed", None):   # operand precision each ViT block's attention runs at (backbone.check_attention_guard)
+            modes = [m_ for m_, _ in model.attention_modes()]
+            attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3")}
         hbm = None
-        hfile = latest_profile("hbm_kernels.json")
-        if hfile and headline and not a.no_roofline:
-            hj = json.load(open(hfile))
-            hbm = {"peak_GBps": hj.get("peak_GBps", 8000.0), "source": f"profiles/{os.path.basename(hfile)}",
-                   "kernels": {k: {"GBps": v["GBps"], "frac": v["frac"]} for k, v in hj["kernels"].items()}}
+        if headline and not a.no_roofline:
+            _, hj, hnote = latest_profile("hbm_kernels.json")
+            hbm = {"source": hnote}
+            if hj:
+                hbm = {"peak_GBps": hj.get("peak_GBps", 8000.0), "source": hnote,
+                       "kernels": {k: {"GBps": v["GBps"], "frac": v["frac"]} for k, v in hj["kernels"].items()}}
         out = {
             "metric": f"images/sec encoder fwd @{size}x{size} RGB+LiDAR {arch}" if not STUB else "stub (no GPU): control path of the N > 1 bench",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -496,7 +577,7 @@ def main():
             "verified": verified,
             "encoder_only": encoder_only,
             "end_to_end_algorithmic_tflops": round(value * fpi / 1e12, 1) if fpi else None,
-            "chains_probe_ms": chain_probe,
+            "chains_probe_ms": chain_probe, "replay_ms": replay_ms, "attention_guard": guard, "worst_case_precision": worst,
             "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         try:   # RCCL prints a banner through C stdio; flush it so that the JSON line is the LAST line of stdout

@@ -13,6 +13,9 @@
  *  - the caller owns all memory (inputs, outputs, workspaces); the library never allocates or frees.
  *  - every call enqueues work on `stream` (a hipStream_t) and returns immediately; no host sync inside, so the
  *    whole forward can be captured into a HIP graph.
+ *  - the library is stateless: no environment variable is read and there is no writable global besides the thread-local error string
+ *    (A/B knobs exist only in debug-knob builds of single sources, tools/build_variant.sh -DMMSA_DEBUG_KNOBS); what used to be set
+ *    through `mmsa_debug_*_flavour` / `mmsa_gemm_next_extras` is an explicit argument of the call it concerns.
  *  - return 0 on success, negative on error; `mmsa_last_error()` returns a thread-local message.  Shapes,
  *    alignment and strides are validated on the host BEFORE anything is launched.
  *  - activations are fp32, token-major / NHWC: a [rows, channels] matrix with a row stride `ld*` in elements.
@@ -38,15 +41,9 @@ typedef void* mmsa_stream_t; /* hipStream_t */
 int mmsa_version(void);
 const char* mmsa_last_error(void);
 
-/* HIP events on the launch stream (for bench.py; torch.cuda.Event only sees torch's current stream). */
 /* testing aid: fill the LDS of every CU with `pattern` (finds kernels that read LDS they did not write) */
 int mmsa_debug_poison_lds(unsigned pattern, mmsa_stream_t stream);
-/* testing / A-B aid: force the workgroup flavour of mmsa_gemm_split3's LDS-DMA kernel (4 = 128-row tiles, two workgroups per CU;
- * 8 = 256-row ping-pong tiles; 3 = the 4-wave kernel whose epilogue runs inside the next k loop, gemm_v3.hip; 0 = automatic by shape).  Results are bit-identical either way (same k order per output element). */
-int mmsa_debug_gemm_flavour(int waves_per_workgroup);
-/* testing / A-B aid for mmsa_window_attention_planes with v_fmt = 2: 2 = the one-barrier persistent kernel (double-buffered hi-only K / V
- * images; measured slower, opt-in), 1 = the three-barrier persistent kernel, 0 = automatic (= 1 today).  Results are bit-identical. */
-int mmsa_debug_wattn_flavour(int flavour);
+/* HIP events on the launch stream (for bench.py; torch.cuda.Event only sees torch's current stream). */
 int mmsa_event_create(void** ev);
 int mmsa_event_record(void* ev, mmsa_stream_t stream);
 int mmsa_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
@@ -108,14 +105,15 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * whatever the base format (the qkv projection: q and k bf16 hi/lo, v with an fp16 hi part for the attention kernels' v_fmt = 1).
  * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
  * its share of the CUs); 0 = all CUs.  Results do not depend on it. */
-/* LayerNorm folded into a producer / consumer pair of GEMMs (base/image_encoder.py:396-421: x -> norm1 -> qkv, x -> norm2 -> lin1).  One-shot
- * extras of the NEXT mmsa_gemm_split3 call (cleared by it; that call must be one the LDS-DMA kernel takes: activation planes, M >= 128):
+/* LayerNorm folded into a producer / consumer pair of GEMMs (base/image_encoder.py:396-421: x -> norm1 -> qkv, x -> norm2 -> lin1): three
+ * optional arguments of the call (it must then be one the LDS-DMA kernel takes: activation planes, M >= 128):
  *   rowstats_out [M, N/64, 2] fp32: the call also writes, per output row and 64-column strip, the sum and the sum of squares of the fp32
  *     values it stores (plain fp32 output, no activation, N % 64 == 0) -- the producer of the residual stream;
  *   rownorm_mean_rstd [M, 2] + rownorm_colsum [N] (batch stride = strideBias): the call runs on the RAW stream's planes against W o w and its
  *     epilogue computes rstd_r * (acc - mean_r * colsum_n) + bias_n before the activation (planes-only output, N % 128 == 0) -- the consumer.
- * mmsa_rowstats_finalize turns the strip sums into (mean, rstd) per row (D = 64 * strips columns, biased variance, eps inside the root). */
-int mmsa_gemm_next_extras(float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum);
+ * mmsa_rowstats_finalize turns the strip sums into (mean, rstd) per row (D = 64 * strips columns, biased variance, eps inside the root).
+ * flavour: 0 = workgroup shape chosen by the problem (256-row ping-pong tiles; 128-row tiles, two workgroups per CU, for bf16 hi/lo
+ * operands with K <= 256); 4 / 8 force the 128- / 256-row form (tests, A/B runs).  Results are bit-identical either way. */
 int mmsa_rowstats_finalize(const float* rowstats, int rows, int strips, int D, float eps, float* mean_rstd, mmsa_stream_t stream);
 int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      const uint16_t* Wp, long strideW,
@@ -123,7 +121,8 @@ int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      long strideR, int resid_mod, float beta, float* C, long ldc, long strideC,
                      uint16_t* Cp, long ldcp, long strideCp, int M, int N, int K,
                      int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt,
-                     int max_grid, mmsa_stream_t stream);
+                     int max_grid, float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum, int flavour,
+                     mmsa_stream_t stream);
 
 /* ConvNeXt pointwise pair of the narrow stages as ONE kernel (TC:107-132): x[b] <- x[b] + gamma[b] * (GELU(A[b] W1[b]^T + b1[b]) W2[b]^T
  * + b2[b]); A = LayerNorm output as bf16 hi/lo planes [M, C] (row stride lda, batch stride strideA, uint16 units), W1 [4C, C] and
@@ -139,6 +138,11 @@ int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pa
                       mmsa_stream_t stream);
 
 /* --- attention (IE:465-501 incl. window_partition/unpartition IE:504-551 and rel-pos IE:587-623) -------------
+ * Attention logit guard: the planes entries take `max_abs_logit`, an optional DEVICE float (NULL = none).  The launch folds the largest
+ * |logit| it scores -- scale * q.k + the rel-pos terms, natural units, over existing keys (pad tokens of a window included, they are
+ * attended to) and live queries -- into it with an atomic max (never lowered; the caller zeroes it).  The reference computes attention
+ * in fp32 (IE:488-499) and needs no such word; this library chooses the operand precision of a block's attention (v_fmt) from it:
+ * the host reads it after the step and moves a block whose logits outgrow fp16 operands to bf16 hi/lo ones (mmsa/backbone.py). */
  * qkv [B*H*W, ldq] = q|k|v, channel = head*head_dim + c; qkv_bias [3*D]; rp from mmsa_relpos_bias;
  * window_size 0 = global.  out [B*H*W, ldo]. head_dim in {32, 64}. */
 int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo, int B,
@@ -152,7 +156,7 @@ int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* 
                                        P rounded to fp16; 2 (the two fused rel-pos entries below): qkv_planes, bias_planes AND relpos_planes
                                        are h8 planes throughout (and the window kernel's selector holds fp16 ones): every contraction of
                                        the kernel is one fp16 MFMA on the hi parts */,
-                          mmsa_stream_t stream);
+                          float* max_abs_logit /* optional, see "Attention logit guard" */, mmsa_stream_t stream);
 
 /* rel-pos bias terms: rp [B, heads, H*W, KH+KW]; Rh [QS,KH,head_dim], Rw [QS,KW,head_dim] = gathered tables
  * get_rel_pos(...)  (IE:554-584), (KH,KW,QS) = (ws,ws,ws) for windowed blocks or (H,W,max) for global ones. */
@@ -196,12 +200,6 @@ int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, co
                      float* rowstats /* optional, 7x7 only (C % 64 == 0, H, W % 8 == 0): per pixel and 64-channel chunk (sum, sum of squares) of the
                                         output, [B*H*W][C/64][2]: the strip sums of the LayerNorm fold (mmsa_rowstats_finalize) */,
                      mmsa_stream_t stream);
-/* ConvNeXt block front half fused: 7x7 depthwise conv (TC:69-70,102) + LayerNorm over channels (TC:103-106, eps as given) ->
-   interleaved planes [B*H*W, 2*C] (the A operand of pointwise_conv1).  C: multiple of 64, <= 384.  Weights tap-major [49][C];
-   imgs_per_group > 0: image group g = b / imgs_per_group uses w + g*49*C and bias / ln_w / ln_b + g*C. */
-int mmsa_dwconv7_ln(const float* x, long ldx, long xstrideB, const float* w, const float* bias, const float* ln_w, const float* ln_b,
-                    float eps, uint16_t* y_planes, long ldp, long pstrideB, int B, int H, int W, int C, int imgs_per_group,
-                    mmsa_stream_t stream);
 int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
                     int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);
 /* gated pair stage of the neck Mlp (AM:127-132): y = gelu(dw3x3(x)[:, :C]) * dw3x3(x)[:, C:], x token-major [B*H*W, 2C], the
@@ -241,7 +239,8 @@ int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const float* xtok
  *     H <= 64 and a multiple of 4, head_dim 64.  No mmsa_relpos_bias pass. --- */
 int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const uint16_t* relpos_planes,
                                  uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim, float scale,
-                                 int out_fmt /* MMSA_FMT_* of out_planes */, int v_fmt /* 0 or 2: see mmsa_attention_planes */, mmsa_stream_t stream);
+                                 int out_fmt /* MMSA_FMT_* of out_planes */, int v_fmt /* 0 or 2: see mmsa_attention_planes */,
+                                 float* max_abs_logit /* optional */, mmsa_stream_t stream);
 
 /* --- windowed attention with the rel-pos bias fused (Block.forward IE:382-423 on a window_size > 0 block: window_partition ->
  *     Attention.forward IE:465-501 + add_decomposed_rel_pos IE:587-623 -> window_unpartition).  qkv / bias / out as in
@@ -252,7 +251,7 @@ int mmsa_global_attention_planes(const uint16_t* qkv_planes, long ldq, const uin
 int mmsa_window_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes,
                                  const uint16_t* relpos_planes, const uint16_t* selector, uint16_t* out_planes, long ldo, int B, int H, int W,
                                  int heads, int head_dim, int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
-                                 int v_fmt /* 0 or 2: see mmsa_attention_planes */, mmsa_stream_t stream);
+                                 int v_fmt /* 0 or 2: see mmsa_attention_planes */, float* max_abs_logit /* optional */, mmsa_stream_t stream);
 
 /* --- Segformer decode head (segmentation/mmseg_custom/models/decode_heads/segformer_head.py:47-66; the 1x1 convs are
  *     mmsa_gemm_split3 calls).  nchw_to_planes: backbone map [B,C,HW] fp32 (image b at b*strideB) -> interleaved planes

@@ -19,6 +19,17 @@ OUT = os.path.join(HERE, "mmsa", "libmmsa_hip.so")
 CXXFLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-fno-slp-vectorize"]
 
 
+def source_digest():
+    """sha1 over the kernel sources (csrc/*.hip, *.h, *.inc: names and bytes).  The counter profiles under profiles/ carry the digest of the
+    sources they were measured on; bench.py attaches a profile to its JSON line only when it equals the digest of the sources in the tree."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

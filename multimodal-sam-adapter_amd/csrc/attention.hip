@@ -41,6 +41,8 @@ struct AttnArgs {
   int KHs, KWs;                  // odd LDS row strides for the bias tables
   unsigned magicKW;              // ceil(2^24 / KW): j / KW == (j * magic) >> 24 for the j used here
   float scale;
+  float* guard;                  // optional device word: max |logit| (natural units, rel-pos terms included) over every query / key pair the launch
+                                 // scores is folded into it with one atomic max per wave (include/mmsa.h "attention logit guard")
 };
 
 // REL (with PL, FB, HD = 64): the rel-pos terms are computed in the kernel's prologue (MFMA, like wattn.hip) instead of being
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
     for (int d = 0; d < DT; ++d) o[s][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY};
   float l_run[2] = {0.f, 0.f};
+  float amax = 0.f;   // logit guard: largest |score| (log2 units) this lane's LIVE queries have seen
 
   const int nkb = (a.Nk + 63) / 64;
   LOAD_KV(0);
@@ -380,15 +383,19 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         // kw = 16t + 4G + r is the same in every block -> the W-term lives in registers, the H-term is one read
         // the H-term is the same for all 64 keys of the block: it is added to the row maximum, not to every score
         bhv_blk = bhq[kb] * LOG2E;
+        float mn = INFINITY;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = s[sub][t][r] * sc2 + bwr[sub][t][r];
-            s[sub][t][r] = v;
-            mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; r += 2) {
+            const float v0 = s[sub][t][r] * sc2 + bwr[sub][t][r], v1 = s[sub][t][r + 1] * sc2 + bwr[sub][t][r + 1];
+            s[sub][t][r] = v0;
+            s[sub][t][r + 1] = v1;
+            mx = fmaxf(fmaxf(mx, v0), v1);     // v_max3_f32 / v_min3_f32: half an instruction per score for the guard
+            mn = fminf(fminf(mn, v0), v1);
           }
         mx += bhv_blk;
+        if (tq_sub[sub] >= 0) amax = fmaxf(fmaxf(amax, fabsf(mx)), fabsf(mn + bhv_blk));
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
               const int kh = (int)(((unsigned)j * a.magicKW) >> 24);
               const int kw = j - kh * a.KW;
               v = s[sub][t][r] * sc2 + (bhq[kh] + bwq[kw]) * LOG2E;
+              if (tq_sub[sub] >= 0) amax = fmaxf(amax, fabsf(v));
             } else {
               v = -INFINITY;
             }
@@ -473,6 +481,11 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
     }
   }
 
+  // ---- logit guard: one atomic max per wave, and only when it would raise the word (after the first batches it never does)
+  if (a.guard) {
+    const float gv = wave_max(amax) * 0.6931471805599453f;
+    if (lane == 0 && gv > *reinterpret_cast<volatile float*>(a.guard)) atomicMax(reinterpret_cast<unsigned*>(a.guard), __float_as_uint(gv));
+  }
   // ---- epilogue: O[q][16d + 4G .. +3] / l  -> out[token(q)][head*HD + ...]
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
@@ -579,14 +592,15 @@ extern "C" int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias,
 // planes form: qkv, qkv_bias and the output are bf16 hi/lo planes (same layouts, strides in elements)
 extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p, const float* rp,
                                      unsigned short* out_p, long ldo, int B, int H, int W,
-                                     int heads, int head_dim, int window_size, float scale, int out_fmt, int v_fmt, hipStream_t stream) {
+                                     int heads, int head_dim, int window_size, float scale, int out_fmt, int v_fmt, float* max_abs_logit,
+                                     hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && rp && out_p, "attention_planes: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG((heads * head_dim) % 32 == 0, "attention_planes: embed dim must be a multiple of 32");
   AttnArgs a = {};
-  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt; a.vf = v_fmt;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.rp = rp; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt; a.vf = v_fmt; a.guard = max_abs_logit;
   return attention_launch(a, B, H, W, heads, head_dim, window_size, scale, true, stream);
 }
 
@@ -594,14 +608,15 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, cons
 // of 4, head_dim 64.  relpos_planes: interleaved planes of a [256, 64] matrix, rows 0..2H-2 = rel_pos_h, 128..128+2W-2 = rel_pos_w
 extern "C" int mmsa_global_attention_planes(const unsigned short* qkv_p, long ldq, const unsigned short* bias_p,
                                             const unsigned short* relpos_planes, unsigned short* out_p, long ldo, int B, int H, int W,
-                                            int heads, int head_dim, float scale, int out_fmt, int v_fmt, hipStream_t stream) {
+                                            int heads, int head_dim, float scale, int out_fmt, int v_fmt, float* max_abs_logit,
+                                            hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && relpos_planes && out_p, "global_attention_planes: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "global_attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)relpos_planes) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "global_attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG(head_dim == 64 && W == 64 && H <= 64 && (H % 4) == 0, "global_attention_planes: needs head_dim 64 and a W = 64, H <= 64 (multiple of 4) grid");
   AttnArgs a = {};
-  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt; a.vf = v_fmt;
+  a.qp = qkv_p; a.ldq = ldq; a.bp = bias_p; a.relg = relpos_planes; a.op = out_p; a.ldo = ldo; a.ofmt = out_fmt; a.vf = v_fmt; a.guard = max_abs_logit;
   return attention_launch(a, B, H, W, heads, head_dim, 0, scale, true, stream);
 }
 

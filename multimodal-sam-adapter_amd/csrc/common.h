@@ -15,6 +15,17 @@ enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
 extern "C" const char* mmsa_last_error(void);
 void mmsa_set_error(const char* fmt, ...);
 
+// A/B and timing knobs.  The RELEASE library reads no environment variable and holds no writable global besides the thread-local error
+// string: MMSA_KNOB(name, default) is the default, as a constant.  A debug-knob build of one source (tools/build_variant.sh <so> <file>
+// -DMMSA_DEBUG_KNOBS) reads the integer environment variable `name` instead -- the experiments recorded in DESIGN.md were run that way.
+#ifdef MMSA_DEBUG_KNOBS
+#include <stdlib.h>
+static inline int mmsa_knob_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#define MMSA_KNOB(name_, dflt_) mmsa_knob_env(name_, dflt_)
+#else
+#define MMSA_KNOB(name_, dflt_) (dflt_)
+#endif
+
 #define MMSA_CHECK_ARG(cond, ...)            \
   do {                                       \
     if (!(cond)) {                           \

@@ -7,7 +7,6 @@
 //                 K order = (c, kh, kw) = the reference weight's flattened order, zero padded to Kpad.
 // These are fp32 VALU kernels (exact fp32 like the reference), 16-byte channel vectors per lane.
 #include "common.h"
-#include <stdlib.h>
 
 // weights repacked tap-major: w[(kh*k+kw)*C + c]
 __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restrict__ x, long ldx, long xstrideB,
@@ -213,7 +212,7 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   MMSA_CHECK_ARG(!rowstats, "dwconv_nhwc: rowstats need the tiled 7x7 kernel (C %% 64 == 0, H, W %% 8 == 0, 16-byte aligned pointers)");
   MMSA_CHECK_ARG(imgs_per_group == 0 || imgs_per_group == B, "dwconv_nhwc: image groups are implemented by the tiled 7x7 kernel only");
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
-  static const bool generic3 = getenv("MMSA_DWCONV3_GENERIC") != nullptr;   // A/B aid
+  const bool generic3 = MMSA_KNOB("MMSA_DWCONV3_GENERIC", 0) != 0;   // A/B aid
   if (k == 3 && !generic3 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
     hipLaunchKernelGGL(dwconv3_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act);
   else
@@ -341,7 +340,7 @@ extern "C" int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const f
                                int B, int H, int W, int G, int cin_g, int cout_g, int k, int act, hipStream_t stream) {
   MMSA_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && G > 0 && cin_g > 0 && cout_g > 0, "gconv_nhwc: bad args");
   MMSA_CHECK_ARG((k & 1) == 1 && k <= 7, "gconv_nhwc: odd kernel <= 7 expected, got %d", k);
-  static const bool no_mfma = getenv("MMSA_GCONV_VALU") != nullptr;   // A/B aid: the FMA kernels for the 3x3 case too
+  const bool no_mfma = MMSA_KNOB("MMSA_GCONV_VALU", 0) != 0;   // A/B aid: the FMA kernels for the 3x3 case too
   if (!bias && act == ACT_NONE && k == 3 && !no_mfma && mmsa_gconv3_mfma_launch(x, ldx, w, y, ldy, B, H, W, G, cin_g, cout_g, stream)) {
     MMSA_CHECK_LAUNCH("gconv_nhwc(3x3 mfma)");
     return MMSA_OK;

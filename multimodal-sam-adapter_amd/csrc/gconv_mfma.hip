@@ -11,7 +11,6 @@
 //     NTW = 16 mod 64 (or 48): conflict free; output columns >= cout_g are zero weights;
 //   * wave w owns pixel rows 4w .. 4w+3 (4 m-tiles) x NT n-tiles: 4 + NT LDS reads per 4 NT MFMAs.
 #include "common.h"
-#include <stdlib.h>
 
 template <int NT>
 __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
@@ -115,7 +114,7 @@ bool mmsa_gconv3_mfma_launch(const float* x, long ldx, const float* w, float* y,
   const int nt = (cout_g + 15) / 16;
   // one n-tile (cout_g <= 16: the 1/4-resolution level, 9 channels per group) is no faster than the FMA kernel (283 vs 276 us:
   // 7 of 16 output columns and 3 of 12 k-slots are padding, and a group's 9 of 288 interleaved channels use 36 B of every line)
-  static const bool all_nt = getenv("MMSA_GCONV_MFMA_ALL") != nullptr;
+  const bool all_nt = MMSA_KNOB("MMSA_GCONV_MFMA_ALL", 0) != 0;
   if (nt < (all_nt ? 1 : 2) || nt > 5 || nt == 4) return false;
   const int tx = cdiv(W, 16), ty = cdiv(H, 16);
   dim3 grid(tx * ty, G, B);

@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   }
 }
 
-#include <stdlib.h>
 int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         const unsigned short* Wp, long strideW,
                         const float* bias, long strideBias, const float* colscale,
@@ -277,16 +276,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
-                        float* rs_out, const float* rn_mr, const float* rn_cs);
-// gemm_v3.hip: the kernel whose epilogue runs inside the next tile's k loop; returns 1 = launched, 0 = not its shape (fall through to gemm_v2)
-int mmsa_gemm_v3_launch(const unsigned short* Ap, long lda, long strideA,
-                        const unsigned short* Wp, long strideW,
-                        const float* bias, long strideBias, const float* colscale,
-                        const float* resid, long ldr, long strideR, int resid_mod, float beta,
-                        float* C, long ldc, long strideC,
-                        unsigned short* Cp, long ldcp, long strideCp,
-                        int M, int N, int K, int batch, int act, float alpha,
-                        int out_mode, int fmt, int cp_fmt, int max_grid, hipStream_t stream);
+                        float* rs_out, const float* rn_mr, const float* rn_cs, int flavour);
 
 // ---- tiny problems (CoordinateAttention's 1x1 convs on pooled maps, AM:187-201: M = B*(h+w) <= ~1000 rows, N or K of 8..48): a
 // 128 x 128 MFMA tile would be one or two workgroups walking K alone (64 us for M = 128, N = 48, K = 1536).  Here one wave owns
@@ -334,16 +324,6 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a, int ncg) {
 }
 
 
-// One-shot extras of the NEXT mmsa_gemm_split3 call (include/mmsa.h): kept out of that entry's 33-argument signature.  Launches are
-// issued from one host thread at a time (the bindings hold the GIL), so a process-wide slot is enough; it is cleared by the call.
-static struct { float* rs_out; const float* rn_mr; const float* rn_cs; } g_gemm_extras = {nullptr, nullptr, nullptr};
-extern "C" int mmsa_gemm_next_extras(float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum) {
-  MMSA_CHECK_ARG(!rownorm_mean_rstd == !rownorm_colsum, "gemm_next_extras: mean/rstd rows and column sums go together");
-  MMSA_CHECK_ARG(!(rowstats_out && rownorm_mean_rstd), "gemm_next_extras: a GEMM either writes row statistics or normalises by them");
-  g_gemm_extras.rs_out = rowstats_out; g_gemm_extras.rn_mr = rownorm_mean_rstd; g_gemm_extras.rn_cs = rownorm_colsum;
-  return MMSA_OK;
-}
-
 // C-ABI entry: see include/mmsa.h for the contract.
 extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long lda, long strideA,
                                 const unsigned short* Wp, long strideW,
@@ -352,12 +332,15 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 float* C, long ldc, long strideC,
                                 unsigned short* Cp, long ldcp, long strideCp,
                                 int M, int N, int K, int batch, int act, float alpha,
-                                int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream) {
+                                int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid,
+                                float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum, int flavour,
+                                hipStream_t stream) {
   const bool ap = Ap != nullptr;
-  float* const rs_out = g_gemm_extras.rs_out;
-  const float* const rn_mr = g_gemm_extras.rn_mr;
-  const float* const rn_cs = g_gemm_extras.rn_cs;
-  g_gemm_extras.rs_out = nullptr; g_gemm_extras.rn_mr = nullptr; g_gemm_extras.rn_cs = nullptr;
+  float* const rs_out = rowstats_out;
+  const float* const rn_mr = rownorm_mean_rstd;
+  const float* const rn_cs = rownorm_colsum;
+  MMSA_CHECK_ARG(!rn_mr == !rn_cs, "gemm_split3: mean/rstd rows and column sums go together");
+  MMSA_CHECK_ARG(!(rs_out && rn_mr), "gemm_split3: a GEMM either writes row statistics or normalises by them");
   const bool extras = rs_out || rn_mr;
   MMSA_CHECK_ARG(!extras || (ap && M >= 128), "gemm_split3: row statistics / row normalisation need activation planes and M >= 128");
   MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && cp_fmt >= 0 && (MMSA_CP_BASE(cp_fmt) == MMSA_FMT_B3 || MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
@@ -396,12 +379,12 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C; a.cp_fmt = cp_fmt;
-  // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 forces this one
-  static const bool force_v1 = getenv("MMSA_GEMM_V1") != nullptr;
+  // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 (debug-knob builds) forces this one
+  const bool force_v1 = MMSA_KNOB("MMSA_GEMM_V1", 0) != 0;
   // (round 1 routed one-strip shapes with many rows and a deep K -- ConvNeXt stage-0 pw2: N = 96, K = 384 -- to the 128-row tiles of
   // this kernel; with the blocked tile order and the 96-column tiles of the LDS-DMA kernel that shape is 18 % faster there: 152 -> 125 us)
   const bool narrow = false;
-  static const bool no_tiny = getenv("MMSA_GEMM_NO_TINY") != nullptr;   // A/B aid
+  const bool no_tiny = MMSA_KNOB("MMSA_GEMM_NO_TINY", 0) != 0;   // A/B aid (debug-knob builds)
   // routed by the problem's small dimension, NOT by the row count (rows scale with the image batch: a batch-dependent choice of
   // kernel would make results depend on how images are batched); M <= 16384 covers 32 images of the largest pooled map
   if (!ap && !Cp && out_mode == 0 && resid_mod <= 0 && (N <= 64 || K <= 64) && M <= 16384 && !no_tiny && !extras) {
@@ -411,12 +394,9 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
     return MMSA_OK;
   }
   if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow))) {   // h8 operands: only the LDS-DMA kernels read them
-    const int r3 = extras ? 0 : mmsa_gemm_v3_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR, resid_mod, beta,
-                                                    C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha, out_mode, fmt, cp_fmt, max_grid, stream);
-    if (r3 != 0) return r3 < 0 ? r3 : MMSA_OK;
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
-                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream, rs_out, rn_mr, rn_cs);
+                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream, rs_out, rn_mr, rn_cs, flavour);
   }
   MMSA_CHECK_ARG(!extras, "gemm_split3: this shape is not routed to the LDS-DMA kernel, which alone writes row statistics / normalises rows");
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);

@@ -21,7 +21,6 @@
 //   * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) walk neighbouring (m-tile, n-tile) pairs so
 //     activation rows and weight panels are re-read from that XCD's L2 (speed only, never correctness).
 #include "common.h"
-#include <stdlib.h>
 typedef __attribute__((ext_vector_type(8))) int mx_v8i;       // operand of the block-scaled fp8 MFMA (32 bytes per lane)
 typedef __attribute__((ext_vector_type(8))) _Float16 mx_h8;  // operand of the f16 MFMA
 
@@ -50,8 +49,15 @@ struct GemmV2Args {
   //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
   float* rs_out; int rs_strips;
   const float* rn_mr; const float* rn_cs;
-  int debug;   // MMSA_GEMM_DEBUG (timing experiments only): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
+#ifdef MMSA_DEBUG_KNOBS
+  int debug;   // MMSA_GEMM_DEBUG (timing experiments, debug-knob builds only: tools/build_variant.sh -DMMSA_DEBUG_KNOBS): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
+#endif
 };
+#ifdef MMSA_DEBUG_KNOBS
+#define V2_DBG(a_) ((a_).debug)
+#else
+#define V2_DBG(a_) 0     // release builds: the timing ablations are compiled out
+#endif
 
 #define V2_BN 128
 #define V2_BK 32
@@ -60,9 +66,6 @@ struct GemmV2Args {
 #define V2_LDS_BYTES(NW_) (((NW_) == 8 ? 3 : 2) * ((NW_) * 32 * 128 + V2_W_BYTES))
 #ifndef V2_FP8_FIRST
 #define V2_FP8_FIRST 1   // 0: fp8 and fp16 MFMAs interleaved per output tile (A/B timing)
-#endif
-#ifndef V2_FP8_SPLIT
-#define V2_FP8_SPLIT 0   // 1: h8, 4 of a pair's 16 fp8 MFMAs (sub-tiles mi, ni >= 2) are issued at the head of the NEXT k-tile's matrix phase (see MFMA_FP8_PENDING).  MEASURED SLOWER (profiles/r03_fp8_split_ab.txt: lin1 146 -> 154 us, K = 512 shapes 129 -> 195, step 33.9 -> 36.3 ms): off
 #endif
 #ifndef V2_EXP_NO_FP8
 #define V2_EXP_NO_FP8 0   // timing experiment: leave the fp8 cross-term MFMAs out (wrong results)
@@ -193,13 +196,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       ow2 = (unsigned)((min(wb_ + 16, a.N - 1) - n0_) * (int)a.ldw + dpiece) * 2u;    \
       ow3 = (unsigned)((min(wb_ + 24, a.N - 1) - n0_) * (int)a.ldw + (dpiece ^ 32)) * 2u; \
     }                                                                            \
-    if (a.debug == 4 || a.debug == 5) { oa1 = oa2 = oa3 = oa0; gW = gA; ow0 = ow1 = oa0; }   /* timing experiment: L1-resident operand stream */ \
+    if (V2_DBG(a) == 4 || V2_DBG(a) == 5) { oa1 = oa2 = oa3 = oa0; gW = gA; ow0 = ow1 = oa0; }   /* timing experiment: L1-resident operand stream */ \
   } while (0)
 
 #define ISSUE_DMA(kt_, st_)                                                       \
   do {                                                                            \
     unsigned char* sb_ = smem + (st_) * V2_STAGE;                                 \
-    const int ko_ = a.debug == 3 ? 0 : (kt_) * 64;   /* debug 3: timing experiment, re-read k-tile 0 */ \
+    const int ko_ = V2_DBG(a) == 3 ? 0 : (kt_) * 64;   /* debug 3: timing experiment, re-read k-tile 0 */ \
     GLDS16(SA(0, ko_), sb_ + lds_a);                                               \
     GLDS16(SA(1, ko_), sb_ + lds_a + 1024);                                        \
     GLDS16(SA(2, ko_), sb_ + lds_a + 2048);                                        \
@@ -270,37 +273,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 // tail the registers still in use are the hi fragments of the finished k-tile, which the next read phase does not touch.
 // The matrix pipe's share of a k-tile pair is then 16 fp16 MFMAs (256 cycles) in the first step and 16 fp8 + 16 fp16 (768) in the second,
 // beside read phases of ~700 cycles on the partner group (the L2 -> LDS operand stream): the second step's phase is matrix-bound, the
-// first one's read-bound, 3350 cycles per pair where 4 x 700 would do.  V2_FP8_SPLIT (an experiment, off: slower as measured) moves the four fp8 MFMAs of sub-tiles (mi, ni >= 2)
-// to the head of the NEXT k-tile's matrix phase (DEFER_ here, MFMA_FP8_PENDING there): 12 x 32 + 256 = 640 and 4 x 32 + 256 = 384
-// cycles, both under the read phase.  Those four need opA[2..3] / opW[2..3] of the finished pair while the read phase between has
-// already fetched the next pair's first 8-bit chunks for the same slots: that phase keeps them in the fragment registers (16 more live
-// registers) and MX_FILL_LATE moves them into the operand tuples once the pending MFMAs are queued.  Same products; sub-tiles
-// (mi, ni >= 2) add a pair's cross terms after, not before, the pair's second fp16 product (results equal to the unsplit order to
-// fp32 rounding, not bit for bit).  The last pair of an output tile defers nothing, the first step of a tile has nothing pending.
+// first one's read-bound, 3350 cycles per pair where 4 x 700 would do.  (Spreading the fp8 MFMAs over both steps -- round 3's the fp8-split experiment --
+// was built, measured slower (profiles/r03_fp8_split_ab.txt) and removed in round 4.)
 #define MFMA_FP8_ALL(NI4_, DEFER_)                                                                          \
   if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
     if (MXPAR && V2_FP8_FIRST && !V2_EXP_NO_FP8) {                                                          \
       _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                      \
         if (ni < 3 || (NI4_)) {                                                                             \
           _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-            if (!(V2_FP8_SPLIT && (DEFER_) && ni >= 2 && mi >= 2))                                          \
               acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
         }                                                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                    \
-    }                                                                                                       \
-  }
-#define MFMA_FP8_PENDING(NI4_, PEND_)                                                                       \
-  if constexpr (FMT == MMSA_FMT_H8) {                                                                       \
-    if (!MXPAR && V2_FP8_SPLIT && V2_FP8_FIRST && !V2_EXP_NO_FP8) {                                         \
-      if (PEND_) {                                                                                          \
-        _Pragma("unroll") for (int ni = 2; ni < 4; ++ni)                                                    \
-          if (ni < 3 || (NI4_)) {                                                                           \
-            _Pragma("unroll") for (int mi = 2; mi < 4; ++mi)                                                \
-              acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
-          }                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-      }                                                                                                     \
-      _Pragma("unroll") for (int i = 2; i < 4; ++i) { MX_SET(opA[i], al[i], 0) MX_SET(opW[i], wl[i], 0) }    \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
     }                                                                                                       \
   }
@@ -327,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     __builtin_amdgcn_s_barrier();                                                                           \
     const bool do_pf = pf_j < total;                                                                        \
     unsigned char* pfb = smem + pf_st * V2_STAGE;                                                           \
-    const int pko = a.debug == 3 ? 0 : pf_kt * 64;                                                          \
+    const int pko = V2_DBG(a) == 3 ? 0 : pf_kt * 64;                                                          \
     const unsigned char* base = smem + st * V2_STAGE;                                                       \
     bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
@@ -403,11 +385,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     if ((i_) == 4) GLDS16(SW(0, pko), pfb + V2_A_BYTES + lds_w);                                             \
     if ((i_) == 5) GLDS16(SW(1, pko), pfb + V2_A_BYTES + lds_w + 1024);                                      \
   }
-#define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { if (MXPAR || i < 2 || !(V2_FP8_SPLIT && V2_FP8_FIRST && !V2_EXP_NO_FP8)) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } } }
+#define MX_FILL() if constexpr (FMT == MMSA_FMT_H8) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { MX_SET(opA[i], al[i], MXPAR) MX_SET(opW[i], wl[i], MXPAR) } }
 // k-loop ablation build (tools/build_variant.sh -DV2_KABL, timing only, results are garbage): MMSA_GEMM_DEBUG = 64 + a bit mask of what
 // to leave out -- 1 the MFMAs, 2 the fragment reads, 4 the LDS-DMA, 8 the barriers inside the k loop; all without the epilogue.
 #ifdef V2_KABL
-#define KABL(x_) (a.debug >= 64 && ((a.debug >> ((x_) - 6)) & 1))
+#define KABL(x_) (V2_DBG(a) >= 64 && ((V2_DBG(a) >> ((x_) - 6)) & 1))
 #define KABL_INIT() _Pragma("unroll") for (int i = 0; i < 4; ++i) { ah[i] = al[i] = wh[i] = wl[i] = __builtin_bit_cast(bf16x8, make_uint4(lane + i, 0x3c003c00u, lane, 0x3c003c00u)); }
 #define KABL_UNDEF() _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(ah[i]), "=v"(al[i]), "=v"(wh[i]), "=v"(wl[i])); }   /* fragments = whatever the registers hold */
 #else
@@ -422,7 +404,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     STAMP_DECL()                                                                                            \
     STAMP(0)                                                                                                \
     unsigned char* pfb = smem + pf_st * V2_STAGE;                                                           \
-    const int pko = a.debug >= 3 && a.debug <= 5 ? 0 : pf_kt * 64;                                          \
+    const int pko = V2_DBG(a) >= 3 && V2_DBG(a) <= 5 ? 0 : pf_kt * 64;                                          \
     const unsigned char* base = smem + st * V2_STAGE;                                                       \
     bf16x8 ah[4], al[4], wh[4], wl[4];                                                                      \
     KABL_INIT()                                                                                             \
@@ -450,7 +432,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     STAMP(5)                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (!KABL(6)) {                                                                                         \
-    MFMA_FP8_PENDING(ni4, kt != 0)                                                                          \
     MFMA_FP8_ALL(ni4, !last_k)                                                                              \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
@@ -518,7 +499,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     ISTAMP(0)                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (!KABL(6)) {                                                                                         \
-    MFMA_FP8_PENDING(NI4_, true)                                                                            \
     MFMA_FP8_ALL(NI4_, true)                                                                                \
     MFMA_CHUNK(0)                                                                                           \
     MFMA_CHUNK(1)                                                                                           \
@@ -551,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       if (grp) __builtin_amdgcn_s_barrier();
       // k-tiles 0, 1 (a wait may be skipped after an epilogue) and nk-2, nk-1 (the prefetch cursor moves to the next output tile, the
       // last one drains) run the general step, everything between them the straight-line one.
-      const bool fast_ok = V2_FAST_STEPS && nk >= 6 && (a.debug < 3 || a.debug == 10 || a.debug >= 64) && (FMT != MMSA_FMT_H8 || ni4);   // h8: a second copy of the loop for 96-column tiles costs registers (spills)
+      const bool fast_ok = V2_FAST_STEPS && nk >= 6 && (V2_DBG(a) < 3 || V2_DBG(a) == 10 || V2_DBG(a) >= 64) && (FMT != MMSA_FMT_H8 || ni4);   // h8: a second copy of the loop for 96-column tiles costs registers (spills)
       const int kt_a = fast_ok ? 2 : nk, kt_b = fast_ok ? nk - 2 : nk;
       if constexpr (FMT == MMSA_FMT_H8) {   // nk is even (checked by the launcher): the fp8 operand tuples are filled by a PAIR of k-tiles
 #pragma unroll 1
@@ -617,7 +597,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     }
     const int st_cur = st == 0 ? V2_NST - 1 : st - 1;   // ring slot of the k-tile just consumed: free until the next DMA into it (issued after the next barrier)
 
-    if (a.debug == 2 || a.debug == 5 || a.debug >= 64) { tile += G; continue; }
+    if (V2_DBG(a) == 2 || V2_DBG(a) == 5 || V2_DBG(a) >= 64) { tile += G; continue; }
     // ---- tile boundary.  MFMA layout: lane holds C[m = ..+l15][n = ..+4g .. +3].  Each wave transposes 16 x 64
     // sub-tiles through the ring slot it has just finished computing from, so that residual loads and output stores
     // are FULL 256-byte row segments (4 rows per wave-instruction).  After the transpose a lane owns the SAME 4
@@ -703,7 +683,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
       // (transpose to rows, then re-stage as lines), and the four sub-tiles' LDS traffic and arithmetic are free to overlap -- a wave's
       // LDS instructions execute in order, so sub-tile mi + 1 may overwrite the staging rows as soon as mi's read-backs are ISSUED.
       bool direct = false;
-      if constexpr (EPI_UNROLL && !GEN) direct = fast && Cp && !C && !resid && ni4 && a.debug == 0 && (((uintptr_t)bias | (uintptr_t)colscale) & 15) == 0;
+      if constexpr (EPI_UNROLL && !GEN) direct = fast && Cp && !C && !resid && ni4 && V2_DBG(a) == 0 && (((uintptr_t)bias | (uintptr_t)colscale) & 15) == 0;
       if constexpr (EPI_UNROLL && !GEN) {
         if (direct) {
           float4 bn_[4], cn_[4], sn_[4];
@@ -787,7 +767,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
           *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][mi];
           acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (a.debug == 1) continue;
+        if (V2_DBG(a) == 1) continue;
         if (fast) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -819,7 +799,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
               if ((lane & 15) == 0 && m < a.M)
                 *reinterpret_cast<float2*>(a.rs_out + (((long)bz * a.M + m) * a.rs_strips + (nb_ >> 6)) * 2) = make_float2(s1, s2);
             }
-            if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
+            if (V2_DBG(a) == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
             else if (m < a.M && lane_ok) {
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
@@ -871,7 +851,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
           acc[ni][2] = acc[ni][3];
           acc[ni][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (a.debug == 1) continue;
+        if (V2_DBG(a) == 1) continue;
         if (fast) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -896,7 +876,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
               pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
             }
             const int m = mb + rl;
-            if (a.debug == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
+            if (V2_DBG(a) == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
             else if (m < a.M && lane_ok) {
               long drow_, rrow; int dcol;
               map_row(m, n, drow_, dcol, rrow);
@@ -944,15 +924,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 #undef MFMA_FP8_ALL
 }
 
-static int g_num_cus = 0;
-static int g_nw_override = 0;   // testing / A-B aid: 4 or 8 forces the workgroup flavour of every later launch, 0 = automatic
-extern int g_mmsa_v3_mode;      // gemm_v3.hip
-extern "C" int mmsa_debug_gemm_flavour(int waves_per_workgroup) {
-  g_nw_override = (waves_per_workgroup == 4 || waves_per_workgroup == 8) ? waves_per_workgroup : 0;
-  g_mmsa_v3_mode = waves_per_workgroup == 3 ? 1 : (g_nw_override ? 0 : -1);   // 3: the epilogue-in-the-k-loop kernel wherever it takes the shape; 4 / 8: gemm_v2's flavours only
-  return MMSA_OK;
-}
-
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
 // fmt = format of the A and W planes, cp_fmt = format of the planes output (common.h).
 int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
@@ -963,7 +934,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
-                        float* rs_out, const float* rn_mr, const float* rn_cs) {
+                        float* rs_out, const float* rn_mr, const float* rn_cs, int flavour) {
   GemmV2Args a;
   // LayerNorm fold (mmsa_gemm_next_extras): both forms run on the unrolled fast epilogue of 128-column tiles with whole 64-column strips
   MMSA_CHECK_ARG(!rs_out || (C && out_mode == 0 && resid_mod <= 0 && act == ACT_NONE && (N & 63) == 0 && (ldc & 3) == 0 && (!resid || (ldr & 3) == 0) && (!Cp || (ldcp & 3) == 0)),
@@ -986,29 +957,25 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.cp_fmt = cp_fmt;
   const bool h8 = fmt == MMSA_FMT_H8;
   MMSA_CHECK_ARG(!h8 || (K & 63) == 0, "gemm(v2): h8 operands need K %% 64 == 0 (K=%d)", K);
-  // workgroup flavour: 8-wave 256-row ping-pong tiles by default.  The 4-wave flavour (128-row tiles, two workgroups per CU: the
-  // epilogue of one under the k-loop of the other) measured no faster on any of the model's shapes (profiles/r02_gemm_flavours.txt:
-  // its 2-slot ring gives up more in the k-loop than the overlap returns), so it is OFF unless asked for: MMSA_GEMM_NW = 4 / 8
-  // forces one, MMSA_GEMM_NW4_MAXK = k routes shapes with K <= k to it.  Results are bit-identical either way.  (bf16 planes only.)
-  static const int nw_force = getenv("MMSA_GEMM_NW") ? atoi(getenv("MMSA_GEMM_NW")) : 0;
-  static const int nw4_maxk = getenv("MMSA_GEMM_NW4_MAXK") ? atoi(getenv("MMSA_GEMM_NW4_MAXK")) : 0;
-  const int nw = (h8 || rs_out || rn_mr) ? 8 : g_nw_override ? g_nw_override : nw_force == 4 || nw_force == 8 ? nw_force : (K <= nw4_maxk ? 4 : 8);
+  // workgroup flavour: 8-wave 256-row ping-pong tiles, except shallow contractions on bf16 hi/lo planes (K <= 256: at most four k-tile
+  // pairs per output tile -- the tile is its prologue and epilogue), which take the 4-wave flavour (128-row tiles, two workgroups per
+  // CU, 2-slot ring: one workgroup's epilogue under the other's k loop; profiles/r03_gemm_flavour4.txt: -9 ... -12 % there, slower on
+  // every deeper shape).  `flavour` = 4 / 8 forces one (tests, A/B runs); results are bit-identical either way.  (bf16 planes only.)
+  MMSA_CHECK_ARG(flavour == 0 || flavour == 4 || flavour == 8, "gemm(v2): flavour %d (0 = by shape, 4, 8)", flavour);
+  const int nw = (h8 || rs_out || rn_mr) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) ? 4 : 8);
   const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
   a.nbm = cdiv(M, bm);
   a.bn = V2_BN;
   a.nbn = cdiv(N, V2_BN);
   a.ntiles = a.nbm * a.nbn * batch;
-  static const int dbg = getenv("MMSA_GEMM_DEBUG") ? atoi(getenv("MMSA_GEMM_DEBUG")) : 0;
-  a.debug = dbg;
-  if (g_num_cus == 0) {
-    int dev = 0;
+#ifdef MMSA_DEBUG_KNOBS
+  a.debug = MMSA_KNOB("MMSA_GEMM_DEBUG", 0);
+#endif
+  // CU count of the device + the kernels' LDS attributes: set once per process (immutable afterwards)
+  static const int num_cus = [] {
+    int dev = 0, n = 256;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      mmsa_set_error("gemm_split3(v2): cannot query the device");
-      return MMSA_ERR_LAUNCH;
-    }
-    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (getenv("MMSA_GEMM_MAX_GRID")) g_num_cus = atoi(getenv("MMSA_GEMM_MAX_GRID"));   // experiment: leave CUs to concurrent streams
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
 #define V2_ATTR(GEN_, ACT_)                                                                                                   \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8)); \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
@@ -1016,16 +983,17 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1) V2_ATTR(true, ACT_NONE)
 #undef V2_ATTR
-  }
+    return n;
+  }();
   // max_grid > 0: at most that many persistent workgroups -- a caller that runs independent chains on concurrent streams gives each
   // GEMM its share of the CUs, so that the kernels of two chains are resident together (one 144 KiB workgroup fits a CU).  The tile
   // shape below is chosen for THAT many CUs (the value of an output element does not depend on the shape of its tile).
-  const int cus = (max_grid > 0 && max_grid < g_num_cus) ? max_grid : g_num_cus;
+  const int cus = (max_grid > 0 && max_grid < num_cus) ? max_grid : num_cus;
   // 96-column tiles when they occupy the CUs better: rounds(tiles) x relative tile cost (0.75) against rounds of 128-column tiles.
   // fp32 output only (the planes epilogue writes whole 64-column strips) and no pixel-shuffle / broadcast-residual store.
   if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96 && N % 96 == 0 && !rs_out) {   // (a ragged last 96-column tile would run the element-wise
     // epilogue: N = 256 -- the ConvFFN fc1 of the extractors -- was routed here and spent 40 of its 92 us in it, profiles/r03_v3_vs_v2.txt)
-    static const bool no96 = getenv("MMSA_GEMM_NO96") != nullptr;   // A/B aid
+    const bool no96 = MMSA_KNOB("MMSA_GEMM_NO96", 0) != 0;   // A/B aid (debug-knob builds)
     const int nbn96 = cdiv(N, 96);
     const long t96 = (long)a.nbm * nbn96 * batch;
     const int slots = cus * wg_per_cu;
@@ -1041,7 +1009,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   // makes the XCDs fetch the fewest operand bytes -- every activation panel is fetched once per block column, every weight panel
   // once per block row: (nbn / tn) * M * K + (nbm / tm) * N * K; row-major order when none fits.  MMSA_GEMM_ROWMAJOR=1 forces
   // row-major (A/B aid).  Results do not depend on the order.
-  static const bool rowmajor = getenv("MMSA_GEMM_ROWMAJOR") != nullptr;
+  const bool rowmajor = MMSA_KNOB("MMSA_GEMM_ROWMAJOR", 0) != 0;
   a.tm = a.tn = 0;
   if (!rowmajor) {
     double best = 0.0;
@@ -1059,7 +1027,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   const int rounds_ = cdiv(a.ntiles, slots_);
   const int grid = cdiv(a.ntiles, rounds_);
   const bool gen = out_mode != 0 || resid_mod > 0;
-  static const bool pp = getenv("MMSA_GEMM_PP") ? atoi(getenv("MMSA_GEMM_PP")) != 0 : true;   // 0: every wave in phase (A/B timing)
+  const bool pp = MMSA_KNOB("MMSA_GEMM_PP", 1) != 0;   // 0 (debug-knob builds): every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \
   do {                                                                                                                     \
     if (h8) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);          \

@@ -7,7 +7,6 @@
 //                    nn.LayerNorm(H*W) AM:241,265; F.normalize over HW AM:100-101; avg-pool AM:159).
 //   lnhw_apply     : GFFM LayerNorm over the spatial axis + FFRM recalibration, fused apply pass.
 #include "common.h"
-#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // RPW = rows per wave: 1 (64 lanes x NV float4 per row) or 2 (C <= 128: two rows per wave, 32 lanes each -- with one row per
@@ -133,7 +132,7 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
   MMSA_CHECK_ARG(group_rows == 0 || map_mode == 0 || (group_rows % (map_H * map_W) == 0 && y_wrap == 0 && y_gcol == 0), "layernorm_rows: grouping with patchify needs whole images per group");
   const int rpw = C <= 128 ? 2 : 1;
   // rows per wave slot: 4 once there are enough rows to keep every CU busy that way (streamed: see the kernel); MMSA_LN_ROWS overrides (A/B timing)
-  static const int ln_rows = getenv("MMSA_LN_ROWS") ? atoi(getenv("MMSA_LN_ROWS")) : 0;
+  const int ln_rows = MMSA_KNOB("MMSA_LN_ROWS", 0);
   const int per_slot = ln_rows > 0 ? ln_rows : (rows >= 8192 ? 4 : rows >= 4096 ? 2 : 1);
   dim3 grid(cdiv(rows, 4 * rpw * per_slot)), block(256);
 #define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt)

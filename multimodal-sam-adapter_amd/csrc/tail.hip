@@ -6,7 +6,6 @@
 // a 32(pixels) x 32(channels) tile is read channel-contiguous, transposed through LDS (padded, conflict-free)
 // and written pixel-contiguous into the NCHW output the mmseg head expects.
 #include "common.h"
-#include <stdlib.h>
 
 __global__ __launch_bounds__(256) void tail_fuse_kernel(const float* __restrict__ cmap, long ldc, long cstrideB, const float* __restrict__ xtok, long ldx,
                                                         const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
@@ -144,7 +143,7 @@ extern "C" int mmsa_tail_fuse(const float* cmap, long ldc, long cstrideB, const 
   MMSA_CHECK_ARG(!out_planes || ((C & 31) == 0 && ldp >= 2L * C), "tail_fuse: planes output needs C % 32 == 0 and ldp >= 2C");
   // scale_factor s = Hc/Hx is what the reference passes (4, 2, 1, 0.5); PyTorch uses 1/s as the source step
   const float rh = (float)Hx / (float)Hc, rw = (float)Wx / (float)Wc;
-  static const bool old_tiles = getenv("MMSA_TAIL32") != nullptr;   // A/B aid
+  const bool old_tiles = MMSA_KNOB("MMSA_TAIL32", 0) != 0;   // A/B aid
   const bool wide = !old_tiles && (C & 3) == 0 && (ldc & 3) == 0 && (!xtok || (ldx & 3) == 0) && (cstrideB & 3) == 0 &&
                     ((((uintptr_t)cmap) | ((uintptr_t)xtok) | ((uintptr_t)bn_scale) | ((uintptr_t)bn_shift) | ((uintptr_t)out)) & 15) == 0 &&
                     (!out_planes || ((C & 7) == 0 && (ldp & 7) == 0 && (((uintptr_t)out_planes) & 15) == 0));

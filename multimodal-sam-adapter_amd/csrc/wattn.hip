@@ -19,7 +19,6 @@
 //     sel[j] = onehot(kh(j)) | onehot(14 + kw(j)) -- the first version gathered two table entries per score element
 //     with ~15 VALU instructions each and was VALU-bound (1500 VALU vs 186 MFMA per wave).
 #include "common.h"
-#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define LDS_AS __attribute__((address_space(3)))
@@ -44,265 +43,15 @@ struct WAttnArgs {
   unsigned short* op; long ldo;         // output planes [B*T, >= 2*D]
   int ofmt;                             // their format (common.h: MMSA_FMT_B3 bf16 hi/lo, MMSA_FMT_H8 for an h8 proj GEMM)
   int B, H, W, heads, D, ws, nWw;
-  int debug;                            // MMSA_WATTN_DEBUG timing ablations: 1 = stop after the barrier, 2 = no K/V DMA
+  float* guard;                         // optional device word: max |logit| (natural units, rel-pos bias included) over the live (query, key) pairs,
+                                        // folded in with one atomic max per wave (include/mmsa.h "attention logit guard")
   unsigned magic;                       // ceil(65536 / ws): j / ws == (j * magic) >> 16 for j < 224 (checked on the host)
   float scale;
 };
 
-__global__ __launch_bounds__(WA_WAVES * 64) void wattn_kernel(WAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ks = smem;
-  unsigned char* Vhi = smem + WA_K_BYTES;
-  unsigned char* Vlo = Vhi + WA_V_BYTES;
-  unsigned char* Es = Vlo + WA_V_BYTES;
-  if (a.debug == 3) return;   // launch cost only
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* Bw = reinterpret_cast<float*>(Es + WA_E_BYTES + wave * WA_B_BYTES);
-  const int l15 = lane & 15, G = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int wi = blockIdx.x / a.nWw, wj = blockIdx.x - wi * a.nWw;
-  const int T = a.H * a.W, ws = a.ws, Nk = ws * ws;
-  const unsigned short* pq_b = a.qp + (long)b * T * a.ldq;
-  const int colq = head * 64, colk = a.D + head * 64, colv = 2 * a.D + head * 64;
-
-  // window-local index j -> token, -1 for a zero-pad token (inside the window, outside the image), -2 beyond the window
-  auto token_of = [&](int j) -> int {
-    if (j >= Nk) return -2;
-    const int r = (int)(__umul24(j, a.magic) >> 16), c = j - __umul24(r, ws);
-    const int hh = wi * ws + r, ww = wj * ws + c;
-    return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
-  };
-  // source row of a key: the token's qkv planes, or the bias planes for pad / non-existent keys (finite values; the
-  // scores of non-existent keys are masked to -inf below)
-  auto key_row = [&](int j) -> const unsigned short* {
-    const int t = token_of(j);
-    return t >= 0 ? pq_b + (long)t * a.ldq : a.bp;
-  };
-
-  // ---- this wave's 16 queries: Q fragments (B operand: B[k = 8G + j][col = query l15]), straight from HBM/L2
-  const int jq = 16 * wave + l15;
-  const int tq = token_of(jq);
-  bf16x8 qh[2], ql[2];
-  {
-    const unsigned short* qrow = pq_b + (long)(tq >= 0 ? tq : 0) * a.ldq;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned short* qq = qrow + 2 * (colq + 32 * ks) + 8 * G;
-      qh[ks] = *reinterpret_cast<const bf16x8*>(qq);
-      ql[ks] = *reinterpret_cast<const bf16x8*>(qq + 32);
-    }
-  }
-  // ---- rel-pos table fragments (A operand: A[row = i][k = 8G + j]) straight from the packed planes (16 KiB, L2-resident)
-  bf16x8 rh[4][2], rl[4][2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned short* rr = a.relp + (16 * t + l15) * 128 + 64 * ks + 8 * G;
-      rh[t][ks] = *reinterpret_cast<const bf16x8*>(rr);
-      rl[t][ks] = *reinterpret_cast<const bf16x8*>(rr + 32);
-    }
-  if (a.debug == 4) return;   // + address setup, Q / table loads issued
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- K, V, selector -> LDS by LDS-DMA (one wave-instruction = 1 KiB).  Wave w brings in "its" 16 keys 16w..16w+15:
-  //      4 instructions for K (2 k-steps x 2 groups of 8 rows), 4 for V (hi/lo x 2 groups), 1 for the selector tile;
-  //      wave 12 also fills the 16 V rows beyond the last tile (bias rows: finite, their probabilities are zero).
-  if (a.debug != 2) {
-    const int dr = lane >> 3, slot = lane & 7;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int key = 16 * wave + 8 * half + dr;
-      const unsigned short* row = key_row(key);
-      const int piece = slot ^ ((key & 15) >> 1);                 // GEMM LDS image: slot = piece ^ ((row >> 1) & 7)
-      const int c = slot ^ (((key >> 1) & 3) << 1);               // V: 16-B chunk held by this LDS slot (32-B unit swizzle)
-      const unsigned short* vsrc = row + 2 * (colv + 32 * (c >> 2)) + (c & 3) * 8;
-      GLDS16(row + 2 * colk + piece * 8, Ks + (16 * wave + 8 * half) * 128);
-      GLDS16(row + 2 * (colk + 32) + piece * 8, Ks + (WA_NKEY + 16 * wave + 8 * half) * 128);
-      GLDS16(vsrc, Vhi + (16 * wave + 8 * half) * 128);
-      GLDS16(vsrc + 32, Vlo + (16 * wave + 8 * half) * 128);
-    }
-    {   // selector tile of this wave's keys: 16 rows x 64 B; LDS chunk = chunk ^ ((row >> 2) & 3)
-      const int row = lane >> 2, ch = (lane & 3) ^ ((row >> 2) & 3);
-      GLDS16(a.sel + (16 * wave + row) * 32 + ch * 8, Es + 16 * wave * 64);
-    }
-    if (wave == WA_WAVES - 1) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int key = WA_NKEY + 8 * half + dr;
-        const int c = slot ^ (((key >> 1) & 3) << 1);
-        const unsigned short* vsrc = a.bp + 2 * (colv + 32 * (c >> 2)) + (c & 3) * 8;
-        GLDS16(vsrc, Vhi + (WA_NKEY + 8 * half) * 128);
-        GLDS16(vsrc + 32, Vlo + (WA_NKEY + 8 * half) * 128);
-      }
-    }
-  }
-
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- rel-pos terms of the wave's queries: T[i][q] = rel_pos[i] . q (unscaled q), 4 MFMA tiles (2 per axis).  The Q and
-  //      table loads were issued BEFORE the DMA instructions and vmcnt retires in order, so the wait in front of these
-  //      MFMAs is a counted one that leaves the DMA in flight (hipcc counts the 9 / 13 younger DMA instructions itself;
-  //      check the .s for "s_waitcnt vmcnt(9)" when touching this): the MFMAs and the table build below run in the
-  //      shadow of the K/V transfer.
-  f32x4 tt[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    tt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl[t][ks], qh[ks], tt[t], 0, 0, 0);
-      tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[t][ks], ql[ks], tt[t], 0, 0, 0);
-      tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[t][ks], qh[ks], tt[t], 0, 0, 0);
-    }
-  }
-
-  // ---- bias operand of this wave's queries, in the shadow of the DMA flight.  The MFMA left T[i = 16t + 4G + r][q = l15]
-  //      in this lane; re-indexed by KEY coordinate (get_rel_pos's gather, IE:579-584: i = (q - k) + (ws - 1)) it goes
-  //      to the wave's table  Bq[q][kh] = T_h[q][qh - kh + ws-1] / scale,  Bq[q][14 + kw] = T_w[q][qw - kw + ws-1] / scale
-  //      (zero elsewhere); the score accumulators then get the bias through ONE extra MFMA k-step per key tile,
-  //      bias^T[j][q] = sum_i sel[j][i] Bq[q][i]  (sel = 0/1 selector, exact in bf16), instead of 2 LDS gathers and ~15
-  //      VALU instructions per score element.
-  bf16x8 bqh, bql;
-  {
-    const float rscale = 1.0f / a.scale;
-    const int jqc = jq < Nk ? jq : 0;
-    const int qr = (int)(__umul24(jqc, a.magic) >> 16), qc = jqc - __umul24(qr, ws);
-    *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * (t & 1) + 4 * G + r;
-        const int kc = ((t >> 1) ? qc : qr) + (ws - 1) - i;          // key coordinate served by table entry i
-        if (kc >= 0 && kc < ws) Bw[l15 * 32 + (t >> 1) * 14 + kc] = tt[t][r] * rscale;
-      }
-    // B operand of the extra k-step: B[k = 8G + j][col = query l15] = Bq[l15][8G + j]
-    const float4 b0 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G);
-    const float4 b1 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G + 4);
-    uint4 hh, ll;
-    split2(b0.x, b0.y, hh.x, ll.x);
-    split2(b0.z, b0.w, hh.y, ll.y);
-    split2(b1.x, b1.y, hh.z, ll.z);
-    split2(b1.z, b1.w, hh.w, ll.w);
-    bqh = __builtin_bit_cast(bf16x8, hh);
-    bql = __builtin_bit_cast(bf16x8, ll);
-  }
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA instructions have landed
-  __syncthreads();                                    // ... and everyone else's
-
-  if (a.debug == 1) return;
-  const bool live = tq >= 0;   // pad / non-existent queries are computed by the reference too, but cropped away (IE:547-550)
-  if (!__builtin_amdgcn_readfirstlane(__any(live) ? 1 : 0)) return;
-
-  // ---- S^T = sel Bq^T + K Q^T: 13 key tiles x (1 + 2) k-steps; lane holds keys 16t + 4G + r (r = reg) of query column l15
-  f32x4 s[13];
-  const int fslot = G ^ ((l15 >> 1) & 7);
-  const int frag_hi = l15 * 128 + fslot * 16, frag_lo = l15 * 128 + (fslot ^ 4) * 16;
-  const int frag_e = l15 * 64 + ((G ^ ((l15 >> 2) & 3)) << 4);
-#pragma unroll
-  for (int t = 0; t < 13; ++t) {
-    const bf16x8 e_ = *reinterpret_cast<const bf16x8*>(Es + 16 * t * 64 + frag_e);
-    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bql, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bqh, s[t], 0, 0, 0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned char* kb = Ks + (ks * WA_NKEY + 16 * t) * 128;
-      const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(kb + frag_hi);
-      const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(kb + frag_lo);
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], s[t], 0, 0, 0);
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], s[t], 0, 0, 0);
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], s[t], 0, 0, 0);
-    }
-  }
-
-  // ---- exact softmax over the Nk keys of the window (log2 domain); key slots beyond the window are masked
-  constexpr float LOG2E = 1.4426950408889634f;
-  const float sc2 = a.scale * LOG2E;
-  float mxs;
-  {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 13; ++t) {
-      s[t] *= sc2;
-      if (16 * t + 16 > Nk) {   // wave-uniform: only the tile(s) straddling the end of the window
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * G + r) < Nk ? s[t][r] : -INFINITY;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    mxs = mx;
-  }
-
-  // ---- O^T = V^T P^T over 7 groups of 32 keys.  MFMA k-slot (G, j): j < 4 -> key 32g + 4G + j (tile 2g),
-  //      j >= 4 -> key 32g + 16 + 4G + (j - 4) (tile 2g+1); the transposed V reads use the same key order.
-  f32x4 o[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float psum = 0.f;
-#pragma unroll
-  for (int g = 0; g < 7; ++g) {
-    // exponentials of this group's two key tiles right in front of the MFMAs that consume them: the VALU work of group
-    // g+1 can issue under the matrix-pipe time of group g (unnormalised; the row sum divides the output)
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      if (2 * g + hf < 13) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
-          s[2 * g + hf][r] = p;
-          psum += p;
-        }
-      }
-    }
-    uint4 hh, ll;
-    split2(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
-    split2(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
-    if (2 * g + 1 < 13) {
-      split2(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
-      split2(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
-    } else {
-      hh.z = hh.w = ll.z = ll.w = 0u;   // keys 208..223 do not exist
-    }
-    const bf16x8 ph = __builtin_bit_cast(bf16x8, hh), pl = __builtin_bit_cast(bf16x8, ll);
-    const int row0 = 32 * g + 4 * G + (l15 >> 2);           // lane 4q'+p of a 16-lane group: key row q', columns 4p..4p+3
-    const int sw = (row0 >> 1) & 3;                          // same for row0 + 16
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const int voff = row0 * 128 + ((d ^ sw) << 5) + 8 * (l15 & 3);
-      const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
-      const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + 16 * 128));
-      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
-      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + 16 * 128));
-      const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d], 0, 0, 0);
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d], 0, 0, 0);
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d], 0, 0, 0);
-    }
-  }
-
-  psum += __shfl_xor(psum, 16, 64);
-  psum += __shfl_xor(psum, 32, 64);
-  const float inv = 1.0f / psum;
-  // ---- O[q][16d + 4G .. +3] / sum -> out planes row token(q), columns head*64 + ...  (window_unpartition + crop: IE:534-551)
-  {   // lanes G / G ^ 1 of a query row (lane ^ 16) hold 8 consecutive channels: whole-line stores through the pair exchange (common.h)
-    unsigned short* orow = a.op + ((long)b * T + (live ? tq : 0)) * a.ldo;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-      store_planes8_pair<16>(orow, head * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, live);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// PERSISTENT variant (the default): one workgroup per CU walks the (window, head, image) items.  Measured on the
-// one-shot kernel above: half of a workgroup's life was the cold start (launch, Q / table loads, the K/V transfer of
+// PERSISTENT kernel: one workgroup per CU walks the (window, head, image) items.  Measured on the round-1 one-shot kernel
+// (one workgroup per item; tools/exp/r03_archive/wattn_variants.hip.txt): half of a workgroup's life was the cold start (launch, Q / table loads, the K/V transfer of
 // 110 KiB that every CU requests at the same moment), during which nothing computes.  Here the next item's K is brought in
 // while the current item's softmax and PV run (the K image is free once every wave has its scores), the V image while
 // the next S runs, the next Q fragments are loaded into the registers the current ones vacate, and the rel-pos table and
@@ -433,6 +182,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
   constexpr float LOG2E = 1.4426950408889634f;
   const float sc2 = a.scale * LOG2E, rscale = 1.0f / a.scale;
   bool first = true;
+  float amax = 0.f;
 
 #pragma unroll 1
   for (;;) {
@@ -551,17 +301,24 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       const int G = lane_o >> 4;
-      float mx = -INFINITY;
+      float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
       for (int t = 0; t < 13; ++t) {
         s[t] *= sc2;
         if (16 * t + 16 > Nk) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * G + r) < Nk ? s[t][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (16 * t + 4 * G + r) < Nk;
+            mn = fminf(mn, ok ? s[t][r] : INFINITY);
+            s[t][r] = ok ? s[t][r] : -INFINITY;
+          }
+        } else {
+          mn = fminf(fminf(mn, fminf(s[t][0], s[t][1])), fminf(s[t][2], s[t][3]));
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
       }
+      if (live) amax = fmaxf(amax, fmaxf(fabsf(mx), fabsf(mn)));   // logit guard: this lane's query column, existing keys only
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       mxs = mx;
@@ -647,273 +404,17 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
     it = it_next;
     WP_LOAD_Q()   // (register pressure: loading them before PV spilled)
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// PERSISTENT variant, all-fp16 form, ONE barrier per item (round 3; measured slower than the kernel above and NOT the default: see the launcher).  With h8 planes the kernel above reads only the fp16 hi halves, yet
-// it still transferred K's lo halves and kept a V lo image: here a K row is [hi of channels 0..31 | hi of channels 32..63] (128 B, like a
-// V row), so K and V of an item are 26 KiB each and there is room for TWO of each.  K(i+1) and V(i+1) are requested right after the barrier
-// that opens item i and have the whole item to land; the barriers "#2" (K image free) and "#3" (V landed) of the kernel above are gone, and
-// with them the lockstep of the 13 waves through the S (matrix pipe) -> softmax (VALU) -> P V phases: between two barriers every wave runs
-// its whole item, so the 3-4 waves of a SIMD drift apart and one wave's softmax issues beside another's MFMAs.  Arithmetic, operand
-// order and rounding are those of wattn_persist_kernel<true>: results bit-identical (tests/test_bookkeeping_gpu.py compares them).
-#define WP2_KV_BYTES (WP_NKV * 128)
-#define WP2_LDS (4 * WP2_KV_BYTES + WA_E_BYTES + WP_R_BYTES + WA_WAVES * WA_B_BYTES)
-__global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist2_kernel(WAttnArgs a, int nWin, int nitems) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* KV = smem;                              // [parity]{K, V}: K(p) at p * 2 * WP2_KV_BYTES, V(p) right behind it
-  unsigned char* Es = smem + 4 * WP2_KV_BYTES;
-  unsigned char* Rs = Es + WA_E_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* Bw = reinterpret_cast<float*>(Rs + WP_R_BYTES + wave * WA_B_BYTES);
-  const int l15 = lane & 15, G = lane >> 4;
-  const int T = a.H * a.W, ws = a.ws, Nk = ws * ws;
-  const int dr = lane >> 3, slot = lane & 7;
-
-  int wi, wj, head, b;
-  const int nWh = nWin / a.nWw, nHB = a.heads * a.B;
-  auto decode = [&](int it) {   // same item order as wattn_persist_kernel: interior windows first, overhanging ones last
-    const int r = it / nHB;
-    const int hb = it - r * nHB;
-    head = hb % a.heads;
-    b = hb / a.heads;
-    const int nI = (nWh - 1) * (a.nWw - 1);
-    if (r < nI) {
-      wi = r / (a.nWw - 1);
-      wj = r - wi * (a.nWw - 1);
-    } else if (r - nI < nWh - 1) {
-      wi = r - nI;
-      wj = a.nWw - 1;
-    } else {
-      wi = nWh - 1;
-      wj = r - nI - (nWh - 1);
-    }
-  };
-  auto token_of = [&](int j) -> int {
-    if (j >= Nk) return -2;
-    const int r = (int)(__umul24(j, a.magic) >> 16), c = j - __umul24(r, ws);
-    const int hh = wi * ws + r, ww = wj * ws + c;
-    return (hh < a.H && ww < a.W) ? hh * a.W + ww : -1;
-  };
-  // K and V of the CURRENT decode state into the buffer pair `kvb_`: per wave 16 keys, 2 + 2 LDS-DMA instructions (8 keys x 128 B each).
-  // Logical 16-byte chunk c of a row = hi values of channels 8c .. 8c+7 (c >> 2 = k-block, c & 3 = chunk of its 64-byte hi half);
-  // K: chunk c at slot c ^ ((key & 15) >> 1) (the GEMM image's swizzle: conflict-free fragment reads); V: as in the kernel above.
-#define WP2_ISSUE_KV(kvb_)                                                                                    \
-  {                                                                                                           \
-    int lo_ = lane;   /* opaque: keep the per-lane address parts inside the item loop (register budget) */    \
-    asm volatile("" : "+v"(lo_));                                                                             \
-    const int dr = lo_ >> 3, slot = lo_ & 7;                                                                  \
-    const unsigned short* pq_b_ = a.qp + (long)b * T * a.ldq;                                                 \
-    const int colk_ = a.D + head * 64, colv_ = 2 * a.D + head * 64;                                           \
-    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
-      const int key = 16 * wave + 8 * half + dr;                                                              \
-      const int t_ = token_of(key);                                                                           \
-      const unsigned short* row = t_ >= 0 ? pq_b_ + (long)t_ * a.ldq : a.bp;                                  \
-      const int ck = slot ^ ((key & 15) >> 1);                                                                \
-      GLDS16(row + 2 * (colk_ + 32 * (ck >> 2)) + (ck & 3) * 8, (kvb_) + (16 * wave + 8 * half) * 128);       \
-      const int cv = slot ^ (((key >> 1) & 3) << 1);                                                          \
-      GLDS16(row + 2 * (colv_ + 32 * (cv >> 2)) + (cv & 3) * 8, (kvb_) + WP2_KV_BYTES + (16 * wave + 8 * half) * 128); \
-    }                                                                                                         \
+  if (a.guard) {   // one atomic max per wave, and only when it would raise the word (after the first batches it never does)
+    const float gv = wave_max(amax) * 0.6931471805599453f;
+    if (lane == 0 && gv > *reinterpret_cast<volatile float*>(a.guard)) atomicMax(reinterpret_cast<unsigned*>(a.guard), __float_as_uint(gv));
   }
-#define WP2_LOAD_Q()                                                                                          \
-  {                                                                                                           \
-    tq = token_of(16 * wave + l15);                                                                           \
-    const unsigned short* qrow = a.qp + ((long)b * T + (tq >= 0 ? tq : 0)) * a.ldq;                           \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
-      qh[ks] = *reinterpret_cast<const bf16x8*>(qrow + 2 * (head * 64 + 32 * ks) + 8 * G);                    \
-  }
-
-  // ---- once per workgroup: selector tiles and the rel-pos table image
-  {
-    const int row = lane >> 2, ch = (lane & 3) ^ ((row >> 2) & 3);
-    GLDS16(a.sel + (16 * wave + row) * 32 + ch * 8, Es + 16 * wave * 64);
-#pragma unroll 1
-    for (int u = wave; u < 16; u += WA_WAVES) {
-      const int ks = u >> 3, r0 = 8 * (u & 7);
-      const int rrow = r0 + dr;
-      const int piece = slot ^ ((rrow & 15) >> 1);
-      GLDS16(a.relp + rrow * 128 + 64 * ks + piece * 8, Rs + (ks * 64 + r0) * 128);
-    }
-  }
-  int it = blockIdx.x;
-  if (it >= nitems) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-  decode(it);
-  bf16x8 qh[2];
-  int tq;
-  unsigned kv_off = 0;                                   // byte offset of the running item's buffer pair
-  WP2_ISSUE_KV(KV)
-  WP2_LOAD_Q()
-
-  const int fslot = G ^ ((l15 >> 1) & 7);
-  const int frag_hi = l15 * 128 + fslot * 16;            // rel-pos table image (GEMM layout); K: k-block ks at frag_hi ^ (64 ks)
-  const int frag_e = l15 * 64 + ((G ^ ((l15 >> 2) & 3)) << 4);
-  constexpr float LOG2E = 1.4426950408889634f;
-  const float sc2 = a.scale * LOG2E, rscale = 1.0f / a.scale;
-
-#pragma unroll 1
-  for (;;) {
-    const int jq = 16 * wave + l15;
-    const bool live = tq >= 0;
-    const bool any_live = __builtin_amdgcn_readfirstlane(__any(live) ? 1 : 0) != 0;   // wave-uniform
-    const int tq_cur = tq;
-    const int head_cur = head, b_cur = b;
-    const unsigned char* Kc = KV + kv_off;
-    const unsigned char* Vc = Kc + WP2_KV_BYTES;
-    // ---- the item's only barrier: my K / V pieces and Q have landed (the table image too, first item) => everyone's have; everyone is
-    // past the previous item, whose buffers the next item's pieces may now overwrite
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int it_next = it + gridDim.x;
-    const bool has_next = it_next < nitems;
-    if (has_next) {
-      decode(it_next);
-      WP2_ISSUE_KV(KV + (kv_off ^ (2 * WP2_KV_BYTES)))
-    }
-    if (any_live) {
-      bf16x8 bqh = {0, 0, 0, 0, 0, 0, 0, 0}, bql = {0, 0, 0, 0, 0, 0, 0, 0};
-      {
-        // rel-pos terms T[i][q] = rel_pos[i] . q (table fragments from the LDS image), re-indexed per query by key coordinate
-        f32x4 tt[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          tt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 rh_ = *reinterpret_cast<const bf16x8*>(Rs + (ks * 64 + 16 * t) * 128 + frag_hi);
-            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[ks]), tt[t], 0, 0, 0);
-          }
-        }
-        int lane_o = lane;   // opaque copy: LICM would otherwise hoist ~20 per-lane addresses out of the item loop and spill them
-        asm volatile("" : "+v"(lane_o));
-        const int l15 = lane_o & 15, G = lane_o >> 4;
-        const int jqc = jq < Nk ? jq : 0;
-        const int qr = (int)(__umul24(jqc, a.magic) >> 16), qc = jqc - __umul24(qr, ws);
-        *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * (t & 1) + 4 * G + r;
-            const int kc = ((t >> 1) ? qc : qr) + (ws - 1) - i;
-            if (kc >= 0 && kc < ws) Bw[l15 * 32 + (t >> 1) * 14 + kc] = tt[t][r] * rscale;
-          }
-        const float4 b0 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G);
-        const float4 b1 = *reinterpret_cast<const float4*>(Bw + l15 * 32 + 8 * G + 4);
-        uint4 hh, ll;
-        split2_f16(b0.x, b0.y, hh.x, ll.x);
-        split2_f16(b0.z, b0.w, hh.y, ll.y);
-        split2_f16(b1.x, b1.y, hh.z, ll.z);
-        split2_f16(b1.z, b1.w, hh.w, ll.w);
-        bqh = __builtin_bit_cast(bf16x8, hh);
-        bql = __builtin_bit_cast(bf16x8, ll);
-      }
-      // S^T = sel Bq^T + K Q^T
-      f32x4 s[13];
-#pragma unroll
-      for (int t = 0; t < 13; ++t) {
-        const bf16x8 e_ = *reinterpret_cast<const bf16x8*>(Es + 16 * t * 64 + frag_e);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bql), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bqh), s[t], 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(Kc + 16 * t * 128 + (frag_hi ^ (64 * ks)));
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[ks]), s[t], 0, 0, 0);
-        }
-        if (t & 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 13 tiles' fragment reads (spills at 128 VGPRs)
-      }
-      float mxs;
-      {
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        const int G = lane_o >> 4;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 13; ++t) {
-          s[t] *= sc2;
-          if (16 * t + 16 > Nk) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * G + r) < Nk ? s[t][r] : -INFINITY;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        mxs = mx;
-      }
-      int lane_o = lane;   // opaque copy: the 28 transposed-read addresses below must not be hoisted out of the item loop
-      asm volatile("" : "+v"(lane_o));
-      const int l15 = lane_o & 15, G = lane_o >> 4;
-      f32x4 o[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float psum = 0.f;
-#pragma unroll
-      for (int g = 0; g < 7; ++g) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          if (2 * g + hf < 13) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
-              s[2 * g + hf][r] = p;
-              psum += p;
-            }
-          }
-        }
-        uint4 hh;
-        hh.x = pack_f16(s[2 * g][0], s[2 * g][1]);
-        hh.y = pack_f16(s[2 * g][2], s[2 * g][3]);
-        if (2 * g + 1 < 13) {
-          hh.z = pack_f16(s[2 * g + 1][0], s[2 * g + 1][1]);
-          hh.w = pack_f16(s[2 * g + 1][2], s[2 * g + 1][3]);
-        } else {
-          hh.z = hh.w = 0u;   // keys 208..223 do not exist
-        }
-        const bf16x8 ph = __builtin_bit_cast(bf16x8, hh);
-        const int row0 = 32 * g + 4 * G + (l15 >> 2);
-        const int sw = (row0 >> 1) & 3;
-        const int second = (2 * g + 1 < 13) ? 16 * 128 : 0;   // no V rows beyond 207: re-read valid rows (their P is zero)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int voff = row0 * 128 + ((d ^ sw) << 5) + 8 * (l15 & 3);
-          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vc + voff));
-          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vc + voff + second));
-          const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph), o[d], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      psum += __shfl_xor(psum, 16, 64);
-      psum += __shfl_xor(psum, 32, 64);
-      const float inv = 1.0f / psum;
-      unsigned short* orow = a.op + ((long)b_cur * T + (tq_cur >= 0 ? tq_cur : 0)) * a.ldo;
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-        store_planes8_pair<16>(orow, head_cur * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, tq_cur >= 0);
-    }
-    if (!has_next) break;
-    it = it_next;
-    kv_off ^= 2 * WP2_KV_BYTES;
-    WP2_LOAD_Q()
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-static int g_wattn_flavour = 0;   // testing / A-B aid: 1 = the three-barrier persistent kernel, 2 = the one-barrier kernel (all-fp16 form only), 0 = automatic
-extern "C" int mmsa_debug_wattn_flavour(int flavour) {
-  g_wattn_flavour = (flavour == 1 || flavour == 2) ? flavour : 0;
-  return MMSA_OK;
 }
 
 extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, long ldq, const unsigned short* bias_planes,
                                             const unsigned short* relpos_planes, const unsigned short* selector,
                                             unsigned short* out_planes, long ldo,
                                             int B, int H, int W, int heads, int head_dim, int window_size, float scale,
-                                            int out_fmt, int v_fmt, hipStream_t stream) {
+                                            int out_fmt, int v_fmt, float* max_abs_logit, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
   MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "window_attention: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(v_fmt == 0 || v_fmt == 2, "window_attention: v_fmt %d (0 = bf16 hi/lo planes; 2 = qkv, bias and rel-pos planes in the h8 format and an fp16 selector: every contraction on the fp16 MFMA)", v_fmt);
@@ -929,63 +430,47 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
   a.qp = qkv_planes; a.ldq = ldq; a.bp = bias_planes; a.relp = relpos_planes; a.sel = selector; a.op = out_planes; a.ldo = ldo; a.ofmt = out_fmt;
   a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
   a.nWw = cdiv(W, window_size);
-  static const int dbg = getenv("MMSA_WATTN_DEBUG") ? atoi(getenv("MMSA_WATTN_DEBUG")) : 0;
-  a.debug = dbg;
+  a.guard = max_abs_logit;
   a.magic = (unsigned)((65536 + window_size - 1) / window_size);
   for (int j = 0; j < WA_NKV; ++j)   // the kernel's multiply-shift division must be exact for every index it divides
     if ((int)(((unsigned)j * a.magic) >> 16) != j / window_size) {
       mmsa_set_error("window_attention: index arithmetic not exact for window_size %d", window_size);
       return MMSA_ERR_ARG;
     }
-  static const bool v1 = getenv("MMSA_WATTN_V1") != nullptr;   // one workgroup per item (A/B timing)
-  static bool attr_set = false;
-  static int num_cus = 256;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
+  // (cached per process: the launch attributes and the CU count of the current device -- immutable once set)
+  static const int num_cus = [] {
     (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
     (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
-    (void)hipFuncSetAttribute((const void*)wattn_persist2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WP2_LDS);
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      num_cus = prop.multiProcessorCount;
-    attr_set = true;
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
+    return 256;
+  }();
   const int nWin = cdiv(H, window_size) * a.nWw;
-  if (v1 && !v_fmt) {
-    dim3 grid(nWin, heads, B);
-    hipLaunchKernelGGL(wattn_kernel, grid, dim3(WA_WAVES * 64), WA_LDS, stream, a);
-  } else {
-    const int nitems = nWin * heads * B;
-    // Grid: a workgroup walks items g, g + G, g + 2G, ... of a list that holds the interior windows first and the windows that
-    // overhang the image (fewer live query tiles: cheaper) last.  Candidates: the fewest workgroups that finish in ceil(items / CUs)
-    // items each (leaves CUs to concurrent streams) and one per CU; the cheaper schedule by a two-class cost model wins -- with 200
-    // of 256 workgroups every workgroup of ViT-L's 25 x 16 x 2 items got 3 interior + 1 edge item, with 256 it is 2 + 1 (or 2).
-    const int nWh_ = cdiv(H, window_size), nWw_ = a.nWw, nHB = heads * B;
-    const int n_int = (nWh_ - 1) * (nWw_ - 1) * nHB;                    // items of interior windows (they come first)
-    const int live_h = H - (nWh_ - 1) * window_size, live_w = W - (nWw_ - 1) * window_size;
-    const double edge_cost = 0.35 + 0.65 * (0.5 * (live_h + live_w) / window_size);   // fixed part (K/V transfer, barriers) + live query tiles
-    auto schedule_cost = [&](int G) {
-      double worst = 0.0;
-      for (int g = 0; g < G; ++g) {
-        double c = 0.0;
-        for (int it = g; it < nitems; it += G) c += it < n_int ? 1.0 : edge_cost;
-        worst = c > worst ? c : worst;
-      }
-      return worst;
-    };
-    const int rounds = cdiv(nitems, num_cus);
-    int grid = cdiv(nitems, rounds);
-    const int grid_all = nitems < num_cus ? nitems : num_cus;
-    if (schedule_cost(grid_all) < schedule_cost(grid) - 1e-9) grid = grid_all;
-    // the one-barrier kernel measured SLOWER than the three-barrier one (ViT-L block of one / two images: 26.7 / 44.9 against 24.5 / 41.0 us,
-    // same process, profiles/r03_wattn_one_barrier.txt): opt-in only (MMSA_WATTN_P2=1 or mmsa_debug_wattn_flavour(2)), kept bit-identical by the tests
-    static const bool one_barrier_env = getenv("MMSA_WATTN_P2") != nullptr;
-    const bool one_barrier = (one_barrier_env || g_wattn_flavour == 2) && g_wattn_flavour != 1;
-    if (v_fmt && one_barrier) hipLaunchKernelGGL(wattn_persist2_kernel, dim3(grid), dim3(WA_WAVES * 64), WP2_LDS, stream, a, nWin, nitems);
-    else if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
-    else hipLaunchKernelGGL(wattn_persist_kernel<false>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
-  }
+  const int nitems = nWin * heads * B;
+  // Grid: a workgroup walks items g, g + G, g + 2G, ... of a list that holds the interior windows first and the windows that
+  // overhang the image (fewer live query tiles: cheaper) last.  Candidates: the fewest workgroups that finish in ceil(items / CUs)
+  // items each (leaves CUs to concurrent streams) and one per CU; the cheaper schedule by a two-class cost model wins -- with 200
+  // of 256 workgroups every workgroup of ViT-L's 25 x 16 x 2 items got 3 interior + 1 edge item, with 256 it is 2 + 1 (or 2).
+  const int nWh_ = cdiv(H, window_size), nWw_ = a.nWw, nHB = heads * B;
+  const int n_int = (nWh_ - 1) * (nWw_ - 1) * nHB;                    // items of interior windows (they come first)
+  const int live_h = H - (nWh_ - 1) * window_size, live_w = W - (nWw_ - 1) * window_size;
+  const double edge_cost = 0.35 + 0.65 * (0.5 * (live_h + live_w) / window_size);   // fixed part (K/V transfer, barriers) + live query tiles
+  auto schedule_cost = [&](int G) {
+    double worst = 0.0;
+    for (int g = 0; g < G; ++g) {
+      double c = 0.0;
+      for (int it = g; it < nitems; it += G) c += it < n_int ? 1.0 : edge_cost;
+      worst = c > worst ? c : worst;
+    }
+    return worst;
+  };
+  const int rounds = cdiv(nitems, num_cus);
+  int grid = cdiv(nitems, rounds);
+  const int grid_all = nitems < num_cus ? nitems : num_cus;
+  if (schedule_cost(grid_all) < schedule_cost(grid) - 1e-9) grid = grid_all;
+  if (v_fmt) hipLaunchKernelGGL(wattn_persist_kernel<true>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
+  else hipLaunchKernelGGL(wattn_persist_kernel<false>, dim3(grid), dim3(WA_WAVES * 64), WP_LDS, stream, a, nWin, nitems);
   MMSA_CHECK_LAUNCH("window_attention");
   return MMSA_OK;
 }

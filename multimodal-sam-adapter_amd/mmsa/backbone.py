@@ -275,6 +275,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 sd[b + "rel_pos_w"] = torch.zeros(L, hd, device=dev)
         return sd
 
+    def _fold_ln_wanted(self, hidden=None):
+        """Whether _pack folds the ViT blocks' LayerNorms into their consumer GEMMs (a pack-time setting: checkpoint.load_packed compares it)."""
+        D, heads = self.cfg["embed_dim"], self.cfg["num_heads"]
+        Da = heads * ops.pad32(D // heads)
+        hidden = int(D * self.cfg["mlp_ratio"]) if hidden is None else hidden
+        return (os.environ.get("MMSA_FOLD_LN", "1") != "0" and bool(getattr(self, "fold_ln", True)) and D % 64 == 0
+                and (3 * Da) % 128 == 0 and hidden % 128 == 0)
+
     @torch.no_grad()
     def _pack(self, dev):
         cfg = self.cfg
@@ -326,8 +334,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # residual stream (proj, lin2, the injector's output projection) also writes the stream as planes and per-row strip sums; qkv / lin1
         # run on W o w and compute rstd * (x W'^T - mean * colsum(W')) + (W b + bias) in their epilogue.  tools/lnfold_study.py: same error as
         # LayerNorm + GEMM on the seeded weights, + 1.5e-5 at |mean| = 4.5 std.  Needs whole 128-column tiles and 64-column strips.
-        fold = (os.environ.get("MMSA_FOLD_LN", "1") != "0" and bool(getattr(self, "fold_ln", True)) and D % 64 == 0
-                and (3 * Da) % 128 == 0 and hidden_ % 128 == 0)
+        fold = self._fold_ln_wanted(hidden_)
         pk["fold_ln"] = fold
 
         for i in range(cfg["depth"]):
@@ -539,6 +546,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             inv = sd[f"norm{i}.weight"] / torch.sqrt(sd[f"norm{i}.running_var"] + 1e-5)
             pk["bn"].append((inv.contiguous(), (sd[f"norm{i}.bias"] - sd[f"norm{i}.running_mean"] * inv).contiguous()))
         pk["pos_src"] = sd["pos_embed"]
+        pk["attn_guard"] = torch.zeros(cfg["depth"], device=dev)   # one logit guard word per ViT block (check_attention_guard)
         pk["geom"] = {}
         torch.cuda.synchronize(dev)
         return pk
@@ -617,10 +625,16 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             raise RuntimeError("mmsa: input must be a GPU tensor; the MI355X backbone has no CPU path")
         with torch.cuda.device(x.device):    # launches go to the current stream of the input's device
             x, B, H, W = self._prepare(x)
-            # ---- spatial prior module -> c1, c
-            c1, cbuf, Nc = self._cbufs(B, H, W)
-            c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
-            return self._vit(x, B, H, W, c1, cbuf, c1_ready), None
+            guard = self.attention_guard == "sync" and not torch.cuda.is_current_stream_capturing()
+            for _ in range(self.cfg["depth"] + 1):
+                # ---- spatial prior module -> c1, c
+                c1, cbuf, Nc = self._cbufs(B, H, W)
+                c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
+                outs = self._vit(x, B, H, W, c1, cbuf, c1_ready)
+                # ---- attention logit guard: a block that ran fp16 attention beyond its range has been moved to bf16 hi/lo -> once more
+                if not guard or not self.check_attention_guard():
+                    break
+            return outs, None
 
     @torch.no_grad()
     def forward_taps(self, x):
@@ -772,25 +786,30 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         scale = self._hd_true ** -0.5     # IE:445: head_dim ** -0.5 of the model's true width
         Da = heads * hd
         T = Hp * Wp
-        fold = self._packed["fold_ln"]    # norm1 / norm2 inside the qkv / lin1 GEMMs; x's planes and row sums come from its producer
+        # LayerNorm fold: norm1 / norm2 inside the qkv / lin1 GEMMs; x's planes and row sums come from its producer.  The row-normalising
+        # epilogue lives in the 256-row LDS-DMA kernel only (M >= 128): a forward with fewer token rows (one 128 x 128 image, a small slide
+        # crop) runs the SAME folded weights behind a plain LayerNorm pass without affine part -- LN(x; w, b) W^T + bias = xhat (W o w)^T + (W b + bias)
+        folded_w = self._packed["fold_ln"]
+        fold = folded_w and B * T >= 128
         # intermediate activations travel as bf16 hi/lo planes: split once by the producer, consumed by the
         # GEMM / attention kernels with plain 16-byte copies (same bytes as fp32, no re-splitting per column block)
         fused = bp.get("relp") is not None or relg is not None
         # fp16 operands inside the attention kernels ("attnv" site) only where this block's logits are small enough: _attn_mode (on the
         # first forward it may also move this block's qkv GEMM to bf16 hi/lo operands)
-        vf0 = bp["qkv"].fmt
-        f16 = bp["qkv_bp16"] is not None and self._attn_mode(bp, x, B * T, Da, heads, hd, scale) == "f16"
+        f16 = bp["qkv_bp16"] is not None and self._attn_mode(bp) == "f16"
         vf = bp["qkv"].fmt   # operand format of this block's qkv GEMM: its producer wrote the stream planes / LayerNorm writes them in it
+        gw = self._packed["attn_guard"][bp["index"]:bp["index"] + 1]   # this block's logit guard word
         if fold:
             xp, rs = self._stream_planes(B * T, vf)
-            if vf != vf0:    # that first forward only: the planes were written for the old format -- split the stream again
-                ops.split_planes(x, kpad=D, out=xp)
             mr = ws.get("blk_mr", B * T, 2)
             ops.rowstats_finalize(rs, B * T, D, 1e-6, mr)
             n = None
         else:
             n = ws.planes("blk_n", B * T, D, fmt=vf)
-            ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
+            if folded_w:
+                ops.layernorm(x, self._packed["ln_one"], self._packed["ln_zero"], 1e-6, out_planes=n)
+            else:
+                ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
         all16 = fused and f16            # the fused kernels: every contraction on fp16 hi parts of h8 planes (v_fmt = 2), or none (0)
         qkv = ws.planes("blk_qkv", B * T, 3 * Da, fmt=ops.FMT_H8 if all16 else ops.FMT_B3)
         if all16:
@@ -803,18 +822,18 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         if fold:
             ops.gemm(xp, bp["qkv"], bias=bp["qkv_bf"], out_planes=qkv, row_norm=(mr, bp["qkv_cs"]))
         else:
-            ops.gemm(n, bp["qkv"], bias=bp["qkv_b"], out_planes=qkv)
+            ops.gemm(n, bp["qkv"], bias=bp["qkv_bf"] if folded_w else bp["qkv_b"], out_planes=qkv)
         wsz = bp["ws"]
         ao = ws.planes("blk_ao", B * T, Da, fmt=bp["proj"].fmt)
         if bp.get("relp") is not None:   # windowed block, head_dim 64: K/V-resident kernel with the rel-pos terms fused
-            ops.window_attention(qkv, bias_p, bp["relp16"] if all16 else bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale)
+            ops.window_attention(qkv, bias_p, bp["relp16"] if all16 else bp["relp"], ao, B, Hp, Wp, heads, hd, wsz, scale, max_logit=gw)
         elif relg is not None:           # global block on a 64-wide grid: flash kernel with the rel-pos terms fused
-            ops.global_attention(qkv, bias_p, relg[1] if all16 else relg[0], ao, B, Hp, Wp, heads, hd, scale)
+            ops.global_attention(qkv, bias_p, relg[1] if all16 else relg[0], ao, B, Hp, Wp, heads, hd, scale, max_logit=gw)
         else:
             kk = 2 * wsz if wsz else Hp + Wp
             rp = ws.get("blk_rp", B * heads * T, kk)
             ops.relpos_bias(qkv, rel[0], rel[1], rp, B, Hp, Wp, heads, hd, wsz)
-            ops.attention(qkv, bias_p, rp, ao, B, Hp, Wp, heads, hd, wsz, scale)
+            ops.attention(qkv, bias_p, rp, ao, B, Hp, Wp, heads, hd, wsz, scale, max_logit=gw)
         vf = bp["lin1"].fmt              # the MLP's operand format (the qkv GEMM of a block with large logits runs on bf16 hi/lo: _attn_mode)
         h = ws.planes("blk_h", B * T, bp["lin1"].n, fmt=vf)
         if fold:
@@ -830,69 +849,89 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             return
         ops.gemm(ao, bp["proj"], x, bias=bp["proj_b"], resid=x)
         n = ws.planes("blk_n", B * T, D, fmt=vf)
-        ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
-        ops.gemm(n, bp["lin1"], bias=bp["lin1_b"], act="gelu", out_planes=h)
+        if folded_w:
+            ops.layernorm(x, self._packed["ln_one"], self._packed["ln_zero"], 1e-6, out_planes=n)
+        else:
+            ops.layernorm(x, bp["n2w"], bp["n2b"], 1e-6, out_planes=n)
+        ops.gemm(n, bp["lin1"], bias=bp["lin1_bf"] if folded_w else bp["lin1_b"], act="gelu", out_planes=h)
         ops.gemm(h, bp["lin2"], x, bias=bp["lin2_b"], resid=x)
 
     # fp16 operands inside the attention kernels are safe only while the logits stay small: the rounding error of q.k grows with the
     # logit's magnitude and is then exponentiated.  tools/attention_precision_study.py --logit-scale (CPU oracle, ViT-B, f1..f4 against
     # fp32): max |logit| 3.8 (the seeded test weights) -> 3e-5 for the all-fp16 kernels; 13 -> 1.5e-4; 48 -> 8e-3 (P V alone in fp16:
     # 3e-3), while bf16 hi/lo operands stay at 3e-6 / 1e-5.  Released SAM checkpoints are peakier than the seeded weights, so the
-    # format is a MEASURED per-block decision, not a constant.
+    # format is a MEASURED per-block decision, and it is measured on EVERY batch: the attention kernels fold the largest |logit| they
+    # score (rel-pos terms included) into one device word per block (include/mmsa.h "Attention logit guard"; `_packed["attn_guard"]`).
     ATTN_F16_MAX_LOGIT = 8.0
 
-    def _attn_mode(self, bp, x, rows, Da, heads, hd, scale):
+    # What happens with the guard words (`model.attention_guard`):
+    #   "sync" (default)  every EAGER forward reads them back (one 4*depth-byte copy, a host sync) before it returns; a block that ran fp16
+    #                     attention on logits above ATTN_F16_MAX_LOGIT moves to bf16 hi/lo operands -- its attention kernels AND its four
+    #                     GEMM weights, repacked from the state dict -- and the forward is run again, so the tensors returned were never
+    #                     computed on fp16 attention beyond the threshold.  A block only ever moves from fp16 to bf16 hi/lo.
+    #   "off"             nothing is read back; `check_attention_guard()` does it on demand.
+    # Captured graphs (mmsa.Chains, SlideRunner, bench.py) cannot re-route themselves: their owner calls `check_attention_guard()`
+    # after a replay (Chains.check_guard) and captures again when it reports a change.
+    attention_guard = "sync"
+
+    def _attn_policy(self):
+        return os.environ.get("MMSA_ATTN") or getattr(self, "attention_precision", "auto")
+
+    def _attn_mode(self, bp):
         """'f16' or 'b3' for this block's attention kernels.  `attention_precision` (or MMSA_ATTN): 'f16' / 'b3' force one; 'auto'
-        (default) decides ONCE per block, on the first forward after packing, from that batch's largest |q.k| * scale (computed here
-        with torch from the block's own input and qkv weights: calibration like the weight packing, not part of later
-        forwards or of a captured graph) and keeps the decision: 'f16' iff it is <= ATTN_F16_MAX_LOGIT."""
-        pol = os.environ.get("MMSA_ATTN") or getattr(self, "attention_precision", "auto")
+        (default): the block's recorded mode -- 'f16' until its guard word has exceeded ATTN_F16_MAX_LOGIT once (check_attention_guard)."""
+        pol = self._attn_policy()
         if pol in ("f16", "b3"):
             return pol
-        mode = bp.get("amode")
-        if mode is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("mmsa: run one eager forward before capturing a graph (per-block attention precision is decided on it)")
-            D_ = self.cfg["embed_dim"]
-            w = ops.planes_to_float(bp["qkv"], cols=D_)[:2 * Da]
-            if self._packed["fold_ln"]:      # packed weight = W o n1w, bias = W n1b + qkv bias: feed the normalised stream without its affine part
-                qk = torch.nn.functional.layer_norm(x[:rows], (D_,), None, None, 1e-6) @ w.t() + bp["qkv_bf"][:2 * Da]
-            else:
-                qk = torch.nn.functional.layer_norm(x[:rows], (D_,), bp["n1w"], bp["n1b"], 1e-6) @ w.t() + bp["qkv_b"][:2 * Da]
-            q = qk[:, :Da].reshape(rows, heads, hd).transpose(0, 1)
-            k = qk[:, Da:].reshape(rows, heads, hd).transpose(0, 1)
-            # an upper bound over ALL token pairs of the batch (windows and images are not told apart: conservative), head by head
-            mx = 0.0
-            for h_ in range(heads):
-                kh = k[h_]
-                for r0 in range(0, rows, 8192):
-                    mx = max(mx, float((q[h_, r0:r0 + 8192] @ kh.t()).abs().max()) * scale)
-            mx = max(mx, bp.get("max_logit", 0.0))   # calibrate_attention: the largest value over every batch shown so far
-            bp["max_logit"] = mx
-            mode = bp["amode"] = "f16" if mx <= self.ATTN_F16_MAX_LOGIT else "b3"
-            if mode == "b3" and bp["qkv"].fmt == ops.FMT_H8:
-                # the projections around those logits must not lose them either: q and k from 2^-15.6 products turn a logit of 48 into an
-                # error of ~1e-3 before the exponential, and what proj / lin1 / lin2 lose reaches the NEXT block's q and k.  The whole
-                # block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.
-                bp.update(self._block_gemm_planes(self._pack_state_dict(x.device), bp["index"], ops.FMT_B3, self._packed["fold_ln"], x.device))
-        return mode
+        return bp.get("amode") or "f16"
+
+    @torch.no_grad()
+    def check_attention_guard(self, reroute=True):
+        """Read the per-block logit guard words (host sync) and fold them into the blocks' `max_logit`.  With `attention_precision =
+        "auto"` a block that runs fp16 attention and has seen a logit above ATTN_F16_MAX_LOGIT is moved to bf16 hi/lo operands (attention
+        kernels and the block's four GEMM weights, repacked here) when `reroute`.  Returns the list of block indices that were (or, with
+        reroute=False, would have to be) moved: non-empty means the outputs of the batches since the last check were computed on fp16
+        attention beyond the threshold -- run them again (forward() does by itself), and capture graphs again."""
+        pk = self._packed
+        if pk is None:
+            return []
+        vals = pk["attn_guard"].tolist()      # device -> host: waits for the work queued so far
+        auto = self._attn_policy() == "auto"
+        moved = []
+        for bp, v in zip(pk["blocks"], vals):
+            bp["max_logit"] = max(float(v), bp.get("max_logit", 0.0))
+            if not auto or bp["qkv_bp16"] is None:
+                continue
+            if bp.get("amode") != "b3" and bp["max_logit"] > self.ATTN_F16_MAX_LOGIT:
+                moved.append(bp["index"])
+                if reroute:
+                    bp["amode"] = "b3"
+                    if bp["qkv"].fmt == ops.FMT_H8:
+                        # the projections around those logits must not lose them either: q and k from 2^-15.6 products turn a logit of 48 into
+                        # an error of ~1e-3 before the exponential, and what proj / lin1 / lin2 lose reaches the NEXT block's q and k.  The
+                        # whole block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.
+                        dev = pk["attn_guard"].device
+                        bp.update(self._block_gemm_planes(self._pack_state_dict(dev), bp["index"], ops.FMT_B3, pk["fold_ln"], dev))
+            elif bp.get("amode") is None:
+                bp["amode"] = "f16"
+        return moved
+
+    def attention_modes(self):
+        """[(mode, max |logit| seen)] per ViT block: 'f16' / 'b3' as the next forward will run it."""
+        return [(self._attn_mode(bp), bp.get("max_logit", 0.0)) for bp in self._packed["blocks"]] if self._packed else []
 
     def calibrate_attention(self, x):
-        """Show the model one more batch for the per-block attention-precision decision (`attention_precision = "auto"`): every block
-        measures its logit range again on `x` (eager forward) and keeps the LARGEST value over all batches it has been shown, so a block
-        only ever moves from fp16 to bf16 hi/lo operands.  The first forward after packing calibrates by itself; call this with a few
-        batches that are representative of the deployment data (the decision is frozen afterwards: later forwards and captured graphs do
-        not measure).  Returns [] when no block changed its mode, else the new list of modes -- graphs captured before the call must then be
-        captured again."""
-        if self._packed is None:
+        """Show the model a batch ahead of deployment: an eager forward with the guard read back, whatever `attention_guard` says.  Returns
+        the list of blocks that moved to bf16 hi/lo operands (graphs captured before must then be captured again)."""
+        keep = self.attention_guard
+        before = [bp.get("amode") for bp in self._packed["blocks"]] if self._packed else None
+        self.attention_guard = "sync"
+        try:
             self(x)
-            return [b.get("amode") for b in self._packed["blocks"]]
-        before = [b.get("amode") for b in self._packed["blocks"]]
-        for b in self._packed["blocks"]:
-            b.pop("amode", None)
-        self(x)
-        after = [b.get("amode") for b in self._packed["blocks"]]
-        return after if after != before else []
+        finally:
+            self.attention_guard = keep
+        after = [bp.get("amode") for bp in self._packed["blocks"]]
+        return [i for i, m in enumerate(after) if m == "b3" and (before is None or before[i] != "b3")]
 
     # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)
     def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None, stream_out=None):
@@ -922,7 +961,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
         self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"],
                    stream_out=(self._stream_planes(B * T, self._packed["blocks"][ip["first_block"]]["qkv"].fmt)
-                               if self._packed["fold_ln"] else None))
+                               if self._packed["fold_ln"] and B * T >= 128 else None))
 
     def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
         ws, D = self._ws, self.cfg["embed_dim"]
@@ -1040,12 +1079,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             wf = st["stages"][i][0]["pw1"].fmt          # operand format of this stage's pointwise convs (bf16 hi/lo unless "cnx" is an h8 site)
             n = ws.planes(t + "n", 2 * P, c, fmt=wf)
             hbuf = ws.planes(t + "h", 2 * P, 4 * c, fmt=wf)
-            # one-kernel depthwise conv + LayerNorm (csrc/conv_ln.hip): 42.6 vs 31 + 26 us at C = 384, but step-neutral (its
-            # 122-KiB workgroups push the overlapping neck streams off the CUs: see its header) -- off unless asked for
-            fused = ops.dwconv7_ln_supported(c) and getattr(self, "fuse_dwconv_ln", False)
             # narrow stages (C = 96 / 192): the pointwise pair as ONE kernel that keeps the 4C hidden tensor in LDS (csrc/mlp_fused.hip)
             fuse_mlp = ops.convnext_mlp_fused_supported(c) and bool(getattr(self, "fuse_convnext_mlp", True)) and os.environ.get("MMSA_FUSE_MLP", "1") != "0"
-            fold = "pw1f" in st["stages"][i][0] and not fused and not fuse_mlp and hh % 8 == 0 and wwd % 8 == 0 and P >= 128
+            fold = "pw1f" in st["stages"][i][0] and not fuse_mlp and hh % 8 == 0 and wwd % 8 == 0 and P >= 128
             if fold:
                 rs = ws.get(t + "rs", 2 * P, 2 * (c // 64))
                 mr = ws.get(t + "mr", 2 * P, 2)
@@ -1061,11 +1097,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                              stride_a=P * 2 * hbuf.kpad, stride_w=blk["pw2"].n * 2 * blk["pw2"].kpad, stride_bias=c,
                              stride_r=P * c, stride_c=P * c)
                     continue
-                if fused:   # depthwise conv + LayerNorm in one kernel: the conv output never goes to memory
-                    ops.dwconv7_ln(cur, blk["dw"], blk["dw_b"], blk["nw"], blk["nb"], 1e-6, n, 2 * B, hh, wwd, imgs_per_group=B)
-                else:
-                    ops.dwconv(cur, blk["dw"], blk["dw_b"], d, 2 * B, hh, wwd, 7, imgs_per_group=B)
-                    ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n, group_rows=P, w_gstride=c)
+                ops.dwconv(cur, blk["dw"], blk["dw_b"], d, 2 * B, hh, wwd, 7, imgs_per_group=B)
+                ops.layernorm(d, blk["nw"], blk["nb"], 1e-6, out_planes=n, group_rows=P, w_gstride=c)
                 if fuse_mlp:
                     ops.convnext_mlp_fused(n, blk["pw1"], blk["pw2"], blk["pw1_b"], blk["pw2_b"], blk["gamma"], cur, P, batch=2,
                                            stride_a=P * 2 * n.kpad, stride_w1=blk["pw1"].n * 2 * blk["pw1"].kpad,

@@ -60,17 +60,24 @@ class Chains:
             self.backbone(x[:bc])                    # packs the weights and creates the workspace
             torch.cuda.synchronize(dev)
             ops.GEMM_MAX_GRID = cus // self.n if self.n > 1 else 0
+            self.graphs, self.streams, self.feats = [], [], []
             try:
+                # pass 1, eager: every chain runs its OWN sub-batch once -- allocates its scratch buffers (and the shared logits) and, with
+                # the backbone's attention guard on, shows every image of the batch to the per-block precision decision BEFORE anything is
+                # captured (a block that moves to bf16 hi/lo operands gets new weight planes: a graph captured earlier would point at the old ones)
+                origin = []
                 for i in range(self.n):
                     s = torch.cuda.Stream(device=dev)
-                    xs = x[i * bc:(i + 1) * bc]
                     s.wait_stream(torch.cuda.current_stream(dev))
                     with torch.cuda.stream(s):
-                        self._step(i, xs)            # eager: allocates this chain's scratch buffers (and the shared logits)
+                        self._step(i, x[i * bc:(i + 1) * bc])
                     torch.cuda.synchronize(dev)
+                    origin.append(s)
+                # pass 2: one graph per chain
+                for i in range(self.n):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s):
-                        feats = self._step(i, xs)
+                    with torch.cuda.graph(g, stream=origin[i]):
+                        feats = self._step(i, x[i * bc:(i + 1) * bc])
                     torch.cuda.synchronize(dev)
                     self.graphs.append(g)
                     self.streams.append(torch.cuda.Stream(device=dev))
@@ -99,6 +106,18 @@ class Chains:
         if join:
             self.join()
         return self.logits if self.head is not None else self.feats
+
+    @torch.no_grad()
+    def check_guard(self, recapture=True):
+        """Read the backbone's attention logit guard (host sync: call it after the replays whose outputs matter).  [] = every block ran
+        inside its operand precision's range.  Otherwise the listed blocks have been moved to bf16 hi/lo operands: the outputs of the
+        replays since the last check were computed on fp16 attention beyond the threshold, and the graphs are stale -- with
+        `recapture` they are captured again here (same static input buffer), so the next replay() is valid."""
+        torch.cuda.synchronize(self.x.device)
+        moved = self.backbone.check_attention_guard()
+        if moved and recapture:
+            self.capture(self.x)
+        return moved
 
     def join(self):
         """Make the current stream wait for the chains' last enqueued pass."""

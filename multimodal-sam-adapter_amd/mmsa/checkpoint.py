@@ -11,6 +11,7 @@
 
 Pinned by tests/test_host_cpu.py against tests/golden/sam_ckpt.npz, which the reference's own loader and converter produced on
 seeded checkpoints (tools/oracle/make_golden.py::gen_sam_ckpt)."""
+import hashlib
 import os
 import warnings
 
@@ -18,7 +19,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 7   # 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
+PACK_FORMAT = 8   # 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
 
 
 def unwrap_state_dict(ck):
@@ -118,38 +119,42 @@ def _dec(o, dev):
     return o
 
 
+def _digest_tensor(h, t):
+    t = t.detach().contiguous().cpu()
+    if t.dtype == torch.bfloat16:
+        t = t.view(torch.int16)
+    h.update(str((tuple(t.shape), str(t.dtype))).encode())
+    h.update(t.numpy().tobytes())
+
+
 def _fingerprint(sd):
-    """Identity of a state dict: key list + an ORDER-DEPENDENT double checksum (tensor i weighs i + 1, its elements weigh by position
-    class: permuted tensors or permuted keys change it)."""
-    tot = 0.0
-    for i, (k, v) in enumerate(sd.items()):
-        if not v.dtype.is_floating_point or v.numel() == 0:
-            continue
-        d = v.detach().double().flatten()
-        tot += (i + 1) * (d.abs().sum().item() + 0.5 * d[::2].sum().item() + 0.25 * d[: max(d.numel() // 3, 1)].sum().item())
-    return [list(sd.keys()), tot]
+    """Identity of a state dict: key list + a sha1 over every tensor's shape, dtype and BYTES in key order (exact on every host: the
+    floating-point sums used before depended on the reduction order of the torch build that computed them)."""
+    h = hashlib.sha1()
+    for k, v in sd.items():
+        h.update(k.encode())
+        _digest_tensor(h, v)
+    return [list(sd.keys()), h.hexdigest()]
 
 
 def _packed_checksum(enc):
-    """Order-dependent checksum over every tensor of the ENCODED packed tree (the plane buffers as stored): what load_packed
-    verifies before it trusts the planes instead of repacking."""
-    tot, idx = 0.0, [0]
+    """sha1 over every tensor of the ENCODED packed tree, in traversal order (the plane buffers as stored): what load_packed verifies
+    before it trusts the planes instead of repacking."""
+    h, n = hashlib.sha1(), [0]
 
     def walk(o):
-        nonlocal tot
         if isinstance(o, torch.Tensor):
-            idx[0] += 1
-            d = (o.to(torch.int64) if not o.dtype.is_floating_point else o.double()).flatten()
-            if d.numel():
-                tot += idx[0] * (float(d.double().abs().sum()) + 0.5 * float(d[::2].double().sum()))
+            n[0] += 1
+            _digest_tensor(h, o)
         elif isinstance(o, dict):
-            for v in o.values():
+            for k, v in o.items():
+                h.update(str(k).encode())
                 walk(v)
         elif isinstance(o, (list, tuple)):
             for v in o:
                 walk(v)
     walk(enc)
-    return [idx[0], tot]
+    return [n[0], h.hexdigest()]
 
 
 def save_packed(model, path, device="cuda"):
@@ -158,6 +163,17 @@ def save_packed(model, path, device="cuda"):
     dev = torch.device(device)
     with torch.cuda.device(dev):
         pk = model._pack(dev)
+        # the per-block attention precision the model has settled on (backbone.check_attention_guard) travels with the planes: a block
+        # that was moved to bf16 hi/lo operands is packed that way, and every block keeps the largest logit it has seen
+        old = getattr(model, "_packed", None)
+        if old is not None:
+            sd_dev = model._pack_state_dict(dev)
+            for bp, bo in zip(pk["blocks"], old["blocks"]):
+                for k in ("amode", "max_logit"):
+                    if k in bo:
+                        bp[k] = bo[k]
+                if bo.get("amode") == "b3" and bp["qkv"].fmt == ops.FMT_H8:
+                    bp.update(model._block_gemm_planes(sd_dev, bp["index"], ops.FMT_B3, pk["fold_ln"], dev))
         torch.cuda.synchronize(dev)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     enc = _enc(pk)
@@ -179,7 +195,7 @@ def load_packed(model, path, device="cuda"):
         raise RuntimeError(f"{path}: packed for a different architecture")
     want = {"h8_sites": list(model._h8_sites()),
             "share_c_norm": os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(model, "share_c_norm", True))}
-    want["fold_ln"] = bool((blob.get("settings") or {}).get("fold_ln")) if os.environ.get("MMSA_FOLD_LN", "1") != "0" and getattr(model, "fold_ln", True) else False
+    want["fold_ln"] = bool(model._fold_ln_wanted())
     want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
     if blob.get("settings") != want:
         raise RuntimeError(f"{path}: packed with settings {blob.get('settings')}, the model runs {want}: repack")

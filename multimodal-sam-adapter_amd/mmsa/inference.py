@@ -294,3 +294,9 @@ class SlideRunner:
             lib.call("mmsa_slide_argmax", lg.data_ptr(), len(self.jobs), lg.shape[1], lg.shape[2], lg.shape[3], self.tab, self.out.data_ptr(),
                      B, H, W, self.crop_size[0], self.crop_size[1], self.unc.data_ptr(), ops._stream())
         return self.out, self.unc
+
+    def check_guard(self):
+        """Chains.check_guard for the runner's chains: [] = the frames since the last check ran inside the attention kernels' operand range;
+        otherwise the listed ViT blocks were moved to bf16 hi/lo operands, the graphs were captured again and run() must be repeated for
+        those frames (the class maps returned for them came from fp16 attention beyond its threshold)."""
+        return self.chains.check_guard()

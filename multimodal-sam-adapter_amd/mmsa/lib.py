@@ -8,7 +8,9 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmsa_hip.so")
+# MMSA_LIB: an alternative build of the SAME library (tools/build_variant.sh: one source rebuilt with -D flags, e.g. -DMMSA_DEBUG_KNOBS for
+# the timing ablations) -- an A/B aid of the tools under tools/; the tests and bench.py use the in-tree library.
+LIB_PATH = os.environ.get("MMSA_LIB") or os.path.join(_HERE, "libmmsa_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -32,8 +34,6 @@ SIGNATURES = {
     "mmsa_version": [],
     "mmsa_last_error": [],
     "mmsa_debug_poison_lds": [ctypes.c_uint, P],
-    "mmsa_debug_gemm_flavour": [I],
-    "mmsa_debug_wattn_flavour": [I],
     "mmsa_event_create": [POINTER(c_void_p)],
     "mmsa_event_record": [P, P],
     "mmsa_event_elapsed_ms": [P, P, POINTER(c_float)],
@@ -41,13 +41,12 @@ SIGNATURES = {
     "mmsa_ms_deform_attn_forward": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mmsa_ms_deform_attn_backward": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mmsa_msda_fused": [P, P, P, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, P],
-    "mmsa_gemm_split3": [P, P, L, L, P, L, P, L, P, P, L, L, I, F, P, L, L, P, L, L, I, I, I, I, I, F, I, I, I, I, I, I, I, P],
+    "mmsa_gemm_split3": [P, P, L, L, P, L, P, L, P, P, L, L, I, F, P, L, L, P, L, L, I, I, I, I, I, F, I, I, I, I, I, I, I, P, P, P, I, P],
     "mmsa_convnext_mlp_fused": [P, L, L, P, L, P, L, P, P, P, P, L, L, I, I, I, I, P],
-    "mmsa_gemm_next_extras": [P, P, P],
     "mmsa_rowstats_finalize": [P, I, I, I, F, P, P],
     "mmsa_split_planes": [P, L, I, I, I, P, I, P],
     "mmsa_attention": [P, L, P, P, P, L, I, I, I, I, I, I, F, P],
-    "mmsa_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, I, F, I, I, P],
+    "mmsa_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, I, F, I, I, P, P],
     "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_relpos_bias_planes": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, I, L, L, I, I, P],
@@ -55,7 +54,6 @@ SIGNATURES = {
     "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P, P],
     "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
     "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, I, P, P],
-    "mmsa_dwconv7_ln": [P, L, L, P, P, P, P, F, P, L, L, I, I, I, I, I, P],
     "mmsa_dwpair_gate": [P, L, P, P, L, P, L, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],
     "mmsa_im2col_nchw": [P, I, I, I, I, I, I, I, P, I, P],
@@ -67,8 +65,8 @@ SIGNATURES = {
     "mmsa_pool_hw": [P, L, P, L, I, I, I, I, P],
     "mmsa_ca_apply": [P, L, P, L, P, L, P, L, I, I, I, I, P],
     "mmsa_tail_fuse": [P, L, L, P, L, P, P, P, P, L, I, I, I, I, I, I, P],
-    "mmsa_global_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, F, I, I, P],
-    "mmsa_window_attention_planes": [P, L, P, P, P, P, L, I, I, I, I, I, I, F, I, I, P],
+    "mmsa_global_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, F, I, I, P, P],
+    "mmsa_window_attention_planes": [P, L, P, P, P, P, L, I, I, I, I, I, I, F, I, I, P, P],
     "mmsa_nchw_to_planes": [P, L, P, L, I, I, L, P],
     "mmsa_head_fuse": [P, P, I, I, P, I, I, P, I, I, L, P, P, P, L, P, L, I, I, I, I, I, P],
     "mmsa_tokens_to_nchw": [P, L, P, I, L, I, P],

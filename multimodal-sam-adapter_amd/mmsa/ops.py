@@ -13,6 +13,7 @@ ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
 # (flops, start, stop) is appended; bench.py uses this for the roofline of the dominant kernel.
 GEMM_PROFILE = None
 GEMM_MAX_GRID = 0    # > 0: cap on the persistent workgroups of every gemm() launch (mmsa.chains gives each concurrent chain its share of the CUs)
+GEMM_FLAVOUR = 0     # 0: workgroup shape chosen by the library; 4 / 8 force the 128- / 256-row form of the LDS-DMA GEMM (tests, A/B runs; bit-identical results)
 GEMM_SHAPES = None   # optional parallel list of (m, n, k, batch, act, has_resid, outputs) per profiled launch (tools/gemm_shapes.py)
 
 
@@ -159,7 +160,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
          out_planes=None, stride_cp=0, rowstats_out=None, row_norm=None):
     """out / out_planes = beta*resid + colscale*alpha*act(a @ w^T + bias).
     a: fp32 2-D view or activation Planes; w: weight Planes; out: fp32 view and/or out_planes: Planes.
-    LayerNorm fold (include/mmsa.h mmsa_gemm_next_extras): `rowstats_out` [M, N/64, 2] fp32 -- also write per-row strip sums of the stored
+    LayerNorm fold (include/mmsa.h, mmsa_gemm_split3): `rowstats_out` [M, N/64, 2] fp32 -- also write per-row strip sums of the stored
     values; `row_norm` = (mean_rstd [M, 2], colsum [N]) -- out_planes = colscale*alpha*act(rstd_r * (a @ w^T - mean_r * colsum) + bias)."""
     fmt = w.fmt
     if isinstance(a, Planes):
@@ -191,12 +192,11 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
     if prof is not None:
         e0, e1 = _event(), _event()
         lib.call("mmsa_event_record", e0, _stream())
-    if rowstats_out is not None or row_norm is not None:
-        lib.call("mmsa_gemm_next_extras", _chk(rowstats_out), _chk(row_norm[0]) if row_norm else None, _chk(row_norm[1]) if row_norm else None)
     lib.call("mmsa_gemm_split3", pa, pap, lda, stride_a, w.p.data_ptr(), stride_w,
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
-             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, cp_format(out_planes), GEMM_MAX_GRID, _stream())
+             1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, cp_format(out_planes), GEMM_MAX_GRID,
+             _chk(rowstats_out), _chk(row_norm[0]) if row_norm else None, _chk(row_norm[1]) if row_norm else None, GEMM_FLAVOUR, _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
         nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)
@@ -353,12 +353,21 @@ def split_planes_qkv(x2d, d):
     return Planes(torch.cat([qk.p, v.p], 1).contiguous(), x2d.shape[0], 3 * d, 3 * d, FMT_B3, split=2 * d)
 
 
-def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale):
+def _guard(g):
+    """Pointer of an attention logit-guard word (a 1-element fp32 device tensor, include/mmsa.h "Attention logit guard") or None."""
+    if g is None:
+        return None
+    if g.dtype != torch.float32 or g.numel() != 1 or not g.is_cuda:
+        raise RuntimeError("mmsa attention: max_logit must be a 1-element fp32 device tensor")
+    return g.data_ptr()
+
+
+def attention(qkv, qkv_bias, rp, out, b, h, w, heads, hd, ws, scale, max_logit=None):
     if isinstance(qkv, Planes):
         pq, _, _, ldq = qkv.mat("qkv")
         po, _, _, ldo = out.mat("out")
         lib.call("mmsa_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(rp),
-                 po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd), _stream())
+                 po, ldo, b, h, w, heads, hd, ws, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd), _guard(max_logit), _stream())
     else:
         pq, _, _, ldq = _mat(qkv, "qkv")
         po, _, _, ldo = _mat(out, "out")
@@ -389,12 +398,12 @@ def global_relpos_planes(rel_pos_h, rel_pos_w, fmt=FMT_B3):
     return split_planes(m, fmt=fmt)
 
 
-def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale):
+def global_attention(qkv, qkv_bias, relg, out, b, h, w, heads, hd, scale, max_logit=None):
     """Global attention with the rel-pos terms fused (planes in, planes out); W = 64, H <= 64, head_dim 64."""
     pq, _, _, ldq = qkv.mat("qkv")
     po, _, _, ldo = out.mat("out")
     lib.call("mmsa_global_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relg.p, torch.int16), po, ldo,
-             b, h, w, heads, hd, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd, fused=True, rel=relg), _stream())
+             b, h, w, heads, hd, scale, out.fmt, _v_fmt(qkv, qkv_bias, heads * hd, fused=True, rel=relg), _guard(max_logit), _stream())
     return out
 
 
@@ -415,7 +424,7 @@ def window_selector(ws, device, f16=False):
     return _SELECTORS[key]
 
 
-def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
+def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale, max_logit=None):
     """Windowed attention with the rel-pos bias fused (planes in, planes out); head_dim 64, ws <= 14."""
     if not 1 <= ws <= 14:
         raise RuntimeError(f"mmsa.window_attention: window_size {ws} not supported (1..14)")
@@ -424,7 +433,7 @@ def window_attention(qkv, qkv_bias, relp, out, b, h, w, heads, hd, ws, scale):
     vf = _v_fmt(qkv, qkv_bias, heads * hd, fused=True, rel=relp)
     lib.call("mmsa_window_attention_planes", pq, ldq, _chk(qkv_bias.p, torch.int16), _chk(relp.p, torch.int16),
              _chk(window_selector(ws, qkv.p.device, f16=vf == 2), torch.int16), po, ldo, b, h, w, heads, hd, ws, scale, out.fmt,
-             vf, _stream())
+             vf, _guard(max_logit), _stream())
     return out
 
 
@@ -464,19 +473,6 @@ def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=N
     lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, out_planes.fmt if out_planes is not None else FMT_B3,
              b, h, wd, c, k, ACT[act], imgs_per_group, _chk(rowstats_out), _stream())
     return out if out is not None else out_planes
-
-
-def dwconv7_ln(x, w, bias, ln_w, ln_b, eps, out_planes, b, h, wd, imgs_per_group=0):
-    """7x7 depthwise conv + LayerNorm over channels -> interleaved planes (ConvNeXt block front half, one kernel)."""
-    px, _, c, ldx = _mat(x, "x")
-    pp, _, _, ldp = out_planes.mat("y planes")
-    lib.call("mmsa_dwconv7_ln", px, ldx, h * wd * ldx, _chk(w), _chk(bias), _chk(ln_w), _chk(ln_b), eps, pp, ldp, h * wd * ldp,
-             b, h, wd, c, imgs_per_group, _stream())
-    return out_planes
-
-
-def dwconv7_ln_supported(c):
-    return c % 64 == 0 and 64 <= c <= 384
 
 
 def gconv(x, w, bias, out, b, h, wd, groups, cin_g, cout_g, k, act="none"):

@@ -64,6 +64,27 @@ def test_constructor_switches_one_at_a_time(flag):
         assert_close(f, r, what=f"{flag}=False f{i+1} vs oracle")
 
 
+def test_fewer_than_128_token_rows_with_the_layernorm_fold():
+    """a model whose ViT LayerNorms are folded into the qkv / lin1 GEMMs (embed_dim 128, 2 heads of 64) on ONE 128 x 128 image has
+    B * T = 64 token rows -- below what the row-normalising GEMM epilogue takes.  The forward then runs the same folded weights behind a
+    plain LayerNorm pass; both forms (64 rows, and 128 rows at batch 2 through the folded epilogue) match the oracle."""
+    import mmsa
+    kw = dict(CONFIGS["tiny256"]["kwargs"], img_size=128, embed_dim=128, pretrained_size=128)
+    torch.manual_seed(0)
+    orc = R.OracleEncoder(**kw)
+    sd = seeded_state_dict(orc, seed=77)
+    orc.load_state_dict(sd)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **kw))
+    m.load_state_dict(sd, strict=True)
+    x = make_input(dict(kwargs=kw, in_seed=78), batch=2)
+    for b in (1, 2):
+        fs, _ = m(x[:b].to(DEV))
+        assert m._packed["fold_ln"], "this configuration is meant to fold its LayerNorms"
+        ref, _ = orc(x[:b])
+        for i, (f, r) in enumerate(zip(fs, ref)):
+            assert_close(f, r, what=f"fold, batch {b} ({b * 64} token rows) f{i+1} vs oracle")
+
+
 def test_convnext_layernorm_fold_opt_in(golden_dir):
     """`fold_convnext_ln` (opt-in: at ViT-L it costs more error than its 0.17 ms are worth): the ConvNeXt blocks' LayerNorm
     folded into pointwise_conv1 at the stages where the shapes allow it; within the gate against the golden, and not bit-equal to the default."""
@@ -363,7 +384,7 @@ def test_vitl1024_error_budget(golden_dir):
 
 
 def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_dir):
-    """fp16 operands inside the attention kernels only where the block's logits are small (backbone._attn_mode): with the
+    """fp16 operands inside the attention kernels only where the block's logits are small (backbone.check_attention_guard: the kernels' logit guard words, read back after every eager forward): with the
     seeded weights (max |logit| ~ 4) 'auto' picks fp16 in every block and equals the forced 'f16' run bit for bit; with the q / k rows of
     every qkv projection scaled so that the logits are 9 x larger (max ~ 36), 'auto' falls back to bf16 hi/lo operands (the whole block:
     qkv / proj / MLP weights too) and stays within the gate against the oracle on the SAME scaled weights, where the forced fp16 kernels
@@ -412,3 +433,20 @@ def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_di
     worst_f16 = max(rel_l2(f, r) for f, r in zip(fs16, ref))
     assert worst_auto <= 1e-3, f"auto precision at 9 x logits: {worst_auto:.2e}"
     assert worst_f16 > 2.0 * worst_auto, f"forced fp16 {worst_f16:.2e} vs auto {worst_auto:.2e}: the fallback should matter here"
+    # the same decision without the per-forward read-back (attention_guard = "off": what a captured graph does): the forward runs every
+    # block on fp16 attention, the guard words say so afterwards, check_attention_guard() moves the blocks, and the model converges to the
+    # SAME modes and -- bit for bit -- the same outputs as the model that re-routed inside its first forward
+    m3 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m3.load_state_dict(sd)
+    m3.attention_guard = "off"
+    m3(x.to(DEV))
+    assert all(mode == "f16" for mode, _ in m3.attention_modes())
+    assert m3.check_attention_guard(reroute=False) and all(mode == "f16" for mode, _ in m3.attention_modes())
+    for _ in range(len(modes) + 1):
+        if not m3.check_attention_guard():
+            break
+        m3(x.to(DEV))
+    assert [mode for mode, _ in m3.attention_modes()] == modes
+    fs3, _ = m3(x.to(DEV))
+    assert m3.check_attention_guard() == []
+    assert all(torch.equal(a, b) for a, b in zip(fs3, fs))

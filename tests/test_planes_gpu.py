@@ -76,6 +76,28 @@ def test_layernorm_planes_and_patchify(ops):
     assert_close(planes_to_float(pp), ref, tol=5e-5, what="LN patchify planes")
 
 
+def _ref_max_logit(att, xin, hw, live=None):
+    """max |scale * q.k + rel-pos terms| of the oracle's Attention on xin [N, h, w, D] (IE:488-495), rows of `live` == False excluded."""
+    h, w = hw
+    heads = att.num_heads
+    with torch.no_grad():
+        qkv = att.qkv(xin).reshape(xin.shape[0], h * w, 3, heads, -1).permute(2, 0, 3, 1, 4)
+        q, k, _ = qkv.reshape(3, xin.shape[0] * heads, h * w, -1).unbind(0)
+        lg = (q * att.scale) @ k.transpose(-2, -1)
+        lg = R.add_decomposed_rel_pos(lg, q, att.rel_pos_h, att.rel_pos_w, (h, w), (h, w)).abs()
+        if live is not None:   # [N, h*w] bool
+            lg = lg * live[:, None, :, None].expand(-1, heads, -1, -1).reshape(-1, h * w, 1)
+        return lg.max().item()
+
+
+def _live_queries(B, H, W, ws, pad_hw):
+    Hp_, Wp_ = pad_hw
+    live = torch.zeros(Hp_, Wp_, dtype=torch.bool)
+    live[:H, :W] = True
+    live = live.view(Hp_ // ws, ws, Wp_ // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    return live[None].expand(B, -1, -1).reshape(-1, ws * ws)
+
+
 @pytest.mark.parametrize("H,W,heads,hd,ws,table", [
     (16, 16, 2, 32, 14, 27), (20, 20, 2, 64, 14, 27), (64, 64, 2, 64, 14, 27),
     (14, 14, 2, 32, 0, 31), (20, 12, 3, 64, 0, 39), (64, 64, 2, 64, 0, 127)])
@@ -113,10 +135,14 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table, vf):
     ao = ops.alloc_planes(B * T, D, DEV)
     bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
     biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
-    ops.attention(qkv, biasp, rp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
+    gw = torch.zeros(1, device=DEV)
+    ops.attention(qkv, biasp, rp, ao, B, H, W, heads, hd, ws, hd ** -0.5, max_logit=gw)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
     assert_close(out.view(B, H, W, D), ref, what=f"attention planes {H}x{W} ws={ws} vf={vf}")
+    # logit guard word (include/mmsa.h): max |logit| over live queries and existing keys, natural units
+    want = _ref_max_logit(att, xw, (ws, ws), _live_queries(B, H, W, ws, pad_hw)) if ws else _ref_max_logit(att, x, (H, W))
+    assert abs(gw.item() - want) <= 2e-5 * max(want, 1.0), (gw.item(), want)
 
 
 def test_msda_and_dwconv_planes_outputs(ops):
@@ -174,15 +200,15 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
     assert_close(out.view(B, H, W, D), ref, what=f"window attention {H}x{W} ws={ws} vf={vf}")
     with pytest.raises(RuntimeError):
         ops.window_attention(qkv, biasp, relp, ao, B, H, W, heads, hd, 15, hd ** -0.5)
-    if vf:   # the one-barrier kernel (double-buffered hi-only K / V images; opt-in) and the three-barrier one agree bit for bit
-        from mmsa import lib
-        ao3 = ops.alloc_planes(B * T, D, DEV)
-        try:
-            lib.call("mmsa_debug_wattn_flavour", 2)
-            ops.window_attention(qkv, biasp, relp, ao3, B, H, W, heads, hd, ws, hd ** -0.5)
-        finally:
-            lib.call("mmsa_debug_wattn_flavour", 0)
-        assert torch.equal(ao.p, ao3.p), f"window attention kernels differ: {(ao.p != ao3.p).sum().item()} values"
+    # logit guard (include/mmsa.h): the launch folds max |logit| -- scale * q.k + rel-pos terms over live queries and existing keys -- into a device word
+    gw = torch.zeros(1, device=DEV)
+    ao_g = ops.alloc_planes(B * T, D, DEV)
+    ops.window_attention(qkv, biasp, relp, ao_g, B, H, W, heads, hd, ws, hd ** -0.5, max_logit=gw)
+    assert torch.equal(ao_g.p, ao.p), "the guard must not change the result"
+    want = _ref_max_logit(att, xw, (ws, ws), _live_queries(B, H, W, ws, pad_hw))
+    assert abs(gw.item() - want) <= (2e-3 if vf else 2e-5) * max(want, 1.0), (gw.item(), want)
+    ops.window_attention(qkv, biasp, relp, ao_g, B, H, W, heads, hd, ws, hd ** -0.5, max_logit=gw)   # never lowered, and idempotent
+    assert abs(gw.item() - want) <= (2e-3 if vf else 2e-5) * max(want, 1.0)
     if vf:   # qkv, bias and rel-pos planes must agree on the format; the split form belongs to the entry with a rel-pos prepass
         with pytest.raises(RuntimeError):
             ops.window_attention(qkv, ops.split_planes(bias_row, kpad=3 * D), relp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
@@ -286,7 +312,10 @@ def test_global_attention_fused_relpos(ops, H, vf):
     bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
     biasp = ops.split_planes(bias_row, kpad=3 * D, fmt=pf)
     ao = ops.alloc_planes(B * T, D, DEV)
-    ops.global_attention(qkv, biasp, relg, ao, B, H, W, heads, hd, hd ** -0.5)
+    gw = torch.zeros(1, device=DEV)
+    ops.global_attention(qkv, biasp, relg, ao, B, H, W, heads, hd, hd ** -0.5, max_logit=gw)
+    want = _ref_max_logit(att, x, (H, W))
+    assert abs(gw.item() - want) <= (2e-3 if vf else 2e-5) * max(want, 1.0), (gw.item(), want)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
     assert_close(out.view(B, H, W, D), ref, what=f"global attention fused rel-pos {H}x{W} vf={vf}")
@@ -386,30 +415,6 @@ def test_gemm_persistent_tile_stream(ops, M, N, K, mode):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("C,H,W", [(64, 19, 13), (192, 16, 24), (384, 9, 17), (128, 8, 8), (256, 5, 6), (384, 64, 64)])
-def test_dwconv7_layernorm_fused(ops, C, H, W):
-    """ConvNeXt block front half in one kernel (7x7 depthwise conv + channel LayerNorm -> planes), two image groups with their own
-    conv and norm weights, partial edge tiles -- against torch in double."""
-    nimg, ipg = 4, 2
-    x = torch.randn(nimg, H, W, C, generator=g(130))
-    w = torch.randn(2, C, 7, 7, generator=g(131)) * 0.1
-    bias = torch.randn(2, C, generator=g(132)) * 0.1
-    lw, lb = torch.randn(2, C, generator=g(133)), torch.randn(2, C, generator=g(134))
-    ref = []
-    for i in range(nimg):
-        gi = i // ipg
-        y = F.conv2d(x[i].permute(2, 0, 1)[None].double(), w[gi].double()[:, None], bias[gi].double(), padding=3, groups=C)[0].permute(1, 2, 0)
-        ref.append(F.layer_norm(y, (C,), lw[gi].double(), lb[gi].double(), 1e-6))
-    ref = torch.stack(ref).reshape(nimg * H * W, C).float()
-    wt = w.reshape(2, C, 49).permute(0, 2, 1).contiguous().to(DEV)          # tap-major [groups][49][C]
-    outp = ops.alloc_planes(nimg * H * W, C, DEV)
-    ops.dwconv7_ln(x.reshape(nimg * H * W, C).to(DEV), wt, bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, outp, nimg, H, W, imgs_per_group=ipg)
-    assert_close(planes_to_float(outp), ref, tol=2e-5, what=f"dwconv7 + LN fused, C={C}")
-    again = ops.alloc_planes(nimg * H * W, C, DEV)
-    ops.dwconv7_ln(x.reshape(nimg * H * W, C).to(DEV), wt, bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, again, nimg, H, W, imgs_per_group=ipg)
-    assert torch.equal(again.p, outp.p)
-
-
 @pytest.mark.parametrize("M,N,K,mode", [
     (16384, 1536, 384, "Pgelu"),     # ConvNeXt stage-2 pw1 (the shape the 4-wave flavour was built for)
     (9000, 1100, 160, "P"),
@@ -438,7 +443,7 @@ def test_gemm_workgroup_flavours_agree_bitwise(ops, M, N, K, mode):
     got = {}
     try:
         for nw in (8, 4, 8, 4):
-            lib.call("mmsa_debug_gemm_flavour", nw)
+            ops.GEMM_FLAVOUR = nw
             out = torch.full((M, N), float("nan"), device=DEV) if mode[0] == "C" else None
             outp = ops.alloc_planes(M, N, DEV) if mode[0] == "P" else None
             ops.gemm(ap, pl, out, bias=bd, act=act, resid=res, out_planes=outp)
@@ -448,7 +453,7 @@ def test_gemm_workgroup_flavours_agree_bitwise(ops, M, N, K, mode):
                 assert torch.equal(got[nw], o)
             got[nw] = o.clone()
     finally:
-        lib.call("mmsa_debug_gemm_flavour", 0)
+        ops.GEMM_FLAVOUR = 0
     assert torch.equal(got[4], got[8]), "the 4-wave and the 8-wave flavour differ"
 
 
@@ -607,7 +612,7 @@ def test_convnext_block_layernorm_fold(ops):
 
 @pytest.mark.parametrize("fmt_name,act", [("b3", "none"), ("h8", "gelu")])
 def test_gemm_layernorm_fold(ops, fmt_name, act):
-    """LayerNorm folded into a producer / consumer pair of GEMMs (IE:396-421; include/mmsa.h mmsa_gemm_next_extras): the producer writes
+    """LayerNorm folded into a producer / consumer pair of GEMMs (IE:396-421; include/mmsa.h mmsa_gemm_split3): the producer writes
     x = resid + a W0^T + b0 as fp32 AND as planes AND its per-row strip sums; mmsa_rowstats_finalize turns them into (mean, rstd); the
     consumer runs on the raw planes against W o w and normalises in its epilogue -- against LayerNorm + Linear in float64, with a stream
     whose mean is not small against its spread."""

@@ -1,6 +1,10 @@
 """Summarise tools/pmc_mfma.sh into profiles/<tag>_mfma_util.json: per kernel the duration-weighted MfmaUtil (%), the MFMA
 flops the hardware counted (MOPS x 512) and the resulting MFMA TFLOP/s; the same for the GEMM family and the whole step."""
 import collections, csv, glob, json, sys
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "multimodal-sam-adapter_amd"))
+import build as _build   # multimodal-sam-adapter_amd/build.py
+STAMP = {"source_digest": _build.source_digest(), "commit": _os.environ.get("MMSA_COMMIT", "n/a")}   # bench.py attaches a profile only to the sources it was measured on
 tag = sys.argv[1]
 
 
@@ -45,10 +49,10 @@ def fold(keys):
 
 gem = [k for k in per if "gemm" in k or "mlp_fused" in k]   # the contraction kernels
 # the library's own kernels only: the pass also contains torch / hipBLASLt / runtime-copy kernels of the FIRST forward (weight packing,
-# the per-block logit-range measurement of backbone._attn_mode), which are not part of a step
+# nothing else since round 4: the logit range is measured by the attention kernels themselves), which are not part of a step
 FOREIGN = ("Cijk_", "void at::native", "__amd_rocclr", "void rocprim", "void at::cuda")
 own = [k for k in per if not k.startswith(FOREIGN)]
-res = {"note": "eager forwards of bench.py (ViT-L 1024^2 RGB+LiDAR, batch 2, encoder + head; warm-up + one step) under rocprofv3 --pmc; whole_step = this library's kernels only; kernels run serialised "
+res = {**STAMP, "note": "eager forwards of bench.py (ViT-L 1024^2 RGB+LiDAR, batch 2, encoder + head; warm-up + one step) under rocprofv3 --pmc; whole_step = this library's kernels only; kernels run serialised "
                "under counter collection, so ms is the sum of kernel durations, not the step time; util is duration-weighted MfmaUtil; "
                "mfma_flop_counted = 512 x (MOPS_BF16 + MOPS_F16 + MOPS_F8 + MOPS_F32): 3 x the algorithmic flops for bf16 hi/lo contractions, "
                "1 (F16) + 2 (F8, at twice the rate) for h8 contractions",

@@ -1,5 +1,9 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/<tag>_gemm_traffic.json."""
 import collections, csv, glob, json, sys
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "multimodal-sam-adapter_amd"))
+import build as _build   # multimodal-sam-adapter_amd/build.py
+STAMP = {"source_digest": _build.source_digest(), "commit": _os.environ.get("MMSA_COMMIT", "n/a")}   # bench.py attaches a profile only to the sources it was measured on
 tag = sys.argv[1]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -17,7 +21,7 @@ launches = sum(out["FETCH_SIZE"][k]["launches"] for k in gem)
 fetch_kb = sum(out["FETCH_SIZE"][k]["sum_kb"] for k in gem)
 write_kb = sum(out["WRITE_SIZE"].get(k, {"sum_kb": 0})["sum_kb"] for k in gem)
 wl = sum(out["WRITE_SIZE"].get(k, {"launches": 0})["launches"] for k in gem)
-res = {"kernel_family": gem, "launches_counted": launches,
+res = {**STAMP, "kernel_family": gem, "launches_counted": launches,
        "fetch_bytes_per_launch_raw": fetch_kb * 1024 / max(launches, 1),
        "fetch_bytes_per_launch_corrected": 2 * fetch_kb * 1024 / max(launches, 1),
        "write_bytes_per_launch": write_kb * 1024 / max(wl, 1),
@@ -56,7 +60,7 @@ for k in sorted(out["FETCH_SIZE"]):
     gbps = (rd + wr) / ns
     hb[k] = {"launches_per_pass": fl, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "us_per_launch": round(ns / 1e3, 2),
              "GBps": round(gbps, 1), "frac": round(gbps / PEAK, 4), "ms_per_pass": round(ns * fl / 1e6, 3)}
-json.dump({"peak_GBps": PEAK, "note": "per kernel: (2 x FETCH_SIZE + WRITE_SIZE) per launch / average launch duration of the same rocprofv3 passes "
+json.dump({**STAMP, "peak_GBps": PEAK, "note": "per kernel: (2 x FETCH_SIZE + WRITE_SIZE) per launch / average launch duration of the same rocprofv3 passes "
            "(eager launches of one bench step, no HIP graph; FETCH doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted as traffic); frac = GB/s / 8000",
            "kernels": hb}, open(f"profiles/{tag}_hbm_kernels.json", "w"), indent=1)
 print("hbm kernels:", {k[:40]: (v["GBps"], v["us_per_launch"]) for k, v in sorted(hb.items(), key=lambda t: -t[1]["ms_per_pass"])[:12]})
