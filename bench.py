@@ -221,7 +221,16 @@ def main():
     x = make_input(cfg if not STUB else CONFIGS["tiny256"], batch=a.batch, seed=1234 + rank).to(dev)
 
     head = None
-    stub_logits = torch.full((a.batch, 25, 8, 8), float(rank)) if STUB else None
+    # stub, optional uneven sharding: MMSA_BENCH_STUB_GLOBAL_BATCH = G splits G images over the ranks like mmsa.dist.shard_range (the first
+    # G % world ranks hold one more) and gathers through padded shards -- the N = 8 form of the collective with a ragged last step
+    stub_global = int(os.environ["MMSA_BENCH_STUB_GLOBAL_BATCH"]) if STUB and os.environ.get("MMSA_BENCH_STUB_GLOBAL_BATCH") else None
+    if stub_global is not None:
+        from mmsa.dist import shard_range
+        lo_, hi_ = shard_range(stub_global, rank, world)
+        stub_local = hi_ - lo_
+    else:
+        stub_local = a.batch
+    stub_logits = torch.full((stub_local, 25, 8, 8), float(rank)) if STUB else None
     if not a.no_head:
         hcfg = HEAD_CONFIGS["head_vitl"]
         hkw = dict(hcfg["kwargs"])
@@ -333,6 +342,13 @@ def main():
         if t_one < t_ch:
             chains, nch = None, 1
             replay, local_out, graphed, graph_feats = one_replay, one_out, one_graphed, one_feats
+    elif STUB and use_dist:
+        # the chain probe's collective decision with stand-in timings: every rank must end up with the same (max-over-ranks) pair
+        tt = torch.tensor([5.0 + rank, 50.0 - rank], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        chain_probe = {"chains_ms": float(tt[0]), "one_chain_ms": float(tt[1])}
+        replay, local_out, graphed = capture(local_step)
+        graph_feats = None
     elif chains is None:
         replay, local_out, graphed = capture(local_step)
         graph_feats = feats[0]                 # the four output maps the captured graph writes (fixed addresses)
@@ -361,10 +377,10 @@ def main():
     def run():
         out_ = replay()                     # chains: both sub-batch chains of the step, joined into this stream (a step ends before the next starts)
         if (head is not None or STUB) and use_dist:   # the pipeline's only exchange step; outside the graph (RCCL owns its stream)
-            gathered[0] = allgather_logits(out_ if STUB else local_out)
+            gathered[0] = allgather_logits(out_ if STUB else local_out, stub_global)
 
     dt = timed(run)
-    imgs = a.batch * world * a.steps
+    imgs = (stub_global if stub_global is not None else a.batch * world) * a.steps
     value = imgs / dt
     replay_ms = None
     if not STUB:   # median of >= 20 iterations, each between its own events (untimed by the contract's clock)
@@ -388,9 +404,15 @@ def main():
         if still:
             raise SystemExit(f"[bench] attention blocks {still} ran fp16 attention beyond its logit range inside the timed region")
     if (head is not None or STUB) and use_dist and rank == 0:
-        assert gathered[0].shape[0] == world * a.batch
-        if STUB:    # every rank's shard arrived, in rank order
-            assert [float(gathered[0][r * a.batch, 0, 0, 0]) for r in range(world)] == [float(r) for r in range(world)]
+        if stub_global is not None:   # ragged shards: rank r's images sit at shard_range(G, r) and carry its rank
+            assert gathered[0].shape[0] == stub_global
+            for r in range(world):
+                lo_, hi_ = shard_range(stub_global, r, world)
+                assert all(float(gathered[0][i, 0, 0, 0]) == float(r) for i in range(lo_, hi_)), f"rank {r}'s shard is not where it belongs"
+        else:
+            assert gathered[0].shape[0] == world * a.batch
+            if STUB:    # every rank's shard arrived, in rank order
+                assert [float(gathered[0][r * a.batch, 0, 0, 0]) for r in range(world)] == [float(r) for r in range(world)]
 
     # ---- what was timed is what is verified (untimed; every rank)
     verified = None
@@ -570,7 +592,7 @@ def main():
                        "stage": "encoder forward only" if head is None else
                                 "encoder forward + SegformerHead logits [B,25,H/4,W/4] + all-gather of logits across ranks",
                        "weights": "default init" if a.default_init else "seeded live generator (tests/weights.py), every parameter / buffer non-trivial",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graphed),
+                       "global_batch": stub_global if stub_global is not None else a.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graphed),
                        "chains_per_gpu": nch, "chains_probe_ms": chain_probe, "attention_blocks": attn_blocks,
                        "collective": ("one RCCL all_gather_into_tensor of the logits per step" if (head is not None and use_dist)
                                       else "none (single rank)" if head is not None else "none (encoder only)")},

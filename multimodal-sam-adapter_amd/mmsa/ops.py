@@ -3,6 +3,8 @@ the current HIP stream and shape bookkeeping.  No arithmetic is done by torch on
 falls back to torch when the library fails -- errors propagate as RuntimeError."""
 import ctypes
 
+import os
+
 import torch
 
 from . import lib
@@ -13,7 +15,7 @@ ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
 # (flops, start, stop) is appended; bench.py uses this for the roofline of the dominant kernel.
 GEMM_PROFILE = None
 GEMM_MAX_GRID = 0    # > 0: cap on the persistent workgroups of every gemm() launch (mmsa.chains gives each concurrent chain its share of the CUs)
-GEMM_FLAVOUR = 0     # 0: workgroup shape chosen by the library; 4 / 8 force the 128- / 256-row form of the LDS-DMA GEMM (tests, A/B runs; bit-identical results)
+GEMM_FLAVOUR = int(os.environ.get("MMSA_GEMM_FLAVOUR", "0"))     # 0: workgroup shape chosen by the library; 4 / 8 force the 128- / 256-row form of the LDS-DMA GEMM (tests, A/B runs; bit-identical results)
 GEMM_SHAPES = None   # optional parallel list of (m, n, k, batch, act, has_resid, outputs) per profiled launch (tools/gemm_shapes.py)
 
 

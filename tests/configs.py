@@ -43,6 +43,12 @@ CONFIGS = {
                           batch=1, seed=21, in_seed=22),
     "vitb512": dict(kwargs=_VITB, batch=1, seed=4, in_seed=8),
     "vitl1024": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9),
+    # the second image of the benchmarked batch (image 1 was covered by graph == eager and batch invariance only): same weights,
+    # another seeded input, its own reference probes
+    "vitl1024_b": dict(kwargs=_VITL, batch=1, seed=5, in_seed=39),
+    # peaky attention at ViT-L: the seeded weights with the q / k rows of every qkv projection x 3 (tests/weights.py
+    # peaky_attention): max |logit| ~ 30-40, where fp16 attention operands leave the gate and the blocks must run bf16 hi/lo
+    "vitl1024_peaky": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9, qk_scale=3.0),
     "vith1024": dict(kwargs=_VITH, batch=1, seed=17, in_seed=18),
     "vitl800": dict(kwargs=_VITL800, batch=1, seed=19, in_seed=20, type="SAMAdapterbimodalMixModNewInTwinConvNEWwithcp"),
 }

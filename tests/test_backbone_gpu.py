@@ -151,6 +151,47 @@ def test_vitl1024_probes(golden_dir):
         assert abs(f.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-3 * st[3]
 
 
+def _check_probes(f_img, g, i, what):
+    pi = probe_index(f_img.numel(), 2048, seed=100 + i)
+    assert_close(f_img.flatten()[pi.to(DEV)].cpu(), torch.from_numpy(g[f"f{i+1}_probe"]), what=what)
+    st = g[f"f{i+1}_stats"]
+    assert abs(f_img.double().pow(2).sum().sqrt().item() - st[3]) <= 1e-3 * st[3], what + " (norm)"
+
+
+def test_vitl1024_both_images_of_the_benchmarked_batch(golden_dir):
+    """The benchmarked step is a batch of TWO images: each image of one batch-2 forward against its own reference probes and norms
+    (model_vitl1024.npz: image 0's input, model_vitl1024_b.npz: a second seeded input through the same reference weights)."""
+    cfg, orc, m = _build("vitl1024")
+    del orc
+    x = torch.cat([make_input(CONFIGS["vitl1024"]), make_input(CONFIGS["vitl1024_b"])], 0)
+    fs, _ = m(x.to(DEV))
+    for b, name in enumerate(("vitl1024", "vitl1024_b")):
+        g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
+        for i, f in enumerate(fs):
+            _check_probes(f[b], g, i, f"{name} (image {b} of a batch of 2) f{i+1} probes")
+
+
+def test_vitl1024_peaky_attention_against_the_reference(golden_dir):
+    """the fp16 -> bf16 hi/lo fallback pinned against the REFERENCE at ViT-L.  Weights = the seeded generator with the
+    q / k rows of every qkv projection x 3 (max |logit| ~ 30-40); the golden probes come from the imported reference on those weights.  The
+    first forward starts every block on fp16 attention, the kernels' guard words report the logits, the blocks move to bf16 hi/lo operands
+    (attention and block GEMMs) and the forward is repeated before it returns: the outputs hold the 1e-3 gate."""
+    import mmsa
+    from tests.weights import peaky_attention
+    cfg = CONFIGS["vitl1024_peaky"]
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    sd = peaky_attention(seeded_state_dict(m, seed=cfg["seed"]), cfg["kwargs"]["embed_dim"], cfg["qk_scale"])
+    m.load_state_dict(sd, strict=True)
+    g = np.load(os.path.join(golden_dir, "model_vitl1024_peaky.npz"))
+    fs, _ = m(make_input(cfg).to(DEV))
+    modes = m.attention_modes()
+    nb3 = sum(1 for mode, _ in modes if mode == "b3")
+    assert nb3 >= len(modes) // 2 and max(lg for _, lg in modes) > 2 * m.ATTN_F16_MAX_LOGIT, modes
+    assert all(lg <= m.ATTN_F16_MAX_LOGIT for mode, lg in modes if mode == "f16"), modes
+    for i, f in enumerate(fs):
+        _check_probes(f[0], g, i, f"vitl1024 peaky attention ({nb3} of {len(modes)} blocks on bf16 hi/lo) f{i+1} probes")
+
+
 def test_rejects_wrong_inputs():
     cfg, orc, m = _build("tiny224")
     with pytest.raises(RuntimeError):

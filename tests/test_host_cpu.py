@@ -202,6 +202,20 @@ def test_bench_rank_body_gloo_world2():
     assert line["roofline"] is None and line["cpu_baseline"] is None and line["verified"] is None
 
 
+def test_bench_rank_body_gloo_world8_with_ragged_shards():
+    """The same control path at the width the driver's scaling run uses: `--gpus 8` -> eight ranks on gloo, a global batch of 13 images
+    split 2,2,2,2,2,1,1,1 (mmsa.dist.shard_range) and gathered through padded shards every step, the chain probe's all-reduce (every rank
+    must take the max-over-ranks pair), max-over-ranks timing (rank 7's 80 ms stand-in sets it) and the N = 8 JSON line."""
+    import json
+    r = _run_bench_stub({"MMSA_BENCH_STUB_GLOBAL_BATCH": "13", "OMP_NUM_THREADS": "1"}, args=("--gpus", "8", "--steps", "2", "--warmup", "1"), timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["config"]["parallelism"] == "dp8" and line["config"]["global_batch"] == 13
+    assert line["chains_probe_ms"] == {"chains_ms": 12.0, "one_chain_ms": 50.0}
+    assert 80.0 <= line["ms_per_step"] < 400.0
+    assert abs(line["value"] - 13 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-2 * line["value"]
+
+
 def test_bench_parent_stops_the_job_when_a_rank_dies():
     """A rank that exits at start-up must not leave the parent waiting for rank 0's rendezvous timeout."""
     import time

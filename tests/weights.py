@@ -57,3 +57,16 @@ def seeded_state_dict(model, seed=0):
             out[k] = rn(0.1)
         out[k] = out[k].to(v.dtype)
     return out
+
+
+def peaky_attention(sd, embed_dim, factor):
+    """`sd` with the q and k rows of every attn.qkv projection (weight and bias, the first 2 * embed_dim rows: IE:488 memory order) scaled
+    by `factor`: attention logits factor^2 times larger, everything else unchanged -- the fixtures with peaky attention (released SAM
+    checkpoints are peakier than the seeded generator above) are captured from the reference with these weights."""
+    out = dict(sd)
+    for k in sd:
+        if k.endswith("attn.qkv.weight") or k.endswith("attn.qkv.bias"):
+            v = sd[k].clone()
+            v[:2 * embed_dim] *= factor
+            out[k] = v
+    return out

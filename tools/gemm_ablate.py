@@ -1,6 +1,8 @@
 """Per-shape ablation of the split3 GEMM on the model's own launch configurations (batch, activation, output kind, residual):
-python tools/gemm_ablate.py            -> one table per MMSA_GEMM_DEBUG mode (each mode in its own process: the knob is read once)
-modes: 0 = full kernel, 10 = epilogue without its global stores, 1 = no global stores + no epilogue arithmetic, 2 = no epilogue."""
+python tools/gemm_ablate.py            -> one table per MMSA_GEMM_DEBUG mode (each mode in its own process)
+modes: 0 = full kernel, 10 = epilogue without its global stores, 1 = no global stores + no epilogue arithmetic, 2 = no epilogue.
+The release library has no such knob: the workers load ab/libmmsa_knobs.so, a debug-knob build of gemm_v2.hip (tools/build_variant.sh
+... -DMMSA_DEBUG_KNOBS, built here on first use; MMSA_LIB points mmsa.lib at it)."""
 import os
 import subprocess
 import sys
@@ -63,8 +65,11 @@ if __name__ == "__main__":
         sys.exit(0)
     print("mode      " + " ".join(f"{s[0]:>8s}" for s in SHAPES))
     flops = [2.0 * s[1] * s[2] * s[3] * s[4] for s in SHAPES]
+    knobs = os.path.join(ROOT, "ab", "libmmsa_knobs.so")
+    if not os.path.exists(knobs) or os.path.getmtime(knobs) < os.path.getmtime(os.path.join(ROOT, "multimodal-sam-adapter_amd", "csrc", "gemm_v2.hip")):
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "ab/libmmsa_knobs.so", "gemm_v2.hip", "-DMMSA_DEBUG_KNOBS"], check=True)
     for mode in (sys.argv[1:] or ["0", "10", "1", "2"]):
-        env = dict(os.environ, MMSA_GEMM_DEBUG=mode)
+        env = dict(os.environ, MMSA_GEMM_DEBUG=mode, MMSA_LIB=knobs)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=env, capture_output=True, text=True)
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]
         print(f"dbg {mode:>2s} us " + line)

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
 
 import ref_import  # noqa: E402
-from tests.weights import seeded_state_dict  # noqa: E402
+from tests.weights import peaky_attention, seeded_state_dict  # noqa: E402
 from tests.configs import CONFIGS, HEAD_CONFIGS, make_head_inputs, make_input, weights_checksum, probe_index  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -115,6 +115,8 @@ def gen_model(name, full):
     keys = list(ref.state_dict().keys())
     shapes = [list(v.shape) for v in ref.state_dict().values()]
     sd = seeded_state_dict(ref, seed=cfg["seed"])
+    if cfg.get("qk_scale"):
+        sd = peaky_attention(sd, cfg["kwargs"]["embed_dim"], cfg["qk_scale"])
     ref.load_state_dict(sd)
     x = make_input(cfg)
     with torch.no_grad():
@@ -319,6 +321,8 @@ def main():
     if a.big:
         gen_model("vitb512", full=False)
         gen_model("vitl1024", full=False)
+        gen_model("vitl1024_b", full=False)
+        gen_model("vitl1024_peaky", full=False)
 
 
 if __name__ == "__main__":

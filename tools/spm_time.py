@@ -7,7 +7,6 @@ from tests.configs import CONFIGS, make_input
 cfg = CONFIGS["vitl1024"]
 m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
 x = make_input(cfg, batch=2).cuda()
-m.fuse_dwconv_ln = os.environ.get("MMSA_FUSE_DWLN") == "1"
 for _ in range(2):
     m(x)
 torch.cuda.synchronize()

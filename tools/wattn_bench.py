@@ -15,21 +15,16 @@ qkv = ops.split_planes(x, fmt=pf)
 bias = ops.split_planes(brow, kpad=3 * D, fmt=pf)
 relp = ops.window_relpos_planes(torch.randn(27, hd, device=dev) * 0.3, torch.randn(27, hd, device=dev) * 0.3, ws, fmt=pf)
 out = ops.alloc_planes(B * H * W, D, dev)
-from mmsa import lib
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 50
-best = {}
-for rnd in range(3):          # the two persistent kernels interleaved in one process (flavour 1 = three barriers per item, 2 = one)
-    for fl in ((2, 1) if vf else (0,)):
-        lib.call("mmsa_debug_wattn_flavour", fl)
-        for _ in range(3):
-            ops.window_attention(qkv, bias, relp, out, B, H, W, heads, hd, ws, hd ** -0.5)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            ops.window_attention(qkv, bias, relp, out, B, H, W, heads, hd, ws, hd ** -0.5)
-        e1.record(); torch.cuda.synchronize()
-        best[fl] = min(best.get(fl, 1e9), e0.elapsed_time(e1) / n * 1e3)
-lib.call("mmsa_debug_wattn_flavour", 0)
-print(f"wattn B={B} vf={vf}: " + ", ".join(f"{'one barrier' if fl == 2 else 'three barriers'} {us:.1f} us" for fl, us in best.items())
-      + f" per launch (debug={os.environ.get('MMSA_WATTN_DEBUG', '0')})")
+best = 1e9
+for rnd in range(3):
+    for _ in range(3):
+        ops.window_attention(qkv, bias, relp, out, B, H, W, heads, hd, ws, hd ** -0.5)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        ops.window_attention(qkv, bias, relp, out, B, H, W, heads, hd, ws, hd ** -0.5)
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) / n * 1e3)
+print(f"wattn B={B} vf={vf}: {best:.1f} us per launch")
