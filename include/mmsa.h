@@ -27,7 +27,15 @@
  *                   one block-scaled fp8 MFMA at twice the rate: same precision class, 2/3 of the matrix-pipe time): 32 fp16 hi
  *                   values, then four 16-byte chunks, chunk g = 8 bytes e5m2(lo * 2^11) + 8 bytes e5m2(hi) of k = 8g..8g+7 for an
  *                   ACTIVATION (A operand) row, the two halves swapped for a WEIGHT (W operand) row.  |x| is clamped to 57344.
- *    `mmsa_split_planes` converts fp32; producer kernels emit either format directly (their `*_fmt` argument).
+ *      MMSA_FMT_H8C the h8 arithmetic on 3 bytes per element (round 4), laid out for the LDS-DMA operand stream of the GEMM: q(hi) is not
+ *                   stored (the e5m2 image of an fp16 value is its top byte; the GEMM takes it in registers) and rows are stored in PAIRS --
+ *                   pair j of a [rows, K] matrix (K padded to a multiple of 64, rows to even) occupies `ld` uint16 (>= 3 K):
+ *                   [row 2j: K fp16 hi][row 2j+1: K fp16 hi][K / 64 lines of 128 bytes: chunk c = {row 2j: 64 lo bytes | row 2j+1: 64 lo bytes}],
+ *                   a row's 64 lo bytes of a chunk = 4 groups g of 16 bytes = e5m2(lo * 2^11) of k = 64c + 8g .. +7, then of k = 64c + 32 + 8g .. +7.
+ *                   Every `ld*` of h8c planes is the row-PAIR stride; activations and weights share the layout.  1.5 cache lines per row and
+ *                   64 k-values where MMSA_FMT_H8 has 2: the GEMM's L2 -> LDS stream is what bounds its k loop (csrc/gemm_h8c.hip).
+ *    `mmsa_split_planes` converts fp32; producer kernels emit the format of their `*_fmt` argument (h8c: mmsa_gemm_split3, mmsa_layernorm_rows,
+ *    the three attention entries, mmsa_msda_fused, mmsa_split_planes).
  */
 #ifndef MMSA_H
 #define MMSA_H
@@ -56,7 +64,7 @@ enum { MMSA_ACT_NONE = 0, MMSA_ACT_GELU = 1, MMSA_ACT_RELU = 2, MMSA_ACT_RELU6 =
 enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
 
 /* operand-plane formats (see Conventions) */
-enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
+enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2 };
 
 /* --- reference native ops -----------------------------------------------------------------------------------
  * ms_deform_attn_forward (vision.cpp:14 -> ms_deform_attn.h:20-39 -> cuda/ms_deform_attn_cuda.cu:20-80).
@@ -100,7 +108,8 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * A is EITHER fp32 (`A`, split to hi/lo while staged) OR interleaved activation planes (`Ap`, written by the
  * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
  * The result goes to fp32 `C`, to planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both.
- * fmt = format of the A and W planes (MMSA_FMT_H8: A must come as planes, K % 64 == 0); cp_fmt = format written to `Cp`:
+ * fmt = format of the A and W planes (MMSA_FMT_H8 / MMSA_FMT_H8C: A must come as planes, K % 64 == 0; H8C also M >= 128; lda / ldcp of h8c planes =
+ * row-pair strides >= 3 K / 3 pad64(N)); cp_fmt = format written to `Cp`:
  * bits 0..7 MMSA_FMT_*, bits 8.. = split / 32 -- columns >= split (a multiple of 32; 0 = none) are written as MMSA_FMT_H8 planes
  * whatever the base format (the qkv projection: q and k bf16 hi/lo, v with an fp16 hi part for the attention kernels' v_fmt = 1).
  * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
@@ -133,7 +142,7 @@ int mmsa_convnext_mlp_fused(const uint16_t* Ap, long lda, long strideA, const ui
                             int M, int C, int batch, int max_grid, mmsa_stream_t stream);
 
 /* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
- * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows. */
+ * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows; 3: h8c planes [ceil(rows / 2), 3*cols_pad] (cols_pad % 64 == 0; activations and weights). */
 int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes, int kind,
                       mmsa_stream_t stream);
 

@@ -496,11 +496,11 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
     const int tq = tq_sub[sub];
     if constexpr (PL) {
       // lanes G / G ^ 1 of a query row (lane ^ 16) hold 8 consecutive channels: whole-line stores through the pair exchange (common.h)
-      unsigned short* orow = a.op + ((long)b * T + (tq >= 0 ? tq : 0)) * a.ldo;
+      const long orow = (long)b * T + (tq >= 0 ? tq : 0);
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        store_planes8_pair<16>(orow, head * HD + 16 * d + 8 * (G >> 1),
-                               make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv), a.ofmt, G & 1, tq >= 0);
+        store_planes8_pair_any<16>(a.op, a.ldo, orow, MMSA_PAD64(a.D), head * HD + 16 * d + 8 * (G >> 1),
+                                   make_float4(o[sub][d][0] * inv, o[sub][d][1] * inv, o[sub][d][2] * inv, o[sub][d][3] * inv), a.ofmt, G & 1, tq >= 0);
     } else if (tq >= 0) {
       const long oo = ((long)b * T + tq) * a.ldo + head * HD + 4 * G;
 #pragma unroll
@@ -515,7 +515,7 @@ static int attention_launch(AttnArgs a, int B, int H, int W, int heads, int head
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0 && window_size >= 0, "attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64 || head_dim == 32 || head_dim == 96, "attention: head_dim %d not supported (32, 64 or 96; other widths are zero-padded per head by the caller, e.g. ViT-H's 80 -> 96)", head_dim);
   const int D = heads * head_dim;
-  MMSA_CHECK_ARG(a.ldq >= (planes ? 6L : 3L) * D && (a.ldq & 7) == 0 && a.ldo >= (planes ? 2L : 1L) * D && (a.ldo & 3) == 0,
+  MMSA_CHECK_ARG(a.ldq >= (planes ? 6L : 3L) * D && (a.ldq & 7) == 0 && a.ldo >= (planes ? (a.ofmt == MMSA_FMT_H8C ? 3L * MMSA_PAD64(D) : 2L * D) : 1L * D) && (a.ldo & 3) == 0,
                  "attention: bad leading dimensions");
   a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
   int ngroups;
@@ -595,7 +595,7 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, cons
                                      int heads, int head_dim, int window_size, float scale, int out_fmt, int v_fmt, float* max_abs_logit,
                                      hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && rp && out_p, "attention_planes: null pointer");
-  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "attention_planes: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG((heads * head_dim) % 32 == 0, "attention_planes: embed dim must be a multiple of 32");
@@ -611,7 +611,7 @@ extern "C" int mmsa_global_attention_planes(const unsigned short* qkv_p, long ld
                                             int heads, int head_dim, float scale, int out_fmt, int v_fmt, float* max_abs_logit,
                                             hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && relpos_planes && out_p, "global_attention_planes: null pointer");
-  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "global_attention_planes: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "global_attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)relpos_planes) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "global_attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG(head_dim == 64 && W == 64 && H <= 64 && (H % 4) == 0, "global_attention_planes: needs head_dim 64 and a W = 64, H <= 64 (multiple of 4) grid");

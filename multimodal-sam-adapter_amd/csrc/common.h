@@ -121,7 +121,7 @@ __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k
 // for ACTIVATIONS (A operand); WEIGHTS store the chunk as 8 q(hi) bytes + 8 lo bytes, so that for both operands the lane's 32
 // operand bytes of the fp8 MFMA are just the chunks of two consecutive k-blocks, and byte p of A always meets byte p of W with
 // the roles (lo, q(hi)) crossed.  Values are clamped to +-57344 (the largest e5m2 / a finite fp16) before the split.
-enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1 };
+enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2 };
 // Output-plane format argument of the GEMM (`cp_fmt`): bits 0..7 = format of the columns below the split, bits 8.. = split / 32;
 // columns >= split (a multiple of 32, 0 = no split) are written as MMSA_FMT_H8.  The qkv projection writes q and k as bf16 hi/lo
 // planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: DESIGN.md 4.1).
@@ -225,6 +225,71 @@ __device__ __forceinline__ void store_planes1(unsigned short* row, int c, float 
     row[ilv(c) + 32] = ll;
   }
 }
+
+// ---- "h8c" planes (round 4): the h8 arithmetic on 3 bytes per element instead of 4, laid out for the LDS-DMA operand stream of
+// gemm_h8c.hip (an LDS-DMA instruction costs per 128-byte LINE it touches -- profiles/r03_dma_lanes_microbench.txt -- so the win is in
+// lines, not in masked bytes).  q(hi) is not stored: e5m2 has fp16's exponent width, so the e5m2 image of an fp16 value is its top
+// byte (truncation instead of round-to-nearest: the cross terms carry 2^-12 of a product, their operands' 3 significant bits cost
+// 2^-15 either way), taken in registers with v_perm_b32.  A [rows, K] matrix (K % 64 == 0; rows padded to even) is stored by ROW PAIRS;
+// pair j (rows 2j, 2j+1) occupies `ld` uint16 (>= 3 K):
+//     [row 2j: K fp16 hi][row 2j+1: K fp16 hi][K / 64 lines of 128 B: chunk c = {row 2j: 64 lo bytes | row 2j+1: 64 lo bytes}]
+// and a row's 64 lo bytes of chunk c (k = 64 c .. 64 c + 63) are 4 groups g of 16 B = [e5m2(lo * 2^11) of k = 64c + 8g .. + 7 | of k = 64c + 32 + 8g .. + 7]:
+// the 16 bytes a lane of the fp8 MFMA needs from the two k-tiles of a chunk, contiguous.  Every 64-k chunk of a row is one whole line
+// of hi values, every chunk of a row pair one whole line of lo bytes: 1.5 lines per row and chunk where the h8 line format has 2.
+// Activations and weights use the SAME layout (the (lo, q(hi)) role swap of the h8 line format happens in registers).
+struct H8cRow {
+  unsigned short* hi;   // this row's K fp16 hi values
+  unsigned char* lo;    // this row's 64 lo bytes of chunk 0; chunk c: + 128 c
+};
+__device__ __forceinline__ H8cRow h8c_row(unsigned short* base, long ld_pair, long row, int kpad) {
+  unsigned short* pb = base + (row >> 1) * ld_pair;
+  H8cRow r;
+  r.hi = pb + (row & 1) * kpad;
+  r.lo = reinterpret_cast<unsigned char*>(pb + 2 * kpad) + (row & 1) * 64;
+  return r;
+}
+// byte offset, from H8cRow::lo, of the lo byte of column k
+__host__ __device__ __forceinline__ int h8c_lo_off(int k) { return ((k >> 6) << 7) + (((k & 31) >> 3) << 4) + (((k >> 5) & 1) << 3) + (k & 7); }
+// 4 consecutive columns c .. c+3 (c % 4 == 0) of one row
+__device__ __forceinline__ void h8c_store4(const H8cRow r, int c, const float4 v) {
+  uint2 hi; unsigned lo8, qh8;
+  h8_split4(v, hi, lo8, qh8);
+  *reinterpret_cast<uint2*>(r.hi + c) = hi;
+  *reinterpret_cast<unsigned*>(r.lo + h8c_lo_off(c)) = lo8;
+}
+// a PAIR of lanes (lane ^ XOR) holding columns c8 .. c8+3 (`odd == false`) and c8+4 .. c8+7 (`odd == true`), c8 % 8 == 0: the even lane
+// stores the 16-byte hi chunk, the odd lane the 8 lo bytes.  Both lanes of a pair must be active and agree on `do_store`.
+template <int XOR>
+__device__ __forceinline__ void h8c_store8_pair(const H8cRow r, int c8, const float4 v, bool odd, bool do_store) {
+  uint2 hi; unsigned lo8, qh8;
+  h8_split4(v, hi, lo8, qh8);
+  const uint2 snd = odd ? hi : make_uint2(lo8, 0u);
+  uint2 rcv;
+  rcv.x = __shfl_xor(snd.x, XOR, 64);
+  rcv.y = __shfl_xor(snd.y, XOR, 64);
+  if (!do_store) return;
+  if (!odd) *reinterpret_cast<uint4*>(r.hi + c8) = make_uint4(hi.x, hi.y, rcv.x, rcv.y);
+  else *reinterpret_cast<uint2*>(r.lo + h8c_lo_off(c8)) = make_uint2(rcv.x, lo8);
+}
+// one element (ragged edges; rare)
+__device__ __forceinline__ void h8c_store1(const H8cRow r, int c, float x) {
+  unsigned hi, lo8 = 0u, qh8 = 0u;
+  h8_split2<false>(x, 0.f, hi, lo8, qh8);
+  r.hi[c] = (unsigned short)(hi & 0xFFFFu);
+  r.lo[h8c_lo_off(c)] = (unsigned char)(lo8 & 0xFFu);
+}
+// Plane-output helpers over all three formats: `base` / `ld` as the entry points receive them (h8c: ld = row-PAIR stride), kpad = columns
+// padded to 64 (h8c only).
+template <int XOR>
+__device__ __forceinline__ void store_planes8_pair_any(unsigned short* base, long ld, long row, int kpad, int c8, const float4 v, int fmt, bool odd, bool do_store) {
+  if (fmt == MMSA_FMT_H8C) h8c_store8_pair<XOR>(h8c_row(base, ld, row, kpad), c8, v, odd, do_store);
+  else store_planes8_pair<XOR>(base + row * ld, c8, v, fmt, odd, do_store);
+}
+__device__ __forceinline__ void store_planes4_any(unsigned short* base, long ld, long row, int kpad, int c, const float4 v, int fmt) {
+  if (fmt == MMSA_FMT_H8C) h8c_store4(h8c_row(base, ld, row, kpad), c, v);
+  else store_planes4(base + row * ld, c, v, fmt);
+}
+#define MMSA_PAD64(x_) (((x_) + 63) & ~63)
 
 // activation codes shared by the GEMM epilogue and the conv kernels
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_HSWISH = 4, ACT_SIGMOID = 5 };

@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
   const int oy = strip >> 1, ox0 = (strip & 1) * 4;
   const int c = c0 + cv * 4;
   if (cv * 4 >= cvalid) return;
-  float4 acc[4];
+  mmsa_f2 acc01[4], acc23[4];
   const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) acc[p] = bv;
+  for (int p = 0; p < 4; ++p) { acc01[p] = (mmsa_f2){bv.x, bv.y}; acc23[p] = (mmsa_f2){bv.z, bv.w}; }
   // The 49 tap weights come from global memory (L1 / L2 hits), one kernel row = 7 vectors at a time (all 49 would cost occupancy).  Loaded
   // inside the row's loop they were seven dependent load batches per workgroup; now row kh + 1 is requested before row kh is computed
   // (two register sets, the row loop unrolled by two).
@@ -109,10 +109,12 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
     float4 in[10];                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < 10; ++i) in[i] = *reinterpret_cast<const float4*>(tile + ((oy + (kh_)) * TW + ox0 + i) * CB + cv * 4); \
     _Pragma("unroll") for (int kw = 0; kw < 7; ++kw) {                                                                            \
-      const float4 f = f_[kw];                                                                                                    \
-      _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                             \
-        acc[p].x += in[p + kw].x * f.x; acc[p].y += in[p + kw].y * f.y;                                                           \
-        acc[p].z += in[p + kw].z * f.z; acc[p].w += in[p + kw].w * f.w;                                                           \
+      const mmsa_f2 f01 = {f_[kw].x, f_[kw].y}, f23 = {f_[kw].z, f_[kw].w};                                                       \
+      _Pragma("unroll") for (int p = 0; p < 4; ++p) {   /* explicit packed fp32 (v_pk_fma_f32, plain register pairs): the 784 FMAs */ \
+        /* of a lane are this kernel's longest stream, 3136 issue cycles per tile as scalar instructions against ~1100 of LDS reads */ \
+        const mmsa_f2 i01 = {in[p + kw].x, in[p + kw].y}, i23 = {in[p + kw].z, in[p + kw].w};                                     \
+        acc01[p] = __builtin_elementwise_fma(i01, f01, acc01[p]);                                                                 \
+        acc23[p] = __builtin_elementwise_fma(i23, f23, acc23[p]);                                                                 \
       }                                                                                                                           \
     }                                                                                                                             \
   }
@@ -133,6 +135,9 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
 #undef DW7_ROW
   const int gy = ty0 + oy;
   if (gy >= H) return;
+  float4 acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) acc[p] = make_float4(acc01[p].x, acc01[p].y, acc23[p].x, acc23[p].y);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int gx = tx0 + ox0 + p;

@@ -343,9 +343,10 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   MMSA_CHECK_ARG(!(rs_out && rn_mr), "gemm_split3: a GEMM either writes row statistics or normalises by them");
   const bool extras = rs_out || rn_mr;
   MMSA_CHECK_ARG(!extras || (ap && M >= 128), "gemm_split3: row statistics / row normalisation need activation planes and M >= 128");
-  MMSA_CHECK_ARG((fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_H8) && cp_fmt >= 0 && (MMSA_CP_BASE(cp_fmt) == MMSA_FMT_B3 || MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8), "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
-  MMSA_CHECK_ARG(MMSA_CP_SPLIT(cp_fmt) == 0 || (out_mode == 0 && MMSA_CP_SPLIT(cp_fmt) < N), "gemm_split3: the output-format split %d needs a plain [M, N] planes output with N=%d beyond it", MMSA_CP_SPLIT(cp_fmt), N);
-  MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 operands need A planes and K %% 64 == 0 (K=%d)", K);
+  MMSA_CHECK_ARG(fmt >= MMSA_FMT_B3 && fmt <= MMSA_FMT_H8C && cp_fmt >= 0 && MMSA_CP_BASE(cp_fmt) >= MMSA_FMT_B3 && MMSA_CP_BASE(cp_fmt) <= MMSA_FMT_H8C, "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
+  MMSA_CHECK_ARG(MMSA_CP_SPLIT(cp_fmt) == 0 || (out_mode == 0 && MMSA_CP_SPLIT(cp_fmt) < N && MMSA_CP_BASE(cp_fmt) != MMSA_FMT_H8C), "gemm_split3: the output-format split %d needs a plain [M, N] bf16 hi/lo planes output with N=%d beyond it", MMSA_CP_SPLIT(cp_fmt), N);
+  MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 / h8c operands need A planes and K %% 64 == 0 (K=%d)", K);
+  const bool h8c = fmt == MMSA_FMT_H8C, cp_h8c = MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8C;
   MMSA_CHECK_ARG((A || Ap) && Wp && (C || Cp), "gemm_split3: null pointer");
   MMSA_CHECK_ARG(!(A && Ap), "gemm_split3: pass either fp32 A or A planes, not both");
   MMSA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_split3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -353,7 +354,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   if (ap) {
     MMSA_CHECK_ARG((lda & 63) == 0 && (strideA & 63) == 0 && (((uintptr_t)Ap) & 127) == 0,
                    "gemm_split3: A planes must be 128-byte aligned with lda%%64==0 (lda=%ld)", lda);
-    MMSA_CHECK_ARG(lda >= 2L * K, "gemm_split3: planes lda=%ld < 2*K=%d", lda, 2 * K);
+    MMSA_CHECK_ARG(lda >= (h8c ? 3L : 2L) * K, "gemm_split3: planes lda=%ld < %d*K=%d (h8c: lda is the row-PAIR stride)", lda, h8c ? 3 : 2, K);
   } else {
     MMSA_CHECK_ARG((lda & 3) == 0 && (strideA & 3) == 0 && (((uintptr_t)A) & 15) == 0, "gemm_split3: A must be 16-byte aligned with lda%%4==0 (lda=%ld)", lda);
   }
@@ -365,10 +366,10 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   if (out_mode == 1) {
     MMSA_CHECK_ARG(ps_H > 0 && ps_W > 0 && ps_C > 0 && N == 4 * ps_C && M % (ps_H * ps_W) == 0 && (ps_C & 3) == 0,
                    "gemm_split3: pixel-shuffle store needs N==4*C, M%%(H*W)==0");
-    MMSA_CHECK_ARG((!C || ldc >= ps_C) && (!Cp || ldcp >= 2L * ps_C), "gemm_split3: ldc < C");
+    MMSA_CHECK_ARG((!C || ldc >= ps_C) && (!Cp || ldcp >= (cp_h8c ? 3L * MMSA_PAD64(ps_C) : 2L * ps_C)), "gemm_split3: ldc < C");
   } else {
     MMSA_CHECK_ARG(out_mode == 0, "gemm_split3: bad out_mode %d", out_mode);
-    MMSA_CHECK_ARG((!C || ldc >= N) && (!Cp || ldcp >= 2L * ((N + 31) / 32 * 32)), "gemm_split3: ldc=%ld < N=%d", ldc, N);
+    MMSA_CHECK_ARG((!C || ldc >= N) && (!Cp || ldcp >= (cp_h8c ? 3L * MMSA_PAD64(N) : 2L * ((N + 31) / 32 * 32))), "gemm_split3: ldc=%ld < N=%d", ldc, N);
   }
   GemmArgs a;
   a.A = A; a.Ap = Ap; a.lda = lda; a.strideA = strideA;
@@ -393,12 +394,13 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
     MMSA_CHECK_LAUNCH("gemm_split3(tiny)");
     return MMSA_OK;
   }
-  if (ap && (fmt == MMSA_FMT_H8 || (M >= 128 && !force_v1 && !narrow))) {   // h8 operands: only the LDS-DMA kernels read them
+  if (ap && (fmt != MMSA_FMT_B3 || (M >= 128 && !force_v1 && !narrow))) {   // h8 / h8c operands: only the LDS-DMA kernels read them
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
                                out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream, rs_out, rn_mr, rn_cs, flavour);
   }
   MMSA_CHECK_ARG(!extras, "gemm_split3: this shape is not routed to the LDS-DMA kernel, which alone writes row statistics / normalises rows");
+  MMSA_CHECK_ARG(!cp_h8c, "gemm_split3: h8c output planes are written by the LDS-DMA kernel only (activation planes in, M >= 128)");
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
   const bool gen = out_mode != 0 || resid_mod > 0;
   if (ap) {
@@ -413,13 +415,18 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
 }
 
 // ---- pre-pack: fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad] (zero padded).
-// kind 0: bf16 hi/lo planes; 1: h8 activation rows (chunk = lo bytes | q(hi) bytes); 2: h8 WEIGHT rows (chunk = q(hi) | lo): common.h
+// kind 0: bf16 hi/lo planes; 1: h8 activation rows (chunk = lo bytes | q(hi) bytes); 2: h8 WEIGHT rows (chunk = q(hi) | lo); 3: h8c planes
+// (dense: row-pair stride 3 * cols_pad; rows odd: the pair partner of the last row is not written): common.h
 __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
                                     unsigned short* __restrict__ out, int kind) {
   const long total = (long)rows * cols_pad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
     const float x = c < cols ? src[(long)r * ld + c] : 0.f;
+    if (kind == 3) {   // h8c: row pairs [hi row 2j | hi row 2j+1 | lo lines] (common.h)
+      h8c_store1(h8c_row(out, 3L * cols_pad, r, cols_pad), c, x);
+      continue;
+    }
     unsigned short* row = out + (long)r * 2 * cols_pad;
     if (kind == 0) {
       unsigned short h, l;
@@ -440,7 +447,8 @@ __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int 
 extern "C" int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad,
                                  unsigned short* out, int kind, hipStream_t stream) {
   MMSA_CHECK_ARG(src && out && rows > 0 && cols > 0 && cols_pad >= cols && cols_pad % 32 == 0, "split_planes: bad args");
-  MMSA_CHECK_ARG(kind >= 0 && kind <= 2, "split_planes: kind %d (0 bf16 hi/lo, 1 h8 activation, 2 h8 weight)", kind);
+  MMSA_CHECK_ARG(kind >= 0 && kind <= 3, "split_planes: kind %d (0 bf16 hi/lo, 1 h8 activation, 2 h8 weight, 3 h8c)", kind);
+  MMSA_CHECK_ARG(kind != 3 || cols_pad % 64 == 0, "split_planes: h8c planes need cols_pad %% 64 == 0");
   const long total = (long)rows * cols_pad;
   int blocks = cdiv(total, 256);
   if (blocks > 4096) blocks = 4096;

@@ -21,85 +21,7 @@
 //   * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) walk neighbouring (m-tile, n-tile) pairs so
 //     activation rows and weight panels are re-read from that XCD's L2 (speed only, never correctness).
 #include "common.h"
-typedef __attribute__((ext_vector_type(8))) int mx_v8i;       // operand of the block-scaled fp8 MFMA (32 bytes per lane)
-typedef __attribute__((ext_vector_type(8))) _Float16 mx_h8;  // operand of the f16 MFMA
-
-struct GemmV2Args {
-  const unsigned short* Ap; long lda; long strideA;    // ilv planes (common.h), lda in bf16 units (>= 2K)
-  const unsigned short* Wp; long strideW; long ldw;    // ilv planes, row stride ldw >= 2K (bf16 units)
-  const float* bias; long strideBias;
-  const float* colscale;
-  const float* resid; long ldr; long strideR; int resid_mod; float beta;
-  float* C; long ldc; long strideC;
-  unsigned short* Cp; long ldcp; long strideCp;
-  int M, N, K;
-  int act; float alpha;
-  int out_mode; int ps_H, ps_W, ps_C;
-  int ps_sw, ps_sh;   // log2 of ps_W / ps_H when they are powers of two (the pixel-shuffle row mapping then needs no integer division), else -1
-  int nbm, nbn, ntiles;
-  int tm, tn;  // tile order inside a batch: tm > 0 -> blocks of tm x tn = 32 tiles (see V2_TILE_MN), 0 -> row-major (m-tile, n-tile)
-  int bn;      // columns per output tile: 128 (wave tile 64 x 64) or 96 (wave tile 64 x 48: the fourth n-tile of every wave is skipped).  96 when
-               // that fills the CUs better: N = 384 gives 3 tiles of 128 (192 tiles on 256 CUs for the ConvNeXt pw2 GEMMs) or 4 of 96 (256 tiles)
-  int cp_fmt;  // format of the planes output Cp: MMSA_FMT_B3 (bf16 hi | lo) or MMSA_FMT_H8 (fp16 hi | e5m2 lo, q(hi): common.h), independent of the operands' format
-  // LayerNorm folded into a producer / consumer pair of GEMMs (mmsa_gemm_next_extras; IE:396-421: x -> norm -> qkv / lin1):
-  //   rs_out: this GEMM (the producer of the residual stream: proj, lin2, the injector's output projection) also writes, per output row
-  //           and 64-column strip, the sum and the sum of squares of the fp32 values it stores: rs_out[(row * rs_strips + strip) * 2 + {0,1}]
-  //   rn_mr / rn_cs: this GEMM (the consumer: qkv, lin1) runs on the RAW stream's planes against W o w and normalises in its epilogue:
-  //           out = rstd_r * (acc - mean_r * cs_n) + bias_n   with (mean_r, rstd_r) = rn_mr[2 r], rn_mr[2 r + 1] and cs_n = rn_cs[n] =
-  //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
-  float* rs_out; int rs_strips;
-  const float* rn_mr; const float* rn_cs;
-#ifdef MMSA_DEBUG_KNOBS
-  int debug;   // MMSA_GEMM_DEBUG (timing experiments, debug-knob builds only: tools/build_variant.sh -DMMSA_DEBUG_KNOBS): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
-#endif
-};
-#ifdef MMSA_DEBUG_KNOBS
-#define V2_DBG(a_) ((a_).debug)
-#else
-#define V2_DBG(a_) 0     // release builds: the timing ablations are compiled out
-#endif
-
-#define V2_BN 128
-#define V2_BK 32
-#define V2_W_BYTES (V2_BN * 128)                        // 16 KiB
-// per workgroup flavour (template parameter NW of the kernel): rows per tile 256 / 128, A stage 32 / 16 KiB, ring 3 x 48 / 2 x 32 KiB
-#define V2_LDS_BYTES(NW_) (((NW_) == 8 ? 3 : 2) * ((NW_) * 32 * 128 + V2_W_BYTES))
-#ifndef V2_FP8_FIRST
-#define V2_FP8_FIRST 1   // 0: fp8 and fp16 MFMAs interleaved per output tile (A/B timing)
-#endif
-#ifndef V2_EXP_NO_FP8
-#define V2_EXP_NO_FP8 0   // timing experiment: leave the fp8 cross-term MFMAs out (wrong results)
-#endif
-#ifndef V2_FAST_STEPS
-#define V2_FAST_STEPS 1   // 0: every k-tile runs the general step (A/B timing; the ablation build -DV2_KABL needs it)
-#endif
-#ifndef V2_SETPRIO
-#define V2_SETPRIO 0   // s_setprio(1) around the MFMA chunks: measured no effect on this kernel (same-box A/B)
-#endif
-
-#define GLDS16(gptr, lptr)                                                                                  \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// GEN = true compiles in the rarely used index arithmetic (pixel-shuffle store, broadcast residual: integer
-// divisions per output row); the common epilogue (GEN = false) has none.
-// ACT >= 0: the activation is a compile-time constant (the epilogue then has no activation switch and is small enough to be
-// unrolled over the four sub-tiles inside the instruction cache); ACT = -1: runtime a.act, rolled epilogue.
-// PP = true: "ping-pong" main loop.  The two waves of every SIMD belong to different groups (waves 0-3 / 4-7) that run
-// half a k-tile apart: while one group reads its fragments from LDS and issues its share of the LDS-DMA, the other owns
-// the MFMA pipe.  With every wave in phase (PP = false) the whole CU first reads LDS (~1000 cycles, MFMA idle) and then
-// computes (1536 cycles, LDS idle): MfmaUtil 36-42 %.
-#ifdef V2_STAMP   // timing experiment build only (tools/build_variant.sh -DV2_STAMP): cycle stamps of workgroup 0, k-tiles 8..11
-__device__ unsigned long long g_v2_stamps[8 * 4 * 10 + 4];   // + {memtime, memrealtime} at start and end of workgroup 0
-extern "C" int mmsa_debug_stamps(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v2_stamps), sizeof(unsigned long long) * (8 * 4 * 10 + 4));
-}
-#define STAMP(i_) if (stamp_on) tt[i_] = __builtin_readcyclecounter();
-#define CLK_SAMPLE(o_) if (blockIdx.x == 0 && threadIdx.x == 0) { g_v2_stamps[320 + (o_)] = __builtin_readcyclecounter(); g_v2_stamps[321 + (o_)] = __builtin_amdgcn_s_memrealtime(); }
-#else
-#define CLK_SAMPLE(o_)
-#define STAMP(i_)
-#endif
+#include "gemm_v2_shared.h"
 // NW = waves per workgroup.  8: the 256 x 128 tile, 3-slot ring, one workgroup per CU (ping-pong main loop).  4: a 128 x 128 tile
 // (wave tile 64 x 64 as before), 2-slot ring of 32 KiB stages, TWO workgroups per CU: the epilogue of one workgroup (VALU + stores,
 // matrix pipe idle) runs under the k-loop of the other.  For shapes whose epilogue is a large share of a tile's life (few
@@ -156,24 +78,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 #define SA(i_, ko_) reinterpret_cast<const unsigned short*>(gA + (long)(ko_) * 2 + (unsigned long)oa##i_)
 #define SW(i_, ko_) reinterpret_cast<const unsigned short*>(gW + (long)(ko_) * 2 + (unsigned long)ow##i_)
 
-// Tile index inside a batch -> (m-tile, n-tile).  The 32 workgroups that share an XCD (consecutive logical ids) hold 32 consecutive
-// tile indices at any time; row-major order made those one row of up to 32 n-tiles, i.e. every XCD streamed the WHOLE weight
-// matrix through its L2 per round (counted as fabric traffic: 1.66 x the compulsory bytes over the model's GEMM mix).  Blocked
-// order gives an XCD a tm x tn rectangle (8 x 4 for wide N): tm activation panels + tn weight panels per round.
-#define V2_TILE_MN(r_, mi_, ni_)                                                 \
-  do {                                                                           \
-    if (a.tm > 0) {                                                              \
-      const int blk_ = (r_) >> 5, loc_ = (r_) & 31;                              \
-      const int bpr_ = a.nbn / a.tn;                                             \
-      const int bi_ = blk_ / bpr_, bj_ = blk_ - bi_ * bpr_;                      \
-      const int lm_ = loc_ / a.tn;                                               \
-      mi_ = bi_ * a.tm + lm_;                                                    \
-      ni_ = bj_ * a.tn + (loc_ - lm_ * a.tn);                                    \
-    } else {                                                                     \
-      mi_ = (r_) / a.nbn;                                                        \
-      ni_ = (r_) - mi_ * a.nbn;                                                  \
-    }                                                                            \
-  } while (0)
 #define SET_TILE_SRC(tile_)                                                      \
   do {                                                                           \
     const int t_ = (tile_);                                                      \
@@ -598,316 +502,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     const int st_cur = st == 0 ? V2_NST - 1 : st - 1;   // ring slot of the k-tile just consumed: free until the next DMA into it (issued after the next barrier)
 
     if (V2_DBG(a) == 2 || V2_DBG(a) == 5 || V2_DBG(a) >= 64) { tile += G; continue; }
-    // ---- tile boundary.  MFMA layout: lane holds C[m = ..+l15][n = ..+4g .. +3].  Each wave transposes 16 x 64
-    // sub-tiles through the ring slot it has just finished computing from, so that residual loads and output stores
-    // are FULL 256-byte row segments (4 rows per wave-instruction).  After the transpose a lane owns the SAME 4
-    // columns in every row, so the column-wise part needs 8 registers.
-    {
-      const int per_b = a.nbm * a.nbn;
-      const int bz = tile / per_b;
-      const int rt = tile - bz * per_b;
-      int tmi, tni;
-      V2_TILE_MN(rt, tmi, tni);
-      const int m0 = tmi * V2_BM, n0 = tni * a.bn;
-      const float* bias = a.bias ? a.bias + (long)bz * a.strideBias : nullptr;
-      const float* colscale = a.colscale ? a.colscale + (long)bz * a.strideBias : nullptr;   // per-column vectors share the batch stride
-      const float* resid = a.resid ? a.resid + (long)bz * a.strideR : nullptr;
-      float* C = a.C ? a.C + (long)bz * a.strideC : nullptr;
-      unsigned short* Cp = a.Cp ? a.Cp + (long)bz * a.strideCp : nullptr;
-      const bool vec_ok = ((a.ldc & 3) == 0) && (!resid || (a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((a.ldcp & 3) == 0);
-      if constexpr (PP) {
-        nowait = 1;   // both groups drained before the last barrier of the k loop: k-tile j (and j+1) are visible
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs of j, j+1 (already issued) and every store issued so far
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave has read its fragments of slot st_cur; the k-tiles already issued (two, or one with the 2-slot ring) landed for all
-        nowait = V2_NST - 1;
-      }
-      float* stg = reinterpret_cast<float*>(smem + st_cur * V2_STAGE) + wave * (16 * 68);
-      const int nb_ = n0 + wn * swid;
-      const int cp_base = MMSA_CP_BASE(a.cp_fmt);
-      const bool cp_split = MMSA_CP_SPLIT(a.cp_fmt) != 0;   // kernel-uniform: columns >= the split leave as h8 planes (common.h)
-      const int rl0 = lane >> 4;            // read-back: lane -> (row = rl0 + 4*i, columns cl .. cl+3)
-      const int cl = (lane & 15) * 4;
-      const bool lane_ok = cl < swid;        // 96-column tiles: the lanes of the (skipped) fourth n-tile only keep the loads in bounds
-      const int n = nb_ + (lane_ok ? cl : 0);
-      // column parameters of this lane's 4 columns: loaded ONCE per tile, unconditionally (clamped index)
-      float bv[4], cv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ci = min(n + r, a.N - 1);
-        bv[r] = bias ? bias[ci] : 0.f;
-        if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-        cv[r] = colscale ? colscale[ci] * a.alpha : a.alpha;
-      }
-      // row mapping (destination row / column, residual row); identity unless GEN
-      // pixel-shuffle store: the (i, j) quadrant of this lane's own columns is fixed for the tile -- one division per tile, not per row
-      int ij_n = 0, dcol_n = n;
-      if constexpr (GEN) { if (a.out_mode == 1) { ij_n = n / a.ps_C; dcol_n = n - ij_n * a.ps_C; } }
-      auto map_row = [&](int m, int nn, long& drow_, int& dcol, long& rrow) {
-        drow_ = m; dcol = nn; rrow = m;
-        if constexpr (GEN) {
-          if (a.out_mode == 1) {
-            int ij = ij_n;
-            dcol = dcol_n;
-            if (nn != n) { ij = nn / a.ps_C; dcol = nn - ij * a.ps_C; }
-            int w_, h_, b_;
-            if (a.ps_sw >= 0 && a.ps_sh >= 0) {   // power-of-two grids (every shipped config): shifts and masks
-              w_ = m & (a.ps_W - 1);
-              const int t_ = m >> a.ps_sw;
-              h_ = t_ & (a.ps_H - 1);
-              b_ = t_ >> a.ps_sh;
-            } else {
-              w_ = m % a.ps_W;
-              const int t_ = m / a.ps_W;
-              h_ = t_ % a.ps_H;
-              b_ = t_ / a.ps_H;
-            }
-            drow_ = ((long)(b_ * 2 * a.ps_H + 2 * h_ + (ij >> 1))) * (2 * a.ps_W) + 2 * w_ + (ij & 1);
-          }
-          rrow = a.resid_mod > 0 ? (long)((int)drow_ % a.resid_mod) : drow_;
-        }
-      };
-      // wave-uniform: whole 64-column strip inside N, 16-byte aligned (and, for the planes output of a pixel-shuffle
-      // store, inside one destination row: ps_C a multiple of 64)
-      const bool fast = vec_ok && (nb_ + swid <= a.N) && (ni4 || !Cp) && (!GEN || !Cp || a.out_mode != 1 || (a.ps_C & 63) == 0);
-      // The four 16-row sub-tiles are handled by a ROLLED loop: the code always takes accumulator column 0 and then
-      // rotates the columns down by register moves (48 v_mov per pass).  Fully unrolled -- with the activation switch
-      // expanded per element -- the epilogue was ~100 KiB of straight-line code, far beyond the 64 KiB instruction
-      // cache two CUs share, and ran at instruction-fetch speed: ~45 of the kernel's ~200 us at K = 1024 with
-      // only ~13 us of that being the stores themselves (MMSA_GEMM_DEBUG 1 / 10 / 2 ablations).
-      const int act = ACT >= 0 ? ACT : a.act;
-      // Planes-only outputs (lin1, qkv, the ConvNeXt pw1s: no fp32 copy, no residual, plain row mapping): bias / activation / scale are
-      // applied in the NATIVE accumulator layout (lane = row l15, columns 16 ni + 4g .. +3) and the split values go straight into the
-      // LDS line image, which is read back 16 bytes per lane for whole-line stores: ONE LDS round trip per sub-tile instead of two
-      // (transpose to rows, then re-stage as lines), and the four sub-tiles' LDS traffic and arithmetic are free to overlap -- a wave's
-      // LDS instructions execute in order, so sub-tile mi + 1 may overwrite the staging rows as soon as mi's read-backs are ISSUED.
-      bool direct = false;
-      if constexpr (EPI_UNROLL && !GEN) direct = fast && Cp && !C && !resid && ni4 && V2_DBG(a) == 0 && (((uintptr_t)bias | (uintptr_t)colscale) & 15) == 0;
-      if constexpr (EPI_UNROLL && !GEN) {
-        if (direct) {
-          float4 bn_[4], cn_[4], sn_[4];
-          const bool rn = a.rn_mr != nullptr;       // kernel-uniform: row-normalising epilogue (LayerNorm folded in)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            const int ci = nb_ + ni * 16 + 4 * g;     // fast: the whole 64-column strip is inside N
-            bn_[ni] = bias ? *reinterpret_cast<const float4*>(bias + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
-            cn_[ni] = colscale ? *reinterpret_cast<const float4*>(colscale + ci) : make_float4(1.f, 1.f, 1.f, 1.f);
-            cn_[ni].x *= a.alpha; cn_[ni].y *= a.alpha; cn_[ni].z *= a.alpha; cn_[ni].w *= a.alpha;
-            sn_[ni] = rn ? *reinterpret_cast<const float4*>(a.rn_cs + (long)bz * a.strideBias + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-          unsigned short* wrow = reinterpret_cast<unsigned short*>(stg + l15 * 68);
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int mb = m0 + wm * 64 + mi * 16;
-            float mu = 0.f, rs = 1.f;                 // this lane's row of the sub-tile (rows beyond M: clamped, never stored)
-            if (rn) {
-              const float2 mr = *reinterpret_cast<const float2*>(a.rn_mr + 2 * ((long)bz * a.M + min(mb + l15, a.M - 1)));
-              mu = mr.x; rs = mr.y;
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              float4 o;
-              if (rn) {   // rstd * (acc - mean * colsum) + bias: the two roundings of the reference's (x - mean) * rstd are not reproduced, the value is
-                o = make_float4(fmaf(rs, fmaf(-mu, sn_[ni].x, acc[ni][mi][0]), bn_[ni].x), fmaf(rs, fmaf(-mu, sn_[ni].y, acc[ni][mi][1]), bn_[ni].y),
-                                fmaf(rs, fmaf(-mu, sn_[ni].z, acc[ni][mi][2]), bn_[ni].z), fmaf(rs, fmaf(-mu, sn_[ni].w, acc[ni][mi][3]), bn_[ni].w));
-              } else {
-                o = make_float4(acc[ni][mi][0] + bn_[ni].x, acc[ni][mi][1] + bn_[ni].y, acc[ni][mi][2] + bn_[ni].z, acc[ni][mi][3] + bn_[ni].w);
-              }
-              acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-              if (act != ACT_NONE) {
-                if (act == ACT_GELU) o = gelu4(o);
-                else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
-              }
-              o.x *= cn_[ni].x; o.y *= cn_[ni].y; o.z *= cn_[ni].z; o.w *= cn_[ni].w;
-              store_planes4(wrow, ni * 16 + 4 * g, o, cp_split ? MMSA_CP_AT(a.cp_fmt, nb_ + ni * 16 + 4 * g) : cp_base);
-            }
-            uint4 pk[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              pk[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(stg + (rl0 + 4 * i) * 68) + 8 * (lane & 15));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int m = mb + rl0 + 4 * i;
-              if (m < a.M) *reinterpret_cast<uint4*>(Cp + (long)m * a.ldcp + ilv(n & ~63) + 8 * (lane & 15)) = pk[i];
-            }
-          }
-        }
-      }
-      // (fp32-only outputs stored straight from the accumulator layout -- 16 rows x 64 bytes per instruction, no LDS transpose --
-      // measured time-neutral against the transposed whole-row stores on every shape and on the step, same box: not kept.)
-      if (direct) {
-      } else if constexpr (EPI_UNROLL) {
-        // residual rows one sub-tile AHEAD: the 4 loads of sub-tile mi + 1 are issued before sub-tile mi is processed (its LDS round
-        // trips, arithmetic and stores cover their latency).  Requested per sub-tile -- behind the previous sub-tile's stores, which the
-        // compiler must assume alias them when the GEMM updates its residual in place -- a tile's epilogue was four serialised memory
-        // round trips: 33 us of a 127 us launch at one tile per workgroup (lin2 of one image, profiles/r03_v3_vs_v2.txt).  (All four
-        // sub-tiles up front would need 64 registers and spills.)
-        float4 rrn[4];
-        auto load_rr = [&](int mi_) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            long drow_, rrow; int dcol;
-            map_row(min(m0 + wm * 64 + mi_ * 16 + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
-            rrn[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
-          }
-        };
-        if (fast && resid) load_rr(0);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 16;
-        float4 rr[4];
-        if (fast && resid) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) rr[i] = rrn[i];
-          if (mi < 3) load_rr(mi + 1);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][mi];
-          acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (V2_DBG(a) == 1) continue;
-        if (fast) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int rl = rl0 + 4 * i;
-            float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
-            o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
-            if (act != ACT_NONE) {   // ONE wave-uniform branch per 4 values (none when ACT is a template constant)
-              if (act == ACT_GELU) o = gelu4(o);
-              else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
-            }
-            o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
-            if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
-            // planes output: split in registers, re-stage the bf16 pairs in the INTERLEAVED layout (hi 32 | lo 32 per
-            // k-block) in the same LDS row and read them back 16 bytes per lane, so that a row-group leaves as ONE
-            // instruction of 4 x 256 contiguous bytes = full 128-byte lines (8-byte hi / lo stores wrote every line as
-            // two half-lines from two instructions).  LDS executes a wave's instructions in order: the row was fully
-            // read (above) before it is overwritten here.
-            uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-            if (Cp) {   // either planes format: stage the row image, read it back 16 bytes per lane
-              unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
-              store_planes4(srow, cl, o, cp_split ? MMSA_CP_AT(a.cp_fmt, nb_ + cl) : cp_base);
-              pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
-            }
-            const int m = mb + rl;
-            if (a.rs_out) {   // kernel-uniform: sum and sum of squares of this row's 64 columns (the 16 lanes of one DPP row hold them)
-              float s1 = (o.x + o.y) + (o.z + o.w), s2 = fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w);
-#pragma unroll
-              for (int sh = 8; sh > 0; sh >>= 1) { s1 += __shfl_xor(s1, sh, 64); s2 += __shfl_xor(s2, sh, 64); }
-              if ((lane & 15) == 0 && m < a.M)
-                *reinterpret_cast<float2*>(a.rs_out + (((long)bz * a.M + m) * a.rs_strips + (nb_ >> 6)) * 2) = make_float2(s1, s2);
-            }
-            if (V2_DBG(a) == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
-            else if (m < a.M && lane_ok) {
-              long drow_, rrow; int dcol;
-              map_row(m, n, drow_, dcol, rrow);
-              if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
-              if (Cp) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
-            }
-          }
-        } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare
-#pragma unroll 1
-          for (int e = 0; e < 16; ++e) {
-            const int i = e >> 2, r = e & 3;
-            const int rl = rl0 + 4 * i;
-            const int m = mb + rl;
-            if (m >= a.M || n + r >= a.N || !lane_ok) continue;
-            float x = stg[rl * 68 + cl + r];
-            {
-              int ci = n + r;
-              const float b_ = bias ? bias[ci] : 0.f;
-              if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-              x = apply_act(x + b_, act) * (colscale ? colscale[ci] * a.alpha : a.alpha);
-            }
-            long drow_, rrow; int dcol;
-            map_row(m, n + r, drow_, dcol, rrow);
-            if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
-            if (C) C[drow_ * a.ldc + dcol] = x;
-            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, MMSA_CP_AT(a.cp_fmt, dcol));
-          }
-        }
-        }
-      } else {
-#pragma unroll 1
-        for (int mi = 0; mi < 4; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 16;
-        // residual rows first: 4 independent 16-byte loads in flight, no waits inside the element loops
-        float4 rr[4];
-        if (fast && resid) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            long drow_, rrow; int dcol;
-            map_row(min(mb + rl0 + 4 * i, a.M - 1), n, drow_, dcol, rrow);
-            rr[i] = *reinterpret_cast<const float4*>(resid + rrow * a.ldr + dcol);
-          }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          *reinterpret_cast<f32x4*>(stg + l15 * 68 + ni * 16 + 4 * g) = acc[ni][0];
-          acc[ni][0] = acc[ni][1];
-          acc[ni][1] = acc[ni][2];
-          acc[ni][2] = acc[ni][3];
-          acc[ni][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (V2_DBG(a) == 1) continue;
-        if (fast) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int rl = rl0 + 4 * i;
-            float4 o = *reinterpret_cast<const float4*>(stg + rl * 68 + cl);
-            o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3];
-            if (act != ACT_NONE) {   // ONE wave-uniform branch per 4 values (none when ACT is a template constant)
-              if (act == ACT_GELU) o = gelu4(o);
-              else { o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act); }
-            }
-            o.x *= cv[0]; o.y *= cv[1]; o.z *= cv[2]; o.w *= cv[3];
-            if (resid) { o.x += a.beta * rr[i].x; o.y += a.beta * rr[i].y; o.z += a.beta * rr[i].z; o.w += a.beta * rr[i].w; }
-            // planes output: split in registers, re-stage the bf16 pairs in the INTERLEAVED layout (hi 32 | lo 32 per
-            // k-block) in the same LDS row and read them back 16 bytes per lane, so that a row-group leaves as ONE
-            // instruction of 4 x 256 contiguous bytes = full 128-byte lines (8-byte hi / lo stores wrote every line as
-            // two half-lines from two instructions).  LDS executes a wave's instructions in order: the row was fully
-            // read (above) before it is overwritten here.
-            uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-            if (Cp) {   // either planes format: stage the row image, read it back 16 bytes per lane
-              unsigned short* srow = reinterpret_cast<unsigned short*>(stg + rl * 68);
-              store_planes4(srow, cl, o, cp_split ? MMSA_CP_AT(a.cp_fmt, nb_ + cl) : cp_base);
-              pk = *reinterpret_cast<const uint4*>(srow + 8 * (lane & 15));
-            }
-            const int m = mb + rl;
-            if (V2_DBG(a) == 10) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(pk.x), "v"(pk.w)); }   // timing: everything but the stores
-            else if (m < a.M && lane_ok) {
-              long drow_, rrow; int dcol;
-              map_row(m, n, drow_, dcol, rrow);
-              if (C) *reinterpret_cast<float4*>(C + drow_ * a.ldc + dcol) = o;
-              if (Cp) *reinterpret_cast<uint4*>(Cp + drow_ * a.ldcp + ilv(dcol & ~63) + 8 * (lane & 15)) = pk;
-            }
-          }
-        } else {  // ragged right edge or unaligned leading dimensions: element-wise, rare
-#pragma unroll 1
-          for (int e = 0; e < 16; ++e) {
-            const int i = e >> 2, r = e & 3;
-            const int rl = rl0 + 4 * i;
-            const int m = mb + rl;
-            if (m >= a.M || n + r >= a.N || !lane_ok) continue;
-            float x = stg[rl * 68 + cl + r];
-            {
-              int ci = n + r;
-              const float b_ = bias ? bias[ci] : 0.f;
-              if constexpr (GEN) { if (a.out_mode == 1) ci %= a.ps_C; }
-              x = apply_act(x + b_, act) * (colscale ? colscale[ci] * a.alpha : a.alpha);
-            }
-            long drow_, rrow; int dcol;
-            map_row(m, n + r, drow_, dcol, rrow);
-            if (resid) x += a.beta * resid[rrow * a.ldr + dcol];
-            if (C) C[drow_ * a.ldc + dcol] = x;
-            if (Cp) store_planes1(Cp + drow_ * a.ldcp, dcol, x, MMSA_CP_AT(a.cp_fmt, dcol));
-          }
-        }
-        }
-      }
-    }
+#define EPI_STAGING_BASE (smem + st_cur * V2_STAGE)
+#include "gemm_v2_epilogue.inc"
+#undef EPI_STAGING_BASE
     if constexpr (PP) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // slot st_cur (epilogue staging of every wave) is free again: group 0 DMAs into it next
@@ -923,6 +520,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 #undef MFMA_CHUNK
 #undef MFMA_FP8_ALL
 }
+
+int mmsa_gemm_h8c_dispatch(const GemmV2Args& a, int grid, bool gen, int act, hipStream_t stream);   // gemm_h8c.hip
 
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
 // fmt = format of the A and W planes, cp_fmt = format of the planes output (common.h).
@@ -945,7 +544,8 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   a.rs_out = rs_out; a.rs_strips = N >> 6; a.rn_mr = rn_mr; a.rn_cs = rn_cs;
   a.Ap = Ap; a.lda = lda; a.strideA = strideA;
   a.Wp = Wp; a.strideW = strideW;
-  a.ldw = 2L * K;
+  const bool h8c = fmt == MMSA_FMT_H8C;
+  a.ldw = h8c ? 3L * K : 2L * K;   // dense packed weights (h8c: row-PAIR stride)
   a.bias = bias; a.strideBias = strideBias; a.colscale = colscale;
   a.resid = resid; a.ldr = ldr; a.strideR = strideR; a.resid_mod = resid_mod; a.beta = beta;
   a.C = C; a.ldc = C ? ldc : 0; a.strideC = strideC;
@@ -955,7 +555,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   auto log2_exact = [](int v) { int s_ = -1; if (v > 0 && (v & (v - 1)) == 0) { s_ = 0; while ((1 << s_) < v) ++s_; } return s_; };
   a.ps_sw = log2_exact(ps_W); a.ps_sh = log2_exact(ps_H);
   a.cp_fmt = cp_fmt;
-  const bool h8 = fmt == MMSA_FMT_H8;
+  const bool h8 = fmt == MMSA_FMT_H8 || h8c;
   MMSA_CHECK_ARG(!h8 || (K & 63) == 0, "gemm(v2): h8 operands need K %% 64 == 0 (K=%d)", K);
   // workgroup flavour: 8-wave 256-row ping-pong tiles, except shallow contractions on bf16 hi/lo planes (K <= 256: at most four k-tile
   // pairs per output tile -- the tile is its prologue and epilogue), which take the 4-wave flavour (128-row tiles, two workgroups per
@@ -991,7 +591,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   const int cus = (max_grid > 0 && max_grid < num_cus) ? max_grid : num_cus;
   // 96-column tiles when they occupy the CUs better: rounds(tiles) x relative tile cost (0.75) against rounds of 128-column tiles.
   // fp32 output only (the planes epilogue writes whole 64-column strips) and no pixel-shuffle / broadcast-residual store.
-  if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96 && N % 96 == 0 && !rs_out) {   // (a ragged last 96-column tile would run the element-wise
+  if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96 && N % 96 == 0 && !rs_out && !h8c) {   // (a ragged last 96-column tile would run the element-wise
     // epilogue: N = 256 -- the ConvFFN fc1 of the extractors -- was routed here and spent 40 of its 92 us in it, profiles/r03_v3_vs_v2.txt)
     const bool no96 = MMSA_KNOB("MMSA_GEMM_NO96", 0) != 0;   // A/B aid (debug-knob builds)
     const int nbn96 = cdiv(N, 96);
@@ -1027,10 +627,11 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   const int rounds_ = cdiv(a.ntiles, slots_);
   const int grid = cdiv(a.ntiles, rounds_);
   const bool gen = out_mode != 0 || resid_mod > 0;
+  if (h8c) return mmsa_gemm_h8c_dispatch(a, grid, gen, act, stream);
   const bool pp = MMSA_KNOB("MMSA_GEMM_PP", 1) != 0;   // 0 (debug-knob builds): every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \
   do {                                                                                                                     \
-    if (h8) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);          \
+    if (fmt == MMSA_FMT_H8) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);          \
     else if (nw == 4) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>), dim3(grid), dim3(256), V2_LDS_BYTES(4), stream, a);     \
     else if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);     \
     else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);            \

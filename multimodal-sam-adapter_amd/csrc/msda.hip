@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void msda_kernel(
     unsigned short* __restrict__ op, long ldop, int op_fmt,
     int N, int S, int M, int D, int L, int Lq, int P) {
   const int d4 = D >> 2;                        // lanes per (q, m) pair
+  const int op_kpad = MMSA_PAD64(M * D);        // h8c output planes: fp16 values per row
   // 32-bit index arithmetic (N*Lq*M*d4 < 2^32, checked by the launcher): the four 64-bit div/mod of the first version
   // were a quarter of the kernel's instructions
   const unsigned pair = (blockIdx.x * blockDim.x + threadIdx.x) / (unsigned)d4;
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void msda_kernel(
   if (out) *reinterpret_cast<float4*>(out + bq * ldo + (long)m * D + c) = acc;
   if (op) {   // operand planes for output_proj, either format
     // D % 8 == 0: threads 2j / 2j+1 of a (query, head) group hold 8 consecutive channels: whole-line stores through the lane-pair exchange
-    if ((D & 7) == 0) store_planes8_pair<1>(op + bq * ldop, m * D + (c & ~7), acc, op_fmt, (c >> 2) & 1, true);
-    else store_planes4(op + bq * ldop, m * D + c, acc, op_fmt);
+    if ((D & 7) == 0) store_planes8_pair_any<1>(op, ldop, bq, op_kpad, m * D + (c & ~7), acc, op_fmt, (c >> 2) & 1, true);
+    else store_planes4_any(op, ldop, bq, op_kpad, m * D + c, acc, op_fmt);
   }
 }
 
@@ -346,9 +347,9 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
                                unsigned short* out_p, long ldop, int out_fmt,
                                int batch, int spatial_size, int num_heads, int channels, int num_levels,
                                int num_query, int num_point, hipStream_t stream) {
-  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "msda_fused: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "msda_fused: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && ref_points && (out || out_p), "msda_fused: null pointer");
-  MMSA_CHECK_ARG(!out_p || (ldop >= 2L * num_heads * channels && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
+  MMSA_CHECK_ARG(!out_p || (ldop >= (out_fmt == MMSA_FMT_H8C ? 3L * MMSA_PAD64(num_heads * channels) : 2L * num_heads * channels) && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
                  "msda_fused: bad output planes");
   int rc = msda_check(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, "msda_fused");
   if (rc) return rc;

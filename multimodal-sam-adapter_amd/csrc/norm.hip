@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     }
     float* yr = y ? y + orow * ldy + ocol : nullptr;
     float* y2r = y2 ? y2 + (long)row * ldy2 : nullptr;
-    unsigned short* pr = yp ? yp + orow * ldp : nullptr;   // ilv planes row (ocol is a multiple of 32 when patchifying)
+    unsigned short* pr = (yp && plane_fmt != MMSA_FMT_H8C) ? yp + orow * ldp : nullptr;   // ilv planes row (ocol is a multiple of 32 when patchifying)
+    const bool h8c = yp && plane_fmt == MMSA_FMT_H8C;      // h8c planes: plain [rows, C] output only (checked by the launcher), row pairs
+    const H8cRow hr = h8c ? h8c_row(yp, ldp, orow, MMSA_PAD64(C)) : H8cRow{nullptr, nullptr};
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + LPR * i) * 4;
@@ -97,7 +99,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
         o.w = (v[i].w - mean) * rstd * wv[i].w + bv[i].w;
         if (yr) *reinterpret_cast<float4*>(yr + c) = o;
       }
-      if (pr) {
+      if (h8c) {
+        if (pair16) h8c_store8_pair<1>(hr, c & ~7, o, lane & 1, in);
+        else if (in) h8c_store4(hr, c, o);
+      } else if (pr) {
         if (pair16) {
           // C % 8 == 0: lanes 2j / 2j+1 hold channels 8j .. 8j+7: whole-line stores through the lane-pair exchange (common.h)
           store_planes8_pair<1>(pr, (int)ocol + (c & ~7), o, plane_fmt, lane & 1, in);
@@ -118,7 +123,9 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
                                    unsigned short* yp, long ldp, int rows, int C,
                                    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap,
                                    int plane_fmt, hipStream_t stream) {
-  MMSA_CHECK_ARG(plane_fmt == MMSA_FMT_B3 || plane_fmt == MMSA_FMT_H8, "layernorm_rows: bad plane format %d", plane_fmt);
+  MMSA_CHECK_ARG(plane_fmt >= MMSA_FMT_B3 && plane_fmt <= MMSA_FMT_H8C, "layernorm_rows: bad plane format %d", plane_fmt);
+  MMSA_CHECK_ARG(!yp || plane_fmt != MMSA_FMT_H8C || (map_mode == 0 && group_rows == 0 && ldp >= 3L * MMSA_PAD64(C)),
+                 "layernorm_rows: h8c planes are a plain [rows, C] output (no patchify / row groups), ldp = pair stride >= 3 * pad64(C)");
   MMSA_CHECK_ARG(x && w && b && (y || yp) && rows > 0 && C > 0, "layernorm_rows: bad args");
   MMSA_CHECK_ARG(!yp || map_mode == 0 || C % 32 == 0, "layernorm_rows: patchified planes need C %% 32 == 0");
   MMSA_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy2 & 3) == 0 && (ldp & 3) == 0, "layernorm_rows: C/ld must be multiples of 4");

@@ -394,10 +394,10 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       psum += __shfl_xor(psum, 32, 64);
       const float inv = 1.0f / psum;
       {   // lanes G / G ^ 1 of a query row (lane ^ 16) hold 8 consecutive channels: whole-line stores through the pair exchange (common.h)
-        unsigned short* orow = a.op + ((long)b_cur * T + (tq_cur >= 0 ? tq_cur : 0)) * a.ldo;
+        const long orow = (long)b_cur * T + (tq_cur >= 0 ? tq_cur : 0);
 #pragma unroll
         for (int d = 0; d < 4; ++d)
-          store_planes8_pair<16>(orow, head_cur * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, tq_cur >= 0);
+          store_planes8_pair_any<16>(a.op, a.ldo, orow, MMSA_PAD64(a.D), head_cur * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, tq_cur >= 0);
       }
     }
     if (!has_next) break;
@@ -416,13 +416,13 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
                                             int B, int H, int W, int heads, int head_dim, int window_size, float scale,
                                             int out_fmt, int v_fmt, float* max_abs_logit, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
-  MMSA_CHECK_ARG(out_fmt == MMSA_FMT_B3 || out_fmt == MMSA_FMT_H8, "window_attention: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "window_attention: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(v_fmt == 0 || v_fmt == 2, "window_attention: v_fmt %d (0 = bf16 hi/lo planes; 2 = qkv, bias and rel-pos planes in the h8 format and an fp16 selector: every contraction on the fp16 MFMA)", v_fmt);
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0, "window_attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64, "window_attention: head_dim %d not supported by this kernel (64)", head_dim);
   MMSA_CHECK_ARG(window_size >= 1 && window_size <= 14, "window_attention: window_size %d not supported (1..14)", window_size);
   const int D = heads * head_dim;
-  MMSA_CHECK_ARG(ldq >= 6L * D && (ldq & 63) == 0 && ldo >= 2L * D && (ldo & 63) == 0, "window_attention: bad leading dimensions");
+  MMSA_CHECK_ARG(ldq >= 6L * D && (ldq & 63) == 0 && ldo >= (out_fmt == MMSA_FMT_H8C ? 3L : 2L) * D && (ldo & 63) == 0, "window_attention: bad leading dimensions");
   MMSA_CHECK_ARG(((reinterpret_cast<uintptr_t>(qkv_planes) | reinterpret_cast<uintptr_t>(bias_planes) |
                    reinterpret_cast<uintptr_t>(relpos_planes) | reinterpret_cast<uintptr_t>(selector) | reinterpret_cast<uintptr_t>(out_planes)) & 127) == 0,
                  "window_attention: planes must be 128-byte aligned");

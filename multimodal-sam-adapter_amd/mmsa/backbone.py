@@ -55,8 +55,8 @@ class Workspace:
 
     def planes(self, name, rows, cols, zero=False, fmt=ops.FMT_B3):
         """Activation planes of a [rows, cols] matrix (cols padded to 32) in the given operand format (ops.Planes)."""
-        cp = ops.pad32(cols)
-        return ops.Planes(self.get(name + ".pl", rows, 2 * cp, torch.int16, zero or cp != cols), rows, cols, cp, fmt)
+        tr, tc, cp = ops.planes_shape(rows, cols, fmt)
+        return ops.Planes(self.get(name + ".pl", tr, tc, torch.int16, zero or cp != cols), rows, cols, cp, fmt)
 
     def nbytes(self):
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
@@ -275,6 +275,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 sd[b + "rel_pos_w"] = torch.zeros(L, hd, device=dev)
         return sd
 
+    def _h8c_wanted(self):
+        """h8 sites with deep contractions travel as h8c planes (default); `model.h8c = False` / MMSA_H8C=0 keeps them on h8 line planes (A/B)."""
+        return os.environ.get("MMSA_H8C", "1") != "0" and bool(getattr(self, "h8c", True))
+
     def _fold_ln_wanted(self, hidden=None):
         """Whether _pack folds the ViT blocks' LayerNorms into their consumer GEMMs (a pack-time setting: checkpoint.load_packed compares it)."""
         D, heads = self.cfg["embed_dim"], self.cfg["num_heads"]
@@ -288,7 +292,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         cfg = self.cfg
         h8_sites = self._h8_sites()
         sd = self._pack_state_dict(dev)
-        pk = {"h8_sites": h8_sites}
+        pk = {"h8_sites": h8_sites, "h8c": self._h8c_wanted()}
         D = cfg["embed_dim"]
 
         def planes(w2d, kpad=None, fmt=ops.FMT_B3):
@@ -328,7 +332,11 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
 
         # operand format of the ViT-block GEMMs: h8 needs every contraction length (D, attention width, MLP hidden) % 64 == 0
         hidden_ = sd["blocks.0.mlp.lin1.weight"].shape[0]
-        vfmt = ops.FMT_H8 if ("vit" in h8_sites and D % 64 == 0 and Da % 64 == 0 and hidden_ % 64 == 0) else ops.FMT_B3
+        # ... as h8c planes (3 bytes per element, csrc/gemm_h8c.hip: a shorter operand stream and balanced matrix phases) where every contraction of
+        # the block is at least 512 deep (few k-tile pairs per output tile leave that kernel's straight-line loop nothing to run), h8 line planes otherwise
+        vfmt = ops.FMT_B3
+        if "vit" in h8_sites and D % 64 == 0 and Da % 64 == 0 and hidden_ % 64 == 0:
+            vfmt = ops.FMT_H8C if (min(D, Da, hidden_) >= 512 and self._h8c_wanted()) else ops.FMT_H8
         pk["vit_fmt"] = vfmt
         # LayerNorm fold (IE:396-421): norm1 / norm2 of the ViT blocks live in their consumer GEMMs.  The producer of the
         # residual stream (proj, lin2, the injector's output projection) also writes the stream as planes and per-row strip sums; qkv / lin1
@@ -484,8 +492,11 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # --- interactions
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
 
-        def ifmt(w2d, site="inter"):   # operand format of one GEMM of a site group: h8 when selected and the contraction length allows it
-            return ops.FMT_H8 if (site in h8_sites and ops.pad32(w2d.shape[1]) % 64 == 0) else ops.FMT_B3
+        def ifmt(w2d, site="inter"):   # operand format of one GEMM of a site group: h8c / h8 when selected and the contraction length allows it
+            kk = ops.pad32(w2d.shape[1])
+            if site not in h8_sites or kk % 64:
+                return ops.FMT_B3
+            return ops.FMT_H8C if (kk >= 512 and self._h8c_wanted()) else ops.FMT_H8
 
         def iplanes(w2d, site="inter"):
             return planes(w2d, fmt=ifmt(w2d, site))
@@ -607,7 +618,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             raise RuntimeError("mmsa: img_size must be a multiple of 32")
         dev = x.device
         x = x.contiguous().float()
-        if self._packed is None or self._packed.get("dev") != dev or tuple(self._packed.get("h8_sites", ())) != self._h8_sites():
+        if (self._packed is None or self._packed.get("dev") != dev or tuple(self._packed.get("h8_sites", ())) != self._h8_sites()
+                or self._packed.get("h8c") != self._h8c_wanted()):
             self._packed = self._pack(dev)
             self._packed["dev"] = dev
         if self._ws is None or self._ws.device != dev:
@@ -747,7 +759,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         c2p = ws.planes("up_a", B * n2, D, fmt=pk["up"].fmt)
         for bi in range(B):
             ops.split_planes(cbuf[bi * Nc:bi * Nc + n2], kpad=D, out=c2p.rows(bi * n2, (bi + 1) * n2))
-        ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=n2 * 2 * D,
+        ops.gemm(c2p, pk["up"], c1, bias=pk["up_b"], resid=c1, batch=B, m=n2, stride_a=c2p.batch_stride(n2),
                  stride_r=(H // 4) * (W // 4) * D, stride_c=(H // 4) * (W // 4) * D, pixel_shuffle=(H // 8, W // 8, D))
         # emit_planes (set by the decode head's caller, e.g. bench.py / mmsa.inference): every output map is also written
         # token-major as interleaved planes and attached to the returned tensor (`_mmsa_planes`), so that mmsa.SegformerHead
@@ -906,7 +918,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 moved.append(bp["index"])
                 if reroute:
                     bp["amode"] = "b3"
-                    if bp["qkv"].fmt == ops.FMT_H8:
+                    if bp["qkv"].fmt != ops.FMT_B3:
                         # the projections around those logits must not lose them either: q and k from 2^-15.6 products turn a logit of 48 into
                         # an error of ~1e-3 before the exponential, and what proj / lin1 / lin2 lose reaches the NEXT block's q and k.  The
                         # whole block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.

@@ -172,14 +172,14 @@ def save_packed(model, path, device="cuda"):
                 for k in ("amode", "max_logit"):
                     if k in bo:
                         bp[k] = bo[k]
-                if bo.get("amode") == "b3" and bp["qkv"].fmt == ops.FMT_H8:
+                if bo.get("amode") == "b3" and bp["qkv"].fmt != ops.FMT_B3:
                     bp.update(model._block_gemm_planes(sd_dev, bp["index"], ops.FMT_B3, pk["fold_ln"], dev))
         torch.cuda.synchronize(dev)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     enc = _enc(pk)
     torch.save({"format": PACK_FORMAT, "cfg": model.cfg, "state_dict": sd, "packed": enc, "fingerprint": _fingerprint(sd),
                 "packed_checksum": _packed_checksum(enc),
-                "settings": {"h8_sites": list(model._h8_sites()), "share_c_norm": bool(pk.get("share_c_norm", True)), "fold_ln": bool(pk.get("fold_ln", False)),
+                "settings": {"h8_sites": list(model._h8_sites()), "h8c": bool(pk.get("h8c", False)), "share_c_norm": bool(pk.get("share_c_norm", True)), "fold_ln": bool(pk.get("fold_ln", False)),
                              "fold_cnx_ln": bool(pk.get("fold_cnx_ln", False))}}, path)
 
 
@@ -193,7 +193,7 @@ def load_packed(model, path, device="cuda"):
         raise RuntimeError(f"{path}: not an mmsa packed checkpoint (format {PACK_FORMAT})")
     if blob["cfg"] != model.cfg:
         raise RuntimeError(f"{path}: packed for a different architecture")
-    want = {"h8_sites": list(model._h8_sites()),
+    want = {"h8_sites": list(model._h8_sites()), "h8c": bool(model._h8c_wanted()),
             "share_c_norm": os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(model, "share_c_norm", True))}
     want["fold_ln"] = bool(model._fold_ln_wanted())
     want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"

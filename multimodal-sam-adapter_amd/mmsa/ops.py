@@ -66,18 +66,23 @@ def _mat(t, name, dtype=torch.float32):
     return _chk(t, dtype, name), t.shape[0], t.shape[1], t.stride(0)
 
 
-FMT_B3, FMT_H8 = 0, 1   # MMSA_FMT_* (include/mmsa.h)
+FMT_B3, FMT_H8, FMT_H8C = 0, 1, 2   # MMSA_FMT_* (include/mmsa.h)
 
 
 class Planes:
     """Operand planes (include/mmsa.h) of a matrix: ONE int16 tensor [rows, 2*kpad]; 128 bytes per row and 32-wide k-block.
     fmt FMT_B3: bf16 hi/lo ("split3": the 32 hi values then the 32 lo values).  fmt FMT_H8: fp16 hi + e5m2 cross-term bytes
     (32 fp16, then four 16-byte chunks of lo / q(hi) bytes; `weight` = the chunk order of a W operand).  Used for weights
-    [N, K] and for activations; a producer writes the format of the Planes it is handed."""
+    [N, K] and for activations; a producer writes the format of the Planes it is handed.
+    fmt FMT_H8C (round 4): the h8 arithmetic on 3 bytes per element, stored by ROW PAIRS -- the tensor is [ceil(rows / 2), 3*kpad] int16
+    (kpad % 64 == 0): a pair's two rows of kpad fp16 hi values, then kpad / 64 lines of 128 lo bytes (include/mmsa.h); `ld` handed to the
+    library is the pair stride.  Row slices start at even rows; the same layout serves activations and weights."""
 
     def __init__(self, p, n=None, k=None, kpad=None, fmt=FMT_B3, weight=False, split=0):
         self.p = p
         self.split = split   # > 0 (multiple of 32, fmt FMT_B3): columns >= split are h8-encoded (the v third of qkv planes: fp16 hi for the attention kernels' P V)
+        if fmt == FMT_H8C and (n is None or kpad is None):
+            raise RuntimeError("mmsa.Planes: h8c planes need their row count and padded width (the tensor holds row pairs)")
         self.n = p.shape[0] if n is None else n
         self.kpad = p.shape[1] // 2 if kpad is None else kpad
         self.k = self.kpad if k is None else k
@@ -95,18 +100,35 @@ class Planes:
 
     def rows(self, lo, hi=None):
         """Row slice (same columns)."""
+        if self.fmt == FMT_H8C:
+            hi = self.n if hi is None else hi
+            if lo % 2 or (hi % 2 and hi != self.n):
+                raise RuntimeError("mmsa.Planes.rows: h8c planes are stored by row pairs -- slices start and end at even rows")
+            return Planes(self.p[lo // 2:(hi + 1) // 2], hi - lo, self.k, self.kpad, self.fmt, self.weight)
         return Planes(self.p[lo:hi], None, self.k, self.kpad, self.fmt, self.weight, self.split)
 
     def cols(self, lo, hi):
         """Column slice [lo, hi) of the matrix (both multiples of 32): the k-blocks are self-contained in the layout."""
-        if lo % 32 or hi % 32:
-            raise RuntimeError("mmsa.Planes.cols: column bounds must be multiples of 32")
+        if lo % 32 or hi % 32 or self.fmt == FMT_H8C:
+            raise RuntimeError("mmsa.Planes.cols: column bounds must be multiples of 32 (and the planes bf16 hi/lo or h8 line planes)")
         return Planes(self.p[:, 2 * lo:2 * hi], self.n, hi - lo, hi - lo, self.fmt, self.weight)
+
+    def batch_stride(self, rows):
+        """uint16 elements between two batches of `rows` rows each inside these planes (the strided-batched GEMM's stride arguments)."""
+        if self.fmt == FMT_H8C:
+            if rows % 2:
+                raise RuntimeError("mmsa.Planes.batch_stride: h8c batches hold an even number of rows")
+            return (rows // 2) * self.p.stride(0)
+        return rows * self.p.stride(0)
 
     def mat(self, name):
         ptr, rows, cols, ld = _mat(self.p, name, torch.int16)
         if ptr % 128 or ld % 64:
             raise RuntimeError(f"mmsa: {name} planes must be 128-byte aligned with a row stride that is a multiple of 64")
+        if self.fmt == FMT_H8C:      # (pointer, logical rows, padded width, row-PAIR stride)
+            if ld < 3 * self.kpad or self.kpad % 64:
+                raise RuntimeError(f"mmsa: {name}: h8c planes need kpad % 64 == 0 and a pair stride >= 3 * kpad")
+            return ptr, self.n, self.kpad, ld
         return ptr, rows, cols // 2, ld
 
 
@@ -114,11 +136,25 @@ def pad32(k):
     return (k + 31) // 32 * 32
 
 
+def pad64(k):
+    return (k + 63) // 64 * 64
+
+
+def planes_shape(rows, cols, fmt):
+    """(tensor rows, tensor columns, padded width) of the int16 tensor behind Planes of a [rows, cols] matrix."""
+    if fmt == FMT_H8C:
+        kp = pad64(cols)
+        return (rows + 1) // 2, 3 * kp, kp
+    kp = pad32(cols)
+    return rows, 2 * kp, kp
+
+
 def alloc_planes(rows, cols, device, zero=False, fmt=FMT_B3, split=0):
     f = torch.zeros if zero else torch.empty
     if split and (split % 32 or fmt != FMT_B3 or not 0 < split < cols):
         raise RuntimeError(f"mmsa.alloc_planes: split={split} must be a multiple of 32 inside a bf16 hi/lo matrix of {cols} columns")
-    return Planes(f(rows, 2 * pad32(cols), dtype=torch.int16, device=device), rows, cols, pad32(cols), fmt, split=split)
+    tr, tc, kp = planes_shape(rows, cols, fmt)
+    return Planes(f(tr, tc, dtype=torch.int16, device=device), rows, cols, kp, fmt, split=split)
 
 
 def cp_format(pl):
@@ -133,6 +169,13 @@ def planes_to_float(pl, cols=None):
         lo_part = planes_to_float(Planes(pl.p[:, :2 * pl.split], pl.n, pl.split, pl.split, FMT_B3))
         hi_part = planes_to_float(Planes(pl.p[:, 2 * pl.split:], pl.n, pl.kpad - pl.split, pl.kpad - pl.split, FMT_H8))
         return torch.cat([lo_part, hi_part], 1)[:, :(pl.k if cols is None else cols)]
+    if pl.fmt == FMT_H8C:
+        kp = pl.kpad
+        by = pl.p[:, :3 * kp].contiguous().view(torch.uint8).view(r, 6 * kp)
+        hi = by[:, :4 * kp].contiguous().view(torch.float16).float().reshape(2 * r, kp)
+        lo = by[:, 4 * kp:].reshape(r, kp // 64, 2, 4, 2, 8).permute(0, 2, 1, 4, 3, 5)        # [pair, row, chunk, k-tile, g, e]
+        lo = lo.contiguous().view(torch.float8_e5m2).float().reshape(2 * r, kp)
+        return (hi + lo / 2048.0)[:pl.n, :(pl.k if cols is None else cols)]
     if pl.fmt == FMT_H8:
         blk = pl.p.contiguous().view(torch.uint8).view(r, w // 64, 128)
         hi = blk[:, :, :64].contiguous().view(torch.float16).float()                       # [r, nb, 32]
@@ -149,10 +192,21 @@ def split_planes(w2d, kpad=None, out=None, fmt=FMT_B3, weight=False):
     """fp32 [N, K] (device) -> Planes with K zero-padded to a multiple of 32.  fmt FMT_H8: `weight` selects the chunk order of a
     GEMM W operand (q(hi) | lo) instead of an activation's (lo | q(hi))."""
     p, n, k, ld = _mat(w2d, "weight")
-    kpad = kpad or pad32(k)
     if out is None:
-        out = Planes(torch.empty(n, 2 * kpad, dtype=torch.int16, device=w2d.device), n, k, kpad, fmt, weight)
-    kind = 0 if out.fmt == FMT_B3 else (2 if out.weight else 1)
+        kpad = kpad or (pad64(k) if fmt == FMT_H8C else pad32(k))
+        if fmt == FMT_H8C:
+            if kpad % 64:
+                raise RuntimeError("mmsa.split_planes: h8c planes need kpad % 64 == 0")
+            out = Planes(torch.zeros((n + 1) // 2, 3 * kpad, dtype=torch.int16, device=w2d.device), n, k, kpad, fmt, False)
+        else:
+            out = Planes(torch.empty(n, 2 * kpad, dtype=torch.int16, device=w2d.device), n, k, kpad, fmt, weight)
+    kpad = out.kpad
+    if out.fmt == FMT_H8C:
+        if out.n != n or not out.p.is_contiguous() or out.p.shape[1] != 3 * kpad:
+            raise RuntimeError("mmsa.split_planes: dense h8c planes of the source's row count expected")
+        kind = 3
+    else:
+        kind = 0 if out.fmt == FMT_B3 else (2 if out.weight else 1)
     lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), kind, _stream())
     return out
 
@@ -170,7 +224,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
         pa = None
         if ka < w.kpad:
             raise RuntimeError(f"mmsa.gemm: A planes have {ka} columns but the packed weight expects K={w.kpad}")
-        if a.fmt != w.fmt or a.weight or (w.fmt == FMT_H8 and not w.weight):
+        if a.fmt != w.fmt or a.weight or (w.fmt == FMT_H8 and not w.weight) or (w.fmt == FMT_H8C and w.weight):
             raise RuntimeError(f"mmsa.gemm: operand formats differ (A fmt {a.fmt}, W fmt {w.fmt} weight={w.weight})")
     elif fmt != FMT_B3:
         raise RuntimeError("mmsa.gemm: h8 weights need A as h8 planes")

@@ -536,6 +536,146 @@ def test_gemm_h8_exact_on_integers_and_cross_terms(ops):
     assert (out.cpu().double() - exact).abs().max() <= 1e-6
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# "h8c" operand planes (round 4; csrc/common.h, csrc/gemm_h8c.hip): the h8 arithmetic on 3 bytes per element, rows stored in pairs, q(hi) taken
+# in registers as the fp16 value's top byte (truncation)
+def _h8c_emulated_product(a, w):
+    """hi.hi exactly + the two cross terms with q(hi) = the fp16 hi value truncated to its top byte (an e5m2) and lo rounded to e5m2."""
+    ah = a.clamp(-57344, 57344).half()
+    wh = w.clamp(-57344, 57344).half()
+    al, wl = (a - ah.float()) * 2048, (w - wh.float()) * 2048
+    q = lambda t: t.to(torch.float8_e5m2).float()
+    trunc = lambda h: (h.view(torch.int16) & -256).view(torch.float16).float()
+    return ah.double() @ wh.double().t() + (trunc(ah).double() @ q(wl).double().t() + q(al).double() @ trunc(wh).double().t()) / 2048
+
+
+def test_split_planes_h8c_roundtrip_and_layout(ops):
+    x = torch.randn(37, 150, generator=g(241)) * 3
+    p = ops.split_planes(x.to(DEV), fmt=ops.FMT_H8C)
+    assert p.p.shape == (19, 3 * 192) and p.kpad == 192 and p.k == 150 and p.n == 37 and p.fmt == ops.FMT_H8C
+    back = ops.planes_to_float(p, cols=192).cpu()
+    assert back.shape == (37, 192) and torch.all(back[:, 150:] == 0)
+    assert ((back[:, :150] - x).abs() <= x.abs() * 2 ** -13).all()      # 11 bits of hi + 3 of lo
+    raw = p.p.cpu().view(torch.uint8).view(19, 6 * 192)
+    hi = raw[:, :4 * 192].contiguous().view(torch.float16).view(38, 192)   # a pair's two rows of fp16 hi values
+    assert torch.equal(hi[:37, :150].float(), x.half().float())
+    # lo lines: chunk c of pair j = [row 2j: 64 B | row 2j+1: 64 B]; a row's 64 B = 4 groups g of [k = 64c + 8g .. +7 | k = 64c + 32 + 8g .. +7]
+    lo = raw[:, 4 * 192:].reshape(19, 3, 2, 4, 2, 8)
+    want = ((x - x.half().float()) * 2048).to(torch.float8_e5m2).float()
+    r, k = 36, 64 + 32 + 8 * 2 + 5                                         # row 36 (pair 18, first row), chunk 1, second k-tile, group 2, byte 5
+    assert lo[18, 1, 0, 2, 1, 5].view(torch.float8_e5m2).float() == want[r, k]
+    r, k = 7, 3                                                             # row 7 (pair 3, second row), chunk 0, first k-tile, group 0, byte 3
+    assert lo[3, 0, 1, 0, 0, 3].view(torch.float8_e5m2).float() == want[r, k]
+    # row slices start at even rows and are views of the same pairs
+    sub = p.rows(4, 10)
+    assert torch.equal(ops.planes_to_float(sub).cpu(), back[4:10, :150])
+    with pytest.raises(RuntimeError):
+        p.rows(3, 9)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(256, 128, 64, "none"), (300, 192, 128, "none"), (1000, 576, 1024, "gelu"), (4096, 1024, 768, "none"), (135, 130, 192, "relu"),
+                                       (8192, 1024, 4096, "none"), (9800, 3072, 1024, "none")])
+def test_gemm_h8c_operands(ops, M, N, K, act):
+    a = torch.randn(M, K, generator=g(242)) * 1.7
+    w = torch.randn(N, K, generator=g(243)) / K ** 0.5
+    b = torch.randn(N, generator=g(244))
+    res = torch.randn(M, N, generator=g(245))
+    fact = {"none": lambda t: t, "gelu": F.gelu, "relu": F.relu}[act]
+    ref = fact(F.linear(a.double(), w.double(), b.double())).float() + res
+    ap = ops.split_planes(a.to(DEV), fmt=ops.FMT_H8C)
+    wp = ops.split_planes(w.to(DEV), fmt=ops.FMT_H8C)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(ap, wp, out, bias=b.to(DEV), act=act, resid=res.to(DEV))
+    assert_close(out, ref, tol=8e-5, what="h8c gemm vs fp64")
+    emu = fact(_h8c_emulated_product(a, w) + b.double()).float() + res
+    assert_close(out, emu, tol=3e-6, what="h8c gemm vs its emulation")
+    again = torch.empty(M, N, device=DEV)
+    ops.gemm(ap, wp, again, bias=b.to(DEV), act=act, resid=res.to(DEV))
+    assert torch.equal(again, out)
+    # planes outputs: every format out of h8c operands, and h8c planes out of bf16 hi/lo and h8 line operands
+    for ofmt in (ops.FMT_B3, ops.FMT_H8, ops.FMT_H8C):
+        outp = ops.alloc_planes(M, N, DEV, zero=True, fmt=ofmt)
+        ops.gemm(ap, wp, bias=b.to(DEV), act=act, resid=res.to(DEV), out_planes=outp)
+        assert_close(planes_to_float(outp), ref, tol=5e-5 if ofmt == ops.FMT_B3 else 1.5e-4, what=f"h8c gemm planes out fmt {ofmt}")
+        if ofmt == ops.FMT_H8C:    # bit-identical to splitting the fp32 output of the same GEMM
+            assert torch.equal(planes_to_float(outp), planes_to_float(ops.split_planes(out, fmt=ops.FMT_H8C)))
+            both = torch.empty(M, N, device=DEV)
+            outp2 = ops.alloc_planes(M, N, DEV, zero=True, fmt=ofmt)
+            ops.gemm(ap, wp, both, bias=b.to(DEV), act=act, resid=res.to(DEV), out_planes=outp2)
+            assert torch.equal(both, out) and torch.equal(outp2.p, outp.p)
+    if M >= 128:
+        for (af, wf) in ((ops.FMT_B3, ops.FMT_B3), (ops.FMT_H8, ops.FMT_H8)):
+            outp = ops.alloc_planes(M, N, DEV, zero=True, fmt=ops.FMT_H8C)
+            ops.gemm(ops.split_planes(a.to(DEV), kpad=K, fmt=af), ops.split_planes(w.to(DEV), fmt=wf, weight=wf == ops.FMT_H8), bias=b.to(DEV), act=act,
+                     resid=res.to(DEV), out_planes=outp)
+            assert_close(planes_to_float(outp), ref, tol=1.5e-4, what=f"fmt {af} gemm, h8c planes out")
+
+
+def test_gemm_h8c_exact_on_integers_and_cross_terms(ops):
+    M, N, K = 512, 256, 256
+    a = torch.randint(-8, 9, (M, K), generator=g(246)).float()
+    w = torch.randint(-8, 9, (N, K), generator=g(247)).float()
+    w[:, 0] += 100 * torch.arange(N)              # asymmetric: catches row/column swaps
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(ops.split_planes(a.to(DEV), fmt=ops.FMT_H8C), ops.split_planes(w.to(DEV), fmt=ops.FMT_H8C), out)
+    assert torch.equal(out.cpu(), a @ w.t())
+    u = torch.randint(-1, 2, (M, K), generator=g(248)).float()
+    v = torch.randint(-1, 2, (N, K), generator=g(249)).float()
+    a2, w2 = 1 + u * 2 ** -12, 1 + v * 2 ** -12      # hi = 1 (its top byte too), lo = +-2^-12: exact in e5m2 after the 2^11 scaling
+    ops.gemm(ops.split_planes(a2.to(DEV), fmt=ops.FMT_H8C), ops.split_planes(w2.to(DEV), fmt=ops.FMT_H8C), out)
+    exact = (K + (u.sum(1)[:, None] + v.sum(1)[None, :]) * 2 ** -12).double()
+    assert (out.cpu().double() - exact).abs().max() <= 1e-6
+
+
+def test_gemm_h8c_batched_layernorm_fold_and_argument_checks(ops):
+    """Strided-batched h8c operands (the up-conv's per-image batches), the LayerNorm-fold extras on the h8c kernel, and what it refuses."""
+    B, M, N, K = 2, 512, 256, 128
+    a = torch.randn(B * M, K, generator=g(250))
+    w = torch.randn(N, K, generator=g(251)) / K ** 0.5
+    ap, wp = ops.split_planes(a.to(DEV), fmt=ops.FMT_H8C), ops.split_planes(w.to(DEV), fmt=ops.FMT_H8C)
+    out = torch.empty(B * M, N, device=DEV)
+    ops.gemm(ap, wp, out, batch=B, m=M, stride_a=ap.batch_stride(M), stride_c=M * N)
+    assert_close(out, (a.double() @ w.double().t()).float(), tol=8e-5, what="batched h8c gemm")
+    # producer: fp32 + h8c planes + per-row strip sums; consumer: row-normalising epilogue on the raw planes (D = N = 256)
+    xp, rs = ops.alloc_planes(B * M, N, DEV, fmt=ops.FMT_H8C), torch.empty(B * M, 2 * (N // 64), device=DEV)
+    ops.gemm(ap, wp, out, out_planes=xp, rowstats_out=rs)
+    x = out.cpu()
+    assert_close(rs.view(B * M, N // 64, 2)[:, :, 0].sum(1).cpu(), x.sum(1), tol=1e-5, what="strip sums")
+    mr = torch.empty(B * M, 2, device=DEV)
+    ops.rowstats_finalize(rs, B * M, N, 1e-6, mr)
+    w2 = torch.randn(128, N, generator=g(252)) / N ** 0.5
+    lnw, lnb, b2 = torch.randn(N, generator=g(253)) * 0.3 + 1, torch.randn(N, generator=g(254)) * 0.1, torch.randn(128, generator=g(255))
+    wf = ops.split_planes((w2 * lnw[None]).to(DEV), fmt=ops.FMT_H8C)
+    cs = ops.planes_to_float(wf).double().sum(1).float().contiguous()
+    bf = (w2.double() @ lnb.double()).float().add_(b2).to(DEV)
+    hp = ops.alloc_planes(B * M, 128, DEV, fmt=ops.FMT_H8C)
+    ops.gemm(xp, wf, bias=bf, act="gelu", out_planes=hp, row_norm=(mr, cs))
+    ref = F.gelu(F.linear(F.layer_norm(x.double(), (N,), lnw.double(), lnb.double(), 1e-6), w2.double(), b2.double())).float()
+    assert_close(planes_to_float(hp), ref, tol=3e-4, what="h8c consumer GEMM with the LayerNorm folded")
+    with pytest.raises(RuntimeError):     # K % 64 != 0
+        ops.gemm(ops.split_planes(torch.randn(128, 96, device=DEV), kpad=96), ops.split_planes(torch.randn(64, 96, device=DEV), fmt=ops.FMT_H8C), out)
+    with pytest.raises(RuntimeError):     # operand formats differ
+        ops.gemm(ops.split_planes(torch.randn(128, 128, device=DEV), fmt=ops.FMT_H8), wp, out)
+    small = torch.randn(50, K, generator=g(259))     # fewer rows than a tile: rows beyond M are clamped on the way in and masked on the way out
+    o50 = torch.empty(50, N, device=DEV)
+    ops.gemm(ops.split_planes(small.to(DEV), fmt=ops.FMT_H8C), wp, o50)
+    assert_close(o50, (small.double() @ w.double().t()).float(), tol=8e-5, what="h8c gemm, 50 rows")
+
+
+@pytest.mark.parametrize("rows,C", [(96, 64), (300, 1024), (50, 100), (33, 1280)])
+def test_layernorm_h8c_planes(ops, rows, C):
+    x = torch.randn(rows, C, generator=g(256)) * 2 + 0.3
+    w, b = torch.randn(C, generator=g(257)), torch.randn(C, generator=g(258))
+    y = F.layer_norm(x, (C,), w, b, 1e-6)
+    p = ops.alloc_planes(rows, C, DEV, zero=True, fmt=ops.FMT_H8C)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out_planes=p)
+    got = planes_to_float(p).cpu()
+    assert ((got - y).abs() <= y.abs() * 2 ** -12 + 1e-5).all()
+    yk = torch.empty(rows, C, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out=yk)
+    assert torch.equal(planes_to_float(p), planes_to_float(ops.split_planes(yk, fmt=ops.FMT_H8C)))
+
+
 def test_gemm_h8_argument_checks(ops):
     a = ops.split_planes(torch.randn(128, 96, device=DEV), fmt=ops.FMT_H8)
     w = ops.split_planes(torch.randn(64, 96, device=DEV), fmt=ops.FMT_H8, weight=True)

@@ -30,22 +30,23 @@ def worker():
     dev = "cuda:0"
     res = []
     for (label, M, N, K, b, act, outk, resid) in SHAPES:
-        h8 = os.environ.get("MMSA_ABLATE_FMT") == "h8" and K % 64 == 0   # operand format (random normal data either way: the clock the chip holds depends on the data)
-        fmt = ops.FMT_H8 if h8 else ops.FMT_B3
+        want = os.environ.get("MMSA_ABLATE_FMT", "b3")   # operand format: b3 | h8 | h8c (random normal data either way: the clock the chip holds depends on the data)
+        h8 = want == "h8" and K % 64 == 0
+        fmt = ops.FMT_H8C if (want == "h8c" and K % 64 == 0) else ops.FMT_H8 if h8 else ops.FMT_B3
         a = ops.split_planes(torch.randn(b * M, K, device=dev), kpad=K, fmt=fmt)
         w = ops.split_planes(torch.randn(b * N, K, device=dev) / K ** 0.5, fmt=fmt, weight=h8)
-        w = ops.Planes(w.p, N, K, w.kpad, fmt, h8)
+        w = ops.Planes(w.p, N, K, w.kpad, fmt, h8)   # the first batch's view (batch stride passed explicitly)
         bias = torch.randn(b * N, device=dev)
         kw = {}
         if outk == "P":
             op = ops.alloc_planes(b * M, N, dev, fmt=fmt)
-            kw.update(out_planes=op, stride_cp=M * 2 * op.kpad)
+            kw.update(out_planes=op, stride_cp=op.batch_stride(M))
         else:
             c = torch.randn(b * M, N, device=dev)
             kw.update(out=c, stride_c=M * N)
             if resid:
                 kw.update(resid=c, stride_r=M * N)
-        kw.update(batch=b, m=M, stride_a=M * 2 * a.kpad, stride_w=N * 2 * w.kpad, stride_bias=N)
+        kw.update(batch=b, m=M, stride_a=a.batch_stride(M), stride_w=w.batch_stride(N), stride_bias=N)
         for _ in range(3):
             ops.gemm(a, w, bias=bias, act=act, **kw)
         torch.cuda.synchronize()
@@ -65,9 +66,11 @@ if __name__ == "__main__":
         sys.exit(0)
     print("mode      " + " ".join(f"{s[0]:>8s}" for s in SHAPES))
     flops = [2.0 * s[1] * s[2] * s[3] * s[4] for s in SHAPES]
-    knobs = os.path.join(ROOT, "ab", "libmmsa_knobs.so")
-    if not os.path.exists(knobs) or os.path.getmtime(knobs) < os.path.getmtime(os.path.join(ROOT, "multimodal-sam-adapter_amd", "csrc", "gemm_v2.hip")):
-        subprocess.run(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "ab/libmmsa_knobs.so", "gemm_v2.hip", "-DMMSA_DEBUG_KNOBS"], check=True)
+    knobs = os.path.join(ROOT, "ab", os.environ.get("MMSA_ABLATE_LIB", "libmmsa_knobs.so"))
+    csrc = os.path.join(ROOT, "multimodal-sam-adapter_amd", "csrc")
+    if not os.path.exists(knobs) or os.path.getmtime(knobs) < max(os.path.getmtime(os.path.join(csrc, f)) for f in ("gemm_v2.hip", "gemm_h8c.hip", "gemm_v2_epilogue.inc")):
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "ab/" + os.path.basename(knobs), "gemm_v2.hip,gemm_h8c.hip", "-DMMSA_DEBUG_KNOBS"]
+                       + os.environ.get("MMSA_ABLATE_DEFS", "").split(), check=True)
     for mode in (sys.argv[1:] or ["0", "10", "1", "2"]):
         env = dict(os.environ, MMSA_GEMM_DEBUG=mode, MMSA_LIB=knobs)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=env, capture_output=True, text=True)
