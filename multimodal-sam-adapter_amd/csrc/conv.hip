@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
 // lane-pair exchange) plus, per pixel and 64-channel chunk, (sum, sum of squares) of the values stored: rs[((img * H * W + pixel) *
 // rs_strips + chunk) * 2 + {0, 1}], the strip sums mmsa_rowstats_finalize turns into (mean, rstd) for a row-normalising GEMM epilogue.
 // Requires C % 64 == 0, H % 8 == 0, W % 8 == 0 (every lane of the workgroup stays active: checked by the launcher).
+// Round 4 measured where its time goes (tools/exp/dw7_abl.hip, profiles/r04_dwconv7_ablation.txt: stage 2, 20.0 us = 12.9 us of loads + stores with one
+// tap + 11.2 us of LDS reads / tap weights / FMAs, barely overlapped) and a persistent variant that slides down a column of tiles through a 14-row
+// LDS ring with the tap weights in LDS (7 instead of 13 halo loads per lane, next rows requested under the arithmetic): bit-identical, not faster
+// (20.3 ... 26 us), so it stayed in tools/exp/.
 __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restrict__ x, long ldx, long xstrideB,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ y, long ldy, long ystrideB,

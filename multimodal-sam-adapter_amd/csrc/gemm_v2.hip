@@ -562,7 +562,9 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   // CU, 2-slot ring: one workgroup's epilogue under the other's k loop; profiles/r03_gemm_flavour4.txt: -9 ... -12 % there, slower on
   // every deeper shape).  `flavour` = 4 / 8 forces one (tests, A/B runs); results are bit-identical either way.  (bf16 planes only.)
   MMSA_CHECK_ARG(flavour == 0 || flavour == 4 || flavour == 8, "gemm(v2): flavour %d (0 = by shape, 4, 8)", flavour);
-  const int nw = (h8 || rs_out || rn_mr) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) ? 4 : 8);
+  // (not under a grid cap: a caller that runs concurrent chains gives each GEMM `max_grid` workgroups so that it holds that many CUs; 2 x
+  // max_grid half-size workgroups would be spread over twice as many CUs and their 64 KiB each would shut the other chain's 144 KiB workgroups out)
+  const int nw = (h8 || rs_out || rn_mr) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) && max_grid <= 0 ? 4 : 8);
   const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
   a.nbm = cdiv(M, bm);
   a.bn = V2_BN;

@@ -65,18 +65,23 @@ class Chains:
                 # pass 1, eager: every chain runs its OWN sub-batch once -- allocates its scratch buffers (and the shared logits) and, with
                 # the backbone's attention guard on, shows every image of the batch to the per-block precision decision BEFORE anything is
                 # captured (a block that moves to bf16 hi/lo operands gets new weight planes: a graph captured earlier would point at the old ones)
-                origin = []
+                self._warm = []
                 for i in range(self.n):
                     s = torch.cuda.Stream(device=dev)
+                    self._warm.append(s)
                     s.wait_stream(torch.cuda.current_stream(dev))
                     with torch.cuda.stream(s):
                         self._step(i, x[i * bc:(i + 1) * bc])
                     torch.cuda.synchronize(dev)
-                    origin.append(s)
-                # pass 2: one graph per chain
+                # pass 2: one graph per chain.  Creation order per chain: capture stream, graph (its instantiation creates the streams of its
+                # parallel branches), replay stream -- the runtime deals its hardware queues to streams in creation order, and with the
+                # streams of both chains created first the chains' branches shared queues: 37.8 ms per step instead of 32.6
+                # (profiles/r04_chains_streams.txt)
                 for i in range(self.n):
+                    s = torch.cuda.Stream(device=dev)
+                    s.wait_stream(torch.cuda.current_stream(dev))
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=origin[i]):
+                    with torch.cuda.graph(g, stream=s):
                         feats = self._step(i, x[i * bc:(i + 1) * bc])
                     torch.cuda.synchronize(dev)
                     self.graphs.append(g)
