@@ -76,11 +76,15 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, G = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // XCD-contiguous order (common.h): the query blocks of one (image, head) -- which all read that head's K and V -- run on ONE XCD, so its L2 holds
+  // them; in dispatch order they went to all eight (614 MB read per launch for 60 MB of q, k, v: profiles/r04_xcd_order.txt)
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());
+  const int bx_ = (int)(wg_ % gridDim.x);
+  const int head = (int)((wg_ / gridDim.x) % gridDim.y), b = (int)(wg_ / (gridDim.x * gridDim.y));
   const int T = a.H * a.W;
   const int nqb = (a.Nk + 127) / 128;
-  const int grp = blockIdx.x / nqb;
-  const int q0 = (blockIdx.x % nqb) * 128;
+  const int grp = bx_ / nqb;
+  const int q0 = (bx_ % nqb) * 128;
   const int wi = a.ws ? grp / a.nWw : 0, wj = a.ws ? grp % a.nWw : 0;
 
   // group index j -> token (or -1 for a zero-pad token, -2 for "does not exist")

@@ -43,6 +43,28 @@ static inline int mmsa_knob_env(const char* name, int dflt) { const char* v = ge
     }                                                                        \
   } while (0)
 
+// XCD-aware workgroup order (round 4).  The dispatcher deals the workgroups of a launch round-robin to the 8 XCDs in dispatch order (x fastest, then
+// y, z), and each XCD has its own L2: neighbouring workgroups -- the rows above and below in a 3 x 3 stencil, the query blocks that read the same
+// K / V, the queries that gather from the same patch of the value map -- land on eight different L2s and each fetches its own copy (measured: 3 x the
+// input bytes for the neck's pair conv, 8 x the value map for the deformable-attention gather, 10 x K / V for global attention).  mmsa_xcd_order maps
+// the dispatch-order id to a work index such that every XCD walks ONE contiguous eighth of the work in order.  A pure permutation of work indices:
+// results do not depend on it (build with -DMMSA_XCD_ORDER=0 for the A/B).
+#ifndef MMSA_XCD_ORDER
+#define MMSA_XCD_ORDER 1
+#endif
+__device__ __forceinline__ unsigned mmsa_xcd_order(unsigned lin, unsigned total) {
+#if MMSA_XCD_ORDER
+  const unsigned per = total >> 3;
+  return lin < (per << 3) ? (lin & 7u) * per + (lin >> 3) : lin;
+#else
+  (void)total;
+  return lin;
+#endif
+}
+// dispatch-order id of this workgroup / number of workgroups of the launch
+__device__ __forceinline__ unsigned mmsa_block_lin() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+__device__ __forceinline__ unsigned mmsa_block_count() { return gridDim.x * gridDim.y * gridDim.z; }
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B operand (8 bf16 = 4 VGPR)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 accumulator

@@ -17,12 +17,14 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
   // one thread per (pixel, 4 channels); blockIdx.y = image row (b*H + h): 32-bit index arithmetic only
   const int c4n = C >> 2;
   const int pad = k >> 1;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
+  const int idx = bx_ * 256 + threadIdx.x;
   if (idx >= W * c4n) return;
   {
     const int ww = idx / c4n;
     const int c = (idx - ww * c4n) * 4;
-    const int hh = blockIdx.y % H, b = blockIdx.y / H;
+    const int hh = by_ % H, b = by_ / H;
     const float* xb = x + (long)b * xstrideB;
     float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int kh = 0; kh < k; ++kh) {
@@ -62,15 +64,18 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
                                                             float* __restrict__ rs, int rs_strips,
                                                             int H, int W, int C, int tilesX, int imgs_per_group, long w_gstride) {
   constexpr int TW = 14, CB = 64;
+  // XCD-contiguous tiles (common.h): the tiles of a (channel chunk, image) -- whose halos overlap -- stay on one XCD's L2
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)((wg_ / gridDim.x) % gridDim.y), bz_ = (int)(wg_ / (gridDim.x * gridDim.y));
   if (imgs_per_group > 0) {   // image groups (the two ConvNeXt streams stacked along the batch) with their own weights
-    const int grp = blockIdx.z / imgs_per_group;
+    const int grp = bz_ / imgs_per_group;
     w += (long)grp * w_gstride;
     if (bias) bias += (long)grp * C;
   }
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [14][14][64]
-  const int b = blockIdx.z;
-  const int c0 = blockIdx.y * CB;
-  const int tx0 = (blockIdx.x % tilesX) * 8, ty0 = (blockIdx.x / tilesX) * 8;
+  const int b = bz_;
+  const int c0 = by_ * CB;
+  const int tx0 = (bx_ % tilesX) * 8, ty0 = (bx_ / tilesX) * 8;
   const float* xb = x + (long)b * xstrideB;
   const int cvalid = min(CB, C - c0);   // multiple of 4
   // halo tile: all 13 loads of a lane are issued before the first LDS write (a rolled load -> store loop serialised 13
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
         float s2 = fmaf(acc[p].x, acc[p].x, acc[p].y * acc[p].y) + fmaf(acc[p].z, acc[p].z, acc[p].w * acc[p].w);
 #pragma unroll
         for (int sh = 8; sh > 0; sh >>= 1) { s1 += __shfl_xor(s1, sh, 64); s2 += __shfl_xor(s2, sh, 64); }
-        if (cv == 0) *reinterpret_cast<float2*>(rs + (((long)b * H * W + pix) * rs_strips + blockIdx.y) * 2) = make_float2(s1, s2);
+        if (cv == 0) *reinterpret_cast<float2*>(rs + (((long)b * H * W + pix) * rs_strips + by_) * 2) = make_float2(s1, s2);
       }
     }
   }
@@ -170,11 +175,13 @@ __global__ __launch_bounds__(256) void dwconv3_nhwc_kernel(const float* __restri
                                                            unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
                                                            int B, int H, int W, int C, int act) {
   const int c4n = C >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
+  const int idx = bx_ * 256 + threadIdx.x;
   if (idx >= W * c4n) return;
   const int ww = idx / c4n;
   const int c = (idx - ww * c4n) * 4;
-  const int hh = blockIdx.y % H, b = blockIdx.y / H;
+  const int hh = by_ % H, b = by_ / H;
   const float* xb = x + (long)b * xstrideB + c;
   float4 v[9], f[9];
 #pragma unroll
@@ -275,6 +282,8 @@ __global__ __launch_bounds__(256) void gconv_tiled_kernel(const float* __restric
                                                           float* __restrict__ y, long ldy, int H, int W, int cin_g, int tilesX) {
   constexpr int PAD = K / 2, TW = 16 + 2 * PAD, CCH = 8;
   __shared__ float tile[CCH][TW * TW];
+  // (dispatch order on purpose: tiles fastest, so XCD k gets tiles k, k + 8, ... of EVERY group, and the groups of a pixel share cache lines --
+  // cin_g = 3 ... 9 floats; an XCD-contiguous order, common.h, gave each XCD whole groups and 7 x the reads: profiles/r04_xcd_order.txt)
   const int g = blockIdx.y, b = blockIdx.z;
   const int tx0 = (blockIdx.x % tilesX) * 16, ty0 = (blockIdx.x / tilesX) * 16;
   const int px = threadIdx.x & 15, py = threadIdx.x >> 4;

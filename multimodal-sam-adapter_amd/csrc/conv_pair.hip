@@ -18,11 +18,13 @@
 __global__ __launch_bounds__(256) void dwpair_nhwc_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                           float* __restrict__ y, long ldy, int B, int H, int W, int C) {
   const int c4n = C >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
+  const int idx = bx_ * 256 + threadIdx.x;
   if (idx >= W * c4n) return;
   const int ww = idx / c4n;
   const int c = (idx - ww * c4n) * 4;
-  const int hh = blockIdx.y % H, b = blockIdx.y / H;
+  const int hh = by_ % H, b = by_ / H;
   const float* xb = x + (long)b * H * W * ldx + c;
   const float* wa = w + (long)(c >> 1) * 36;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -54,11 +56,13 @@ __global__ __launch_bounds__(256) void dwpair_gate_kernel(const float* __restric
                                                           float* __restrict__ y, long ldy, unsigned short* __restrict__ yp, long ldp,
                                                           int H, int W, int C) {
   const int c4n = C >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
+  const int idx = bx_ * 256 + threadIdx.x;
   if (idx >= W * c4n) return;
   const int ww = idx / c4n;
   const int c = (idx - ww * c4n) * 4;
-  const int hh = blockIdx.y % H, b = blockIdx.y / H;
+  const int hh = by_ % H, b = by_ / H;
   const float* xb = x + (long)b * H * W * ldx + c;
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
 #pragma unroll
@@ -112,12 +116,14 @@ __global__ __launch_bounds__(256) void dwpair_gate4_kernel(const float* __restri
                                                            float* __restrict__ y, long ldy, unsigned short* __restrict__ yp, long ldp,
                                                            int H, int W, int C) {
   const int c4n = C >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
+  const int idx = bx_ * 256 + threadIdx.x;
   if (idx >= (W >> 2) * c4n) return;
   const int wq = idx / c4n;
   const int c = (idx - wq * c4n) * 4;
   const int w0 = wq * 4;
-  const int hh = blockIdx.y % H, b = blockIdx.y / H;
+  const int hh = by_ % H, b = by_ / H;
   const float* xb = x + (long)b * H * W * ldx + c;
   float4 a1[4], a2[4];
 #pragma unroll

@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
   constexpr int NTW = (NT == 2) ? 48 : NT * 16;              // weight row stride: 16 / 48 / 48 / 80 floats
   __shared__ float halo[CCH * CST];
   __shared__ float wch[9 * CCH * NTW];
+  // (dispatch order on purpose: tiles fastest, so XCD k gets tiles k, k + 8, ... of EVERY group, and the groups of a pixel share cache lines --
+  // cin_g = 3 ... 9 floats; an XCD-contiguous order, common.h, gave each XCD whole groups and 7 x the reads: profiles/r04_xcd_order.txt)
   const int g = blockIdx.y, b = blockIdx.z;
   const int tx0 = (blockIdx.x % tilesX) * 16, ty0 = (blockIdx.x / tilesX) * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

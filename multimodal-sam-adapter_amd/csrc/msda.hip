@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void msda_kernel(
   const int op_kpad = MMSA_PAD64(M * D);        // h8c output planes: fp16 values per row
   // 32-bit index arithmetic (N*Lq*M*d4 < 2^32, checked by the launcher): the four 64-bit div/mod of the first version
   // were a quarter of the kernel's instructions
-  const unsigned pair = (blockIdx.x * blockDim.x + threadIdx.x) / (unsigned)d4;
+  // XCD-contiguous query order (common.h): a workgroup = a few queries x all heads; queries that are neighbours in the map sample the same patch of
+  // the value map, so every XCD walks one contiguous eighth of the queries (in dispatch order each XCD's L2 pulled the whole value map)
+  const unsigned pair = (mmsa_xcd_order(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) / (unsigned)d4;
   const int c = ((threadIdx.x) % d4) * 4;       // blockDim.x is a multiple of d4 (msda_block)
   const unsigned npairs = (unsigned)N * (unsigned)Lq * (unsigned)M;
   if (pair >= npairs) return;

@@ -38,12 +38,15 @@ __device__ __forceinline__ bool gram_block_needed(int bi, int bj, int c, int nbl
 __global__ __launch_bounds__(256) void gram_part_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
                                                         long strideB, float4* __restrict__ part, int P, int c, int nblk, int nslice) {
   const int nb = (c + GR_BLK - 1) / GR_BLK;
-  const int bi = blockIdx.x / nb, bj = blockIdx.x % nb;
+  // XCD-contiguous order (common.h): the nb x nb blocks of one row slice read the same rows of X and Y -- they stay on one XCD's L2
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());
+  const int bx_ = (int)(wg_ % gridDim.x);
+  const int bi = bx_ / nb, bj = bx_ % nb;
   if (!gram_block_needed(bi, bj, c, nblk)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, kk = lane >> 4;
-  const int b = blockIdx.z;
-  const int slice = blockIdx.y;
+  const int b = (int)(wg_ / (gridDim.x * gridDim.y));
+  const int slice = (int)((wg_ / gridDim.x) % gridDim.y);
   const int u0 = 3 * (wave >> 1), v0 = 3 * (wave & 1);
   const float* Xb = X + (long)b * strideB;
   const float* Yb = Y + (long)b * strideB;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void gram_part_kernel(const float* __restrict_
   }
 #undef GR_LOADS
 #undef GR_MFMAS
-  float4* dst = part + ((((long)b * nb * nb + blockIdx.x) * nslice + slice) * (GR_T * GR_T)) * 64 + lane;
+  float4* dst = part + ((((long)b * nb * nb + bx_) * nslice + slice) * (GR_T * GR_T)) * 64 + lane;
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
