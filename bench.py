@@ -501,7 +501,7 @@ def main():
             mfma = {"gemm_family_mfma_util_pct": round(mj["gemm_family"]["mfma_util_pct"], 1), "gemm_family_mfma_tflops_counted": round(mj["gemm_family"]["mfma_tflops"], 1),
                     "whole_step_mfma_util_pct": round(mj["whole_step"]["mfma_util_pct"], 1), "whole_step_mfma_tflops_counted": round(mj["whole_step"]["mfma_tflops"], 1),
                     "source": "rocprofv3 --pmc MfmaUtil and --pmc SQ_INSTS_VALU_MFMA_MOPS_{BF16,F16,F8,F32} passes of this workload; " + mnote}
-        roofline = {"bound": "mfma", "kernel": "split-operand GEMM (gemm_v2_kernel bf16 hi/lo and h8 flavours + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": "split-operand GEMM (gemm_h8c_kernel + gemm_v2_kernel bf16 hi/lo and h8 flavours + gemm_split3_kernel)", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                     "compulsory_bytes_per_launch": round(mmsa.ops.collect_gemm_profile.bytes / max(len(prof), 1)),
                     "launches_per_step": len(prof), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
@@ -586,7 +586,7 @@ def main():
             "metric": f"images/sec encoder fwd @{size}x{size} RGB+LiDAR {arch}" if not STUB else "stub (no GPU): control path of the N > 1 bench",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, bf16 hi/lo (and bf16 hi/lo block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
+            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8c / h8 planes, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, bf16 hi/lo (and bf16 hi/lo block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else

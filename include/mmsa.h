@@ -124,6 +124,10 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * flavour: 0 = workgroup shape chosen by the problem (256-row ping-pong tiles; 128-row tiles, two workgroups per CU, for bf16 hi/lo
  * operands with K <= 256); 4 / 8 force the 128- / 256-row form (tests, A/B runs).  Results are bit-identical either way. */
 int mmsa_rowstats_finalize(const float* rowstats, int rows, int strips, int D, float eps, float* mean_rstd, mmsa_stream_t stream);
+
+/* Zero-fill `bytes` bytes at p on `stream` (hipMemsetAsync): the statistics blocks the neck's kernels accumulate into.  Host-side mirror: the
+ * `.zero_()` calls of the reference's own accumulator initialisations are torch kernels; inside a captured step every node is the library's. */
+int mmsa_zero_bytes(void* p, size_t bytes, mmsa_stream_t stream);
 int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      const uint16_t* Wp, long strideW,
                      const float* bias, long strideBias, const float* colscale, const float* resid, long ldr,

@@ -363,3 +363,15 @@ extern "C" int mmsa_rowstats_finalize(const float* rowstats, int rows, int strip
   MMSA_CHECK_LAUNCH("rowstats_finalize");
   return MMSA_OK;
 }
+
+// Zero-fill of a scratch range on the caller's stream (the neck's double-precision statistics block): the forward keeps no framework kernel
+// inside a captured step.
+extern "C" int mmsa_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
+  MMSA_CHECK_ARG(p && bytes > 0, "zero_bytes: bad args");
+  const hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+  if (e != hipSuccess) {
+    mmsa_set_error("zero_bytes: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return MMSA_ERR_LAUNCH;
+  }
+  return MMSA_OK;
+}

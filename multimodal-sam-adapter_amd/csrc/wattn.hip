@@ -47,7 +47,21 @@ struct WAttnArgs {
                                         // folded in with one atomic max per wave (include/mmsa.h "attention logit guard")
   unsigned magic;                       // ceil(65536 / ws): j / ws == (j * magic) >> 16 for j < 224 (checked on the host)
   float scale;
+#ifdef MMSA_DEBUG_KNOBS
+  long long* stamps;                    // debug builds only: shader-clock stamps of workgroup 0, waves 0 and 6, first 8 items x 16 slots
+#endif
 };
+#ifdef MMSA_DEBUG_KNOBS   // tools/wattn_bench.py --stamps (tools/build_variant.sh ... -DMMSA_DEBUG_KNOBS); the release library has neither
+static long long* g_wattn_stamps = nullptr;
+extern "C" int mmsa_debug_wattn_stamps(long long* p) { g_wattn_stamps = p; return MMSA_OK; }
+#define WP_STAMP(k_)                                                                                                         \
+  do {                                                                                                                       \
+    if (a.stamps && blockIdx.x == 0 && (wave == 0 || wave == 6) && lane == 0 && nst_ < 8)                                    \
+      a.stamps[((wave ? 1 : 0) * 8 + nst_) * 16 + (k_)] = (long long)__builtin_amdgcn_s_memtime();                           \
+  } while (0)
+#else
+#define WP_STAMP(k_) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // PERSISTENT kernel: one workgroup per CU walks the (window, head, image) items.  Measured on the round-1 one-shot kernel
@@ -183,6 +197,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
   const float sc2 = a.scale * LOG2E, rscale = 1.0f / a.scale;
   bool first = true;
   float amax = 0.f;
+  int nst_ = 0;   // items done (stamps of debug builds)
 
 #pragma unroll 1
   for (;;) {
@@ -194,7 +209,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
     // rel-pos terms and the bias operand need only Q and the table image: done BEFORE barrier #1, in the time a wave
     // would otherwise wait for the slowest wave's PV / K transfer
     bf16x8 bqh = {0, 0, 0, 0, 0, 0, 0, 0}, bql = {0, 0, 0, 0, 0, 0, 0, 0};
+    WP_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q(i) (and this wave's K(i) DMA: older, so it has landed too)
+    WP_STAMP(1);
     if (first) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); first = false; }   // table image of all waves
     if (any_live) {
       // rel-pos terms T[i][q] = rel_pos[i] . q (table fragments from the LDS image), re-indexed per query by key coordinate
@@ -253,9 +270,11 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       }
     }
     // ---- barrier #1
+    WP_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    WP_STAMP(3);
     WP_ISSUE_V()
 
     f32x4 s[13];
@@ -289,7 +308,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
     }
     // ---- barrier #2: the K image and this wave's Q registers are free
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WP_STAMP(4);
     __syncthreads();
+    WP_STAMP(5);
     const int it_next = it + gridDim.x;
     const bool has_next = it_next < nitems;
     if (has_next) {
@@ -324,9 +345,12 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       mxs = mx;
     }
     // ---- barrier #3: V(i) landed (the 4 K DMA instructions of the next item, issued later, stay in flight)
+    WP_STAMP(6);
     if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WP_STAMP(7);
     __syncthreads();
+    WP_STAMP(8);
     if (any_live) {
       int lane_o = lane;   // opaque copy: the 28 transposed-read addresses below must not be hoisted out of the item loop
       asm volatile("" : "+v"(lane_o));
@@ -400,6 +424,8 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
           store_planes8_pair_any<16>(a.op, a.ldo, orow, MMSA_PAD64(a.D), head_cur * 64 + 16 * d + 8 * (G >> 1), make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv), a.ofmt, G & 1, tq_cur >= 0);
       }
     }
+    WP_STAMP(9);
+    ++nst_;
     if (!has_next) break;
     it = it_next;
     WP_LOAD_Q()   // (register pressure: loading them before PV spilled)
@@ -431,6 +457,9 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
   a.B = B; a.H = H; a.W = W; a.heads = heads; a.D = D; a.ws = window_size; a.scale = scale;
   a.nWw = cdiv(W, window_size);
   a.guard = max_abs_logit;
+#ifdef MMSA_DEBUG_KNOBS
+  a.stamps = g_wattn_stamps;
+#endif
   a.magic = (unsigned)((65536 + window_size - 1) / window_size);
   for (int j = 0; j < WA_NKV; ++j)   // the kernel's multiply-shift division must be exact for every index it divides
     if ((int)(((unsigned)j * a.magic) >> 16) != j / window_size) {

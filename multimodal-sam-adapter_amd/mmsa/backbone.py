@@ -699,7 +699,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             if getattr(self, "_pipe_stream", None) is None or self._pipe_stream.device != x_next.device:
                 self._pipe_stream = torch.cuda.Stream(device=x_next.device)
             sa = self._pipe_stream
-            self._ws.get("pl_tick", 1, 1).zero_()   # a node before the fork: forking off a capture stream that has recorded nothing yet crashed hipStreamEndCapture
+            ops.zero_(self._ws.get("pl_tick", 1, 1))   # a node before the fork: forking off a capture stream that has recorded nothing yet crashed hipStreamEndCapture
             sa.wait_stream(main)
             with torch.cuda.stream(sa):
                 joins = self._spm(x_next, B, H, W, c1, cbuf, Nc, join=False)
@@ -1145,7 +1145,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # ONE memset at the head of the level -- a memset node per call was 24 per forward (0.1-0.2 ms per step; the Grams need none)
         n_st, n_g, n_st2 = B * 3 * 3 * c, B * c * c, B * 3 * C
         acc_blk = ws.get("nk_acc", 1, 2 * (n_st + n_g) + n_g + n_st2, dtype=torch.float64)
-        acc_blk[0, :2 * n_st + n_st2].zero_()
+        ops.zero_(acc_blk[0, :2 * n_st + n_st2])
         gram_scr = ws.get("nk_gscr", 1, (ops.gram_tn_scratch_bytes(B, HW, c) + 3) // 4)
         acc_off = [0, 2 * n_st + n_st2]
 

@@ -35,11 +35,11 @@ class Chains:
             try:
                 feats, _ = self.backbone(xs)
                 if self.head is not None:
-                    lg = self.head(feats)
-                    if self.logits is None:
-                        self.logits = torch.empty(self.x.shape[0], *lg.shape[1:], device=lg.device)
                     bc = xs.shape[0]
-                    self.logits[i * bc:(i + 1) * bc].copy_(lg)
+                    if self.logits is None:      # first call: learn the logits' shape from a stand-alone head pass
+                        lg = self.head(feats)
+                        self.logits = torch.empty(self.x.shape[0], *lg.shape[1:], device=lg.device)
+                    self.head(feats, out=self.logits[i * bc:(i + 1) * bc])   # the chain writes its slice of the step's logits itself
             finally:
                 if self.head is not None:
                     self.head.buf_tag = ""

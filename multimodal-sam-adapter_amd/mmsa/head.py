@@ -123,14 +123,16 @@ class SegformerHead(nn.Module):
         return ops.Planes(self._buf(name, (rows, 2 * kp), torch.int16, dev), rows, cols, kp)
 
     @torch.no_grad()
-    def forward(self, inputs):
+    def forward(self, inputs, out=None):
+        """out: optional preallocated fp32 [B, num_classes, H/4, W/4] GPU tensor to write the logits into (mmsa.Chains gives every chain its slice
+        of the step's logits); default: a fresh tensor per call, like the reference's."""
         x0 = inputs[self.in_index[0]]
         if not x0.is_cuda:
             raise RuntimeError("mmsa SegformerHead: inputs must live on the GPU (there is no CPU path)")
         with torch.cuda.device(x0.device):    # launches go to the current stream of the tensors' device
-            return self._forward(inputs)
+            return self._forward(inputs, out)
 
-    def _forward(self, inputs):
+    def _forward(self, inputs, out=None):
         xs = [inputs[i] for i in self.in_index]          # BaseDecodeHead._transform_inputs('multiple_select')
         x0 = xs[0]
         dev = x0.device
@@ -169,6 +171,9 @@ class SegformerHead(nn.Module):
                  ops._stream())
         lt = self._buf("logit_tokens", (B * H * W, pk["ncp"]), dev=dev)
         ops.gemm(fp, pk["wc"], lt, bias=pk["bc"])
-        out = torch.empty(B, self.num_classes, H, W, device=dev)   # a fresh tensor per call, like the reference's (no aliasing across calls)
+        if out is None:
+            out = torch.empty(B, self.num_classes, H, W, device=dev)   # a fresh tensor per call, like the reference's (no aliasing across calls)
+        elif (tuple(out.shape) != (B, self.num_classes, H, W) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous()):
+            raise RuntimeError(f"mmsa SegformerHead: out must be a contiguous fp32 [{B}, {self.num_classes}, {H}, {W}] tensor on {dev}")
         lib.call("mmsa_tokens_to_nchw", lt.data_ptr(), pk["ncp"], out.data_ptr(), B, H * W, self.num_classes, ops._stream())
         return out

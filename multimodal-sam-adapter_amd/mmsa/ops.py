@@ -255,9 +255,10 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
              _chk(rowstats_out), _chk(row_norm[0]) if row_norm else None, _chk(row_norm[1]) if row_norm else None, GEMM_FLAVOUR, _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
-        nout = (1 if out is not None else 0) + (1 if out_planes is not None else 0)
+        ob = 3.0 if fmt == FMT_H8C else 4.0          # bytes per operand element (h8c planes: 3)
+        pb = 0.0 if out_planes is None else (3.0 if out_planes.fmt == FMT_H8C else 4.0)
         prof.append((2.0 * m * w.n * w.k * batch, e0, e1,
-                     4.0 * batch * (m * w.kpad + w.n * w.kpad + m * w.n * (nout + (1 if resid is not None else 0)))))
+                     batch * (ob * (m * w.kpad + w.n * w.kpad) + m * w.n * (pb + 4.0 * ((1 if out is not None else 0) + (1 if resid is not None else 0))))))
         if GEMM_SHAPES is not None:
             GEMM_SHAPES.append((m, w.n, w.k, batch, act, resid is not None, ("C" if out is not None else "") + ("P" if out_planes is not None else ""),
                                 "planes" if pap is not None else "fp32"))
@@ -287,6 +288,15 @@ def convnext_mlp_fused(a, w1, w2, b1, b2, gamma, x, m, batch=1, stride_a=0, stri
 
 def convnext_mlp_fused_supported(c):
     return c == 96
+
+
+def zero_(t):
+    """Zero-fill a contiguous GPU tensor on the current stream (mmsa_zero_bytes: no framework kernel inside a captured step)."""
+    if not t.is_contiguous():
+        raise RuntimeError("mmsa.ops.zero_: contiguous tensor expected")
+    if t.numel():
+        lib.call("mmsa_zero_bytes", _chk(t, t.dtype), t.numel() * t.element_size(), _stream())
+    return t
 
 
 def rowstats_finalize(rowstats, rows, d, eps, out):

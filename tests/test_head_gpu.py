@@ -116,3 +116,24 @@ def test_head_through_the_reference_call_signature_and_no_aliasing():
     assert torch.equal(out_b, lb)
     with pytest.raises(NotImplementedError):
         h.forward_train(fa, [{}], None, None)
+
+
+def test_head_writes_into_a_preallocated_slice():
+    """`forward(inputs, out=...)`: the logits land in the caller's tensor (mmsa.Chains hands every chain its slice of the step's logits, so that
+    no framework copy kernel sits inside a captured step); same values as the fresh-tensor form, wrong shapes / strides rejected."""
+    cfg, orc, head = build("head_tiny")
+    del orc
+    xs = [x.to(DEV) for x in make_head_inputs(cfg)]
+    ref = head(xs).clone()
+    big = torch.full((3 * ref.shape[0],) + tuple(ref.shape[1:]), float("nan"), device=DEV)
+    sl = big[ref.shape[0]:2 * ref.shape[0]]
+    ret = head(xs, out=sl)
+    assert ret.data_ptr() == sl.data_ptr()
+    assert torch.equal(sl, ref)
+    assert torch.isnan(big[:ref.shape[0]]).all() and torch.isnan(big[2 * ref.shape[0]:]).all()
+    with pytest.raises(RuntimeError):
+        head(xs, out=torch.empty(ref.shape[0], ref.shape[1], ref.shape[2] + 1, ref.shape[3], device=DEV))
+    with pytest.raises(RuntimeError):
+        head(xs, out=torch.empty_like(ref, dtype=torch.float64))
+    with pytest.raises(RuntimeError):
+        head(xs, out=torch.empty(ref.shape[0], ref.shape[1], ref.shape[2], 2 * ref.shape[3], device=DEV)[..., ::2])   # not contiguous

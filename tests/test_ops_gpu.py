@@ -493,3 +493,13 @@ def test_convnext_mlp_fused(C, M):
     ops.gemm(hb, w2p, x2, bias=b2.to(DEV), colscale=gam.to(DEV), resid=x2, batch=b, m=M, stride_a=M * 2 * hb.kpad, stride_w=C * 2 * w2p.kpad,
              stride_bias=C, stride_r=M * C, stride_c=M * C)
     assert_close(x, x2, tol=5e-6, what="fused vs the two GEMM launches")
+
+
+def test_zero_bytes(ops):
+    """mmsa_zero_bytes: exactly the named range is cleared, on the current stream; non-contiguous views are refused."""
+    t = torch.full((4, 1000), 7.5, dtype=torch.float64, device=DEV)
+    ops.zero_(t[1, 10:900])
+    torch.cuda.synchronize()
+    assert (t[1, 10:900] == 0).all() and (t[1, :10] == 7.5).all() and (t[1, 900:] == 7.5).all() and (t[0] == 7.5).all() and (t[2:] == 7.5).all()
+    with pytest.raises(RuntimeError):
+        ops.zero_(t[:, 3])
