@@ -205,6 +205,60 @@ __global__ __launch_bounds__(256) void dwconv3_nhwc_kernel(const float* __restri
   if (yp) store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);   // operand planes, either format
 }
 
+// The same 3 x 3 conv on a 1 x 4 pixel strip per thread (W % 4 == 0; round 4, as conv_pair.hip's dwpair_gate4_kernel): a kernel row's six input
+// vectors are loaded once for the three taps of that row and a tap's weight vector once for the four pixels -- 27 loads for four outputs (6.75 per
+// output) instead of 18 per output; every load of a kernel row unconditional (clamped position, zero mask).  Per pixel the same sum of the same nine
+// terms in the same order as dwconv3_nhwc_kernel: bit-identical.
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float* __restrict__ x, long ldx, long xstrideB,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long ldy, long ystrideB,
+                                                            unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
+                                                            int B, int H, int W, int C, int act) {
+  const int c4n = C >> 2;
+  const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
+  const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
+  const int idx = bx_ * 256 + threadIdx.x;
+  if (idx >= (W >> 2) * c4n) return;
+  const int wq = idx / c4n;
+  const int c = (idx - wq * c4n) * 4;
+  const int w0 = wq * 4;
+  const int hh = by_ % H, b = by_ / H;
+  const float* xb = x + (long)b * xstrideB + c;
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = hh + kh - 1;
+    const bool rok = ih >= 0 && ih < H;
+    const int ihc = min(max(ih, 0), H - 1);
+    float4 v[6], f[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int iw = w0 + i - 1;
+      const unsigned m = (rok && iw >= 0 && iw < W) ? 0xffffffffu : 0u;
+      const float4 t = *reinterpret_cast<const float4*>(xb + ((long)ihc * W + min(max(iw, 0), W - 1)) * ldx);
+      v[i] = make_float4(__uint_as_float(__float_as_uint(t.x) & m), __uint_as_float(__float_as_uint(t.y) & m), __uint_as_float(__float_as_uint(t.z) & m), __uint_as_float(__float_as_uint(t.w) & m));
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) f[kw] = *reinterpret_cast<const float4*>(w + (long)(kh * 3 + kw) * C + c);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        acc[p].x += v[p + kw].x * f[kw].x; acc[p].y += v[p + kw].y * f[kw].y;
+        acc[p].z += v[p + kw].z * f[kw].z; acc[p].w += v[p + kw].w * f[kw].w;
+      }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float4 o = acc[p];
+    o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
+    const long pix = (long)hh * W + w0 + p;
+    if (y) *reinterpret_cast<float4*>(y + (long)b * ystrideB + pix * ldy + c) = o;
+    if (yp) store_planes4(yp + (long)b * pstrideB + pix * ldp, c, o, yp_fmt);   // operand planes, either format
+  }
+}
+
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
                                 float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB, int yp_fmt,
                                 int B, int H, int W, int C, int k, int act, int imgs_per_group, float* rowstats, hipStream_t stream) {
@@ -229,7 +283,9 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   MMSA_CHECK_ARG(imgs_per_group == 0 || imgs_per_group == B, "dwconv_nhwc: image groups are implemented by the tiled 7x7 kernel only");
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
   const bool generic3 = MMSA_KNOB("MMSA_DWCONV3_GENERIC", 0) != 0;   // A/B aid
-  if (k == 3 && !generic3 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
+  if (k == 3 && !generic3 && (W & 3) == 0 && MMSA_KNOB("MMSA_DWCONV3_STRIP", 1) != 0 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
+    hipLaunchKernelGGL(dwconv3_strip_kernel, dim3(cdiv((long)(W >> 2) * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act);
+  else if (k == 3 && !generic3 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
     hipLaunchKernelGGL(dwconv3_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act);
   else
     hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, k, act);
