@@ -165,6 +165,121 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
   }
 }
 
+// Round 4: the 7 x 7 conv for the plain case (fp32 output only; H, W % 16 == 0, C % 32 == 0: every ConvNeXt stage of the shipped configs).  The tiled
+// kernel above spends most of its arithmetic phase waiting for the 49 tap-weight vectors each lane pulls through the vector-memory pipe (64 B/clk per CU:
+// 196 KiB per tile against 50 KiB of halo -- profiles/r04_dwconv7_ablation.txt; the 3 x 3 kernels had the same disease).  Here a workgroup owns 16 x 16
+// pixels x 32 channels, a lane a 1 x 8 pixel strip of one 4-channel vector: a tap weight is read once for 8 pixels, and from LDS (the chunk's 49 x 32
+// weights are staged once per workgroup, 6 KiB); the halo is 22 x 22 (1.9 x the tile instead of 3.06 x).  LDS row pitch 23 pixels: the strips of one
+// ds_read_b128 lane group sit in rows r and r + 1, and an odd pitch puts them on different halves of the 64 banks (conflict-free reads).
+// Per pixel the same 49 terms in the same order and the same packed FMAs as dwconv7_tiled_kernel: bit-identical.
+#define DW7B_PITCH 23
+#define DW7B_LDS ((22 * DW7B_PITCH * 32 + 50 * 32) * 4)
+// Persistent: gridDim.x workgroups (two per CU: what LDS admits) walk the nt tiles; the NEXT tile's halo and weights are requested into registers before
+// the current tile's arithmetic -- which touches LDS only, so nothing in it waits on the vector-memory counter -- and written to LDS after it.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwconv7_blk_kernel(const float* __restrict__ x, long ldx, long xstrideB,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, long ldy, long ystrideB,
+                                                          int H, int W, int C, int tilesX, int tilesXY, int nchunk, int nt, int imgs_per_group, long w_gstride) {
+  constexpr int TW = 22, CB = 32, PITCH = DW7B_PITCH;
+  constexpr int NIT = (TW * TW * (CB / 4) + 255) / 256;   // 16 halo vectors per lane (the last one partly)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                        // [22][PITCH][32]
+  float* wl = smem + TW * PITCH * CB;        // [49 taps + the bias][32]
+  const int cv = threadIdx.x & 7, blk = threadIdx.x >> 3;   // 32 strips: x0 = 8 * (blk & 1), row = blk >> 1
+  const int ox0 = (blk & 1) * 8, oy = blk >> 1;
+  float4 v[NIT], wv[2];
+  // tile `lin` in dispatch order -> XCD-contiguous work index (common.h) -> (tile in the map, channel chunk, image); issues the tile's loads into v / wv
+  int tx0, ty0, c0, bz;
+  const float* wg;
+  const float* bg;
+  auto issue = [&](int lin) {
+    const unsigned wk = mmsa_xcd_order((unsigned)lin, (unsigned)nt);
+    const int txy = (int)(wk % (unsigned)tilesXY), rest = (int)(wk / (unsigned)tilesXY);
+    const int ch = rest % nchunk;
+    bz = rest / nchunk;
+    c0 = ch * CB;
+    tx0 = (txy % tilesX) * 16;
+    ty0 = (txy / tilesX) * 16;
+    const int grp = imgs_per_group > 0 ? bz / imgs_per_group : 0;   // image groups (the two ConvNeXt streams stacked along the batch) with their own weights
+    wg = w + (long)grp * w_gstride;
+    bg = bias ? bias + (long)grp * C : nullptr;
+    const float* xb = x + (long)bz * xstrideB + c0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + it * 256;
+      const int pos = i >> 3;
+      const int ly = pos / TW, lx = pos - ly * TW;
+      const int iy = ty0 + ly - 3, ix = tx0 + lx - 3;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < TW * TW * (CB / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v[it] = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx + (i & 7) * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = threadIdx.x + it * 256;
+      wv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 49 * (CB / 4)) wv[it] = *reinterpret_cast<const float4*>(wg + (long)(i >> 3) * C + c0 + (i & 7) * 4);
+      else if (i < 50 * (CB / 4) && bg) wv[it] = *reinterpret_cast<const float4*>(bg + c0 + (i & 7) * 4);   // row 49: the chunk's bias
+    }
+  };
+  auto to_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + it * 256;
+      const int pos = i >> 3;
+      const int ly = pos / TW, lx = pos - ly * TW;
+      if (i < TW * TW * (CB / 4)) *reinterpret_cast<float4*>(tile + (ly * PITCH + lx) * CB + (i & 7) * 4) = v[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = threadIdx.x + it * 256;
+      if (i < 50 * (CB / 4)) *reinterpret_cast<float4*>(wl + i * 4) = wv[it];
+    }
+  };
+  int lin = blockIdx.x;
+  if (lin >= nt) return;
+  issue(lin);
+  to_lds();
+  __syncthreads();
+  for (;;) {
+    // this tile's output position and bias (the decode of `issue` is overwritten by the next tile's below)
+    float* yo = y + (long)bz * ystrideB + ((long)(ty0 + oy) * W + tx0 + ox0) * ldy + c0 + cv * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(wl + 49 * CB + cv * 4);
+    const int nxt = lin + gridDim.x;
+    const bool more = nxt < nt;
+    if (more) issue(nxt);
+    mmsa_f2 acc01[8], acc23[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { acc01[p] = (mmsa_f2){bv.x, bv.y}; acc23[p] = (mmsa_f2){bv.z, bv.w}; }
+#pragma unroll 1   // (unrolled it is no faster and, with the 72 prefetch registers live, spills: a scratch reload between the prefetch loads waits for all of them)
+    for (int kh = 0; kh < 7; ++kh) {
+      float4 in[14], f[7];
+      const float* trow = tile + ((oy + kh) * PITCH + ox0) * CB + cv * 4;
+#pragma unroll
+      for (int i = 0; i < 14; ++i) in[i] = *reinterpret_cast<const float4*>(trow + i * CB);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) f[kw] = *reinterpret_cast<const float4*>(wl + (kh * 7 + kw) * CB + cv * 4);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const mmsa_f2 f01 = {f[kw].x, f[kw].y}, f23 = {f[kw].z, f[kw].w};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const mmsa_f2 i01 = {in[p + kw].x, in[p + kw].y}, i23 = {in[p + kw].z, in[p + kw].w};
+          acc01[p] = __builtin_elementwise_fma(i01, f01, acc01[p]);
+          acc23[p] = __builtin_elementwise_fma(i23, f23, acc23[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(yo + (long)p * ldy) = make_float4(acc01[p].x, acc01[p].y, acc23[p].x, acc23[p].y);
+    if (!more) break;
+    lin = nxt;
+    __syncthreads();   // every wave is done with this tile's LDS image
+    to_lds();
+    __syncthreads();
+  }
+}
+
 // 3 x 3 (the ConvFFN's depthwise conv, AM:446-471): the generic kernel above walks its taps with runtime loops and `continue`s -- two
 // dependent loads per tap, nine round trips per thread, 28 us per launch for maps that stream in 7.  Here the nine taps are unrolled,
 // every tap's input vector is loaded UNCONDITIONALLY from a clamped position and bit-masked to +0 where the tap lies outside the map
@@ -272,6 +387,19 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   MMSA_CHECK_ARG(!rowstats || (k == 7 && act == ACT_NONE), "dwconv_nhwc: rowstats are written by the 7x7 kernel without activation only");
   if (k == 7 && (y || yp) && act == ACT_NONE && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)bias)) & 15) == 0 &&
       (!extras || ((C & 63) == 0 && (H & 7) == 0 && (W & 7) == 0))) {
+    if (y && !extras && (C & 31) == 0 && (H & 15) == 0 && (W & 15) == 0 && MMSA_KNOB("MMSA_DWCONV7_BLK", 1) != 0) {
+      static const bool attr_ = [] { (void)hipFuncSetAttribute((const void*)dwconv7_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW7B_LDS); return true; }();
+      (void)attr_;
+      static const int num_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+      const int txy = (W >> 4) * (H >> 4), nchunk = C >> 5;
+      const long nt = (long)txy * nchunk * B;
+      MMSA_CHECK_ARG(nt < (1L << 30), "dwconv_nhwc: too many tiles");
+      const int grid = (int)(nt < 2L * num_cus ? nt : 2L * num_cus);   // two resident workgroups per CU (71 KiB of LDS each)
+      hipLaunchKernelGGL(dwconv7_blk_kernel, dim3(grid), dim3(256), DW7B_LDS, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, H, W, C, W >> 4, txy, nchunk,
+                         (int)nt, imgs_per_group, (long)k * k * C);
+      MMSA_CHECK_LAUNCH("dwconv_nhwc(7x7 blocks)");
+      return MMSA_OK;
+    }
     const int tx = cdiv(W, 8), ty = cdiv(H, 8);
     dim3 grid(tx * ty, cdiv(C, 64), B);
     hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB,

@@ -236,6 +236,27 @@ def test_layernorm_row_groups_and_wrap(ops):
     assert_close(out2, stacked, tol=5e-5, what="grouped LN stacked")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(1, 16, 48, 96), (2, 32, 32, 64), (1, 48, 16, 160)])
+def test_dwconv7_block_kernel_equals_the_tiled_kernel_and_torch(ops, B, H, W, C):
+    """The 16 x 16 x 32 block kernel (fp32 output only, H, W % 16 == 0, C % 32 == 0: the ConvNeXt stages of the shipped configs) against torch's grouped
+    conv, and BITWISE against the tiled kernel -- the same call with a planes output beside the fp32 one runs that one (same terms, same order, same
+    packed FMAs).  Two image groups with their own weights; maps with tiles on every border and in the interior."""
+    convs = [torch.nn.Conv2d(C, C, 7, padding=3, groups=C) for _ in range(2)]
+    x = torch.randn(2 * B, C, H, W, generator=g(84))
+    ref = torch.cat([convs[0](x[:B]), convs[1](x[B:])], 0).detach().permute(0, 2, 3, 1).reshape(-1, C)
+    wt = torch.stack([c.weight.detach().reshape(C, 49).t().contiguous() for c in convs], 0).contiguous().to(DEV)   # [2, 49, C]
+    bs = torch.stack([c.bias.detach() for c in convs], 0).contiguous().to(DEV)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    out = torch.full((2 * B * H * W, C), float("nan"), device=DEV)
+    ops.dwconv(xd, wt, bs, out, 2 * B, H, W, 7, imgs_per_group=B)
+    assert_close(out, ref, tol=5e-5, what="dwconv7 block kernel vs torch")
+    if C % 64 == 0 and H % 8 == 0 and W % 8 == 0:
+        out2 = torch.full_like(out, float("nan"))
+        pl = ops.alloc_planes(2 * B * H * W, C, DEV)
+        ops.dwconv(xd, wt, bs, out2, 2 * B, H, W, 7, imgs_per_group=B, out_planes=pl)
+        assert torch.equal(out, out2), "block kernel and tiled kernel must agree bitwise"
+
+
 def test_dwconv7_image_groups(ops):
     B, H, W, C = 2, 12, 20, 64
     convs = [torch.nn.Conv2d(C, C, 7, padding=3, groups=C) for _ in range(2)]
