@@ -27,6 +27,9 @@
  *                   one block-scaled fp8 MFMA at twice the rate: same precision class, 2/3 of the matrix-pipe time): 32 fp16 hi
  *                   values, then four 16-byte chunks, chunk g = 8 bytes e5m2(lo * 2^11) + 8 bytes e5m2(hi) of k = 8g..8g+7 for an
  *                   ACTIVATION (A operand) row, the two halves swapped for a WEIGHT (W operand) row.  |x| is clamped to 57344.
+ *      MMSA_FMT_F3  (round 4) the MMSA_FMT_B3 layout with fp16 halves: x = fp16(x) + fp16(x - fp16(x)), 22 significant bits instead of 16, the same
+ *                   three MFMAs per product (on the fp16 MFMA); values are clamped to +-65504.  Read by mmsa_gemm_split3 with A planes (the
+ *                   LDS-DMA kernel); written by it, by mmsa_layernorm_rows and by mmsa_split_planes (kind 4).  The TwinConvNeXt chain uses it.
  *      MMSA_FMT_H8C the h8 arithmetic on 3 bytes per element (round 4), laid out for the LDS-DMA operand stream of the GEMM: q(hi) is not
  *                   stored (the e5m2 image of an fp16 value is its top byte; the GEMM takes it in registers) and rows are stored in PAIRS --
  *                   pair j of a [rows, K] matrix (K padded to a multiple of 64, rows to even) occupies `ld` uint16 (>= 3 K):
@@ -64,7 +67,7 @@ enum { MMSA_ACT_NONE = 0, MMSA_ACT_GELU = 1, MMSA_ACT_RELU = 2, MMSA_ACT_RELU6 =
 enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
 
 /* operand-plane formats (see Conventions) */
-enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2 };
+enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2, MMSA_FMT_F3 = 3 };
 
 /* --- reference native ops -----------------------------------------------------------------------------------
  * ms_deform_attn_forward (vision.cpp:14 -> ms_deform_attn.h:20-39 -> cuda/ms_deform_attn_cuda.cu:20-80).
@@ -140,10 +143,11 @@ int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
 /* ConvNeXt pointwise pair of the narrow stages as ONE kernel (TC:107-132): x[b] <- x[b] + gamma[b] * (GELU(A[b] W1[b]^T + b1[b]) W2[b]^T
  * + b2[b]); A = LayerNorm output as bf16 hi/lo planes [M, C] (row stride lda, batch stride strideA, uint16 units), W1 [4C, C] and
  * W2 [C, 4C] bf16 hi/lo planes per batch, b1 [batch, 4C], b2 / gamma [batch, C], x fp32 [M, C] (row stride ldx) updated in place.
- * C = 96 (the narrowest ConvNeXt stage); the 4C-wide hidden tensor stays in LDS.  max_grid as in mmsa_gemm_split3. */
+ * C = 96 (the narrowest ConvNeXt stage); the 4C-wide hidden tensor stays in LDS.  max_grid as in mmsa_gemm_split3.  fmt = MMSA_FMT_B3 or
+ * MMSA_FMT_F3: the format of A, W1, W2 (and of the hidden image the kernel keeps in LDS). */
 int mmsa_convnext_mlp_fused(const uint16_t* Ap, long lda, long strideA, const uint16_t* W1p, long strideW1, const uint16_t* W2p,
                             long strideW2, const float* b1, const float* b2, const float* gamma, float* x, long ldx, long strideX,
-                            int M, int C, int batch, int max_grid, mmsa_stream_t stream);
+                            int M, int C, int batch, int max_grid, int fmt, mmsa_stream_t stream);
 
 /* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
  * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows; 3: h8c planes [ceil(rows / 2), 3*cols_pad] (cols_pad % 64 == 0; activations and weights). */

@@ -143,7 +143,7 @@ __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k
 // for ACTIVATIONS (A operand); WEIGHTS store the chunk as 8 q(hi) bytes + 8 lo bytes, so that for both operands the lane's 32
 // operand bytes of the fp8 MFMA are just the chunks of two consecutive k-blocks, and byte p of A always meets byte p of W with
 // the roles (lo, q(hi)) crossed.  Values are clamped to +-57344 (the largest e5m2 / a finite fp16) before the split.
-enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2 };
+enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2, MMSA_FMT_F3 = 3 };
 // Output-plane format argument of the GEMM (`cp_fmt`): bits 0..7 = format of the columns below the split, bits 8.. = split / 32;
 // columns >= split (a multiple of 32, 0 = no split) are written as MMSA_FMT_H8.  The qkv projection writes q and k as bf16 hi/lo
 // planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: DESIGN.md 4.1).
@@ -167,6 +167,27 @@ __device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsig
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {
   const mmsa_f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mmsa_h2));
+}
+
+// ---- "f3" planes (round 4): the bf16 hi/lo layout (32 hi values, then 32 lo values per k-block) with fp16 halves -- x = hi + lo, hi = fp16(x),
+// lo = fp16(x - hi): 22 significant bits where bf16 hi/lo has 16, the same three MFMAs per product (v_mfma_f32_16x16x32_f16: hh + hl + lh) at the
+// same rate.  Used where operand rounding is what the outputs see: the TwinConvNeXt chain, whose error GFFM multiplies by ~15 (DESIGN.md section 2;
+// tools/f3_study.py).  fp16's range is the price: values are clamped to +-65504 (LayerNorm outputs, GELU hidden activations and weights are far
+// inside it); below 6.1e-5 hi and lo become subnormal -- the MFMA does not flush them -- and the pair degrades gracefully to an absolute 6e-8.
+#define MMSA_F3_MAX 65504.0f
+__device__ __forceinline__ void f3_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  a = __builtin_amdgcn_fmed3f(a, -MMSA_F3_MAX, MMSA_F3_MAX);
+  b = __builtin_amdgcn_fmed3f(b, -MMSA_F3_MAX, MMSA_F3_MAX);
+  split2_f16(a, b, hi, lo);
+}
+__device__ __forceinline__ void f3_split4(const float4 v, uint2& hi, uint2& lo) {
+  f3_split2(v.x, v.y, hi.x, lo.x);
+  f3_split2(v.z, v.w, hi.y, lo.y);
+}
+// 4 values -> hi / lo halves of a 16-bit pair format (bf16 hi/lo or f3)
+__device__ __forceinline__ void split4_fmt(const float4 v, uint2& hi, uint2& lo, int fmt) {
+  if (fmt == MMSA_FMT_F3) f3_split4(v, hi, lo);
+  else split4(v, hi, lo);
 }
 
 // two floats -> hi (2 packed fp16), lo8 / qh8 (2 e5m2 bytes each, written into the low or high half of `lo8` / `qh8`)
@@ -203,7 +224,7 @@ __device__ __forceinline__ void store_planes4(unsigned short* row, int c, const 
     *reinterpret_cast<unsigned*>(rb + 8) = qh8;
   } else {
     uint2 hh, ll;
-    split4(v, hh, ll);
+    split4_fmt(v, hh, ll, fmt);
     *reinterpret_cast<uint2*>(row + ilv(c)) = hh;
     *reinterpret_cast<uint2*>(row + ilv(c) + 32) = ll;
   }
@@ -218,7 +239,7 @@ template <int XOR>
 __device__ __forceinline__ void store_planes8_pair(unsigned short* row, int c8, const float4 v, int fmt, bool odd, bool do_store) {
   uint2 mine_hi, mine_x;   // hi chunk half; second-chunk half (bf16: lo values; h8: .x = lo bytes, .y = q(hi) bytes)
   if (fmt == MMSA_FMT_H8) h8_split4(v, mine_hi, mine_x.x, mine_x.y);
-  else split4(v, mine_hi, mine_x);
+  else split4_fmt(v, mine_hi, mine_x, fmt);
   const uint2 snd = odd ? mine_hi : mine_x;
   uint2 rcv;
   rcv.x = __shfl_xor(snd.x, XOR, 64);
@@ -242,7 +263,14 @@ __device__ __forceinline__ void store_planes1(unsigned short* row, int c, float 
     rb[8] = (unsigned char)(qh8 & 0xFFu);
   } else {
     unsigned short hh, ll;
-    split_bf16(x, hh, ll);
+    if (fmt == MMSA_FMT_F3) {
+      unsigned h2, l2;
+      f3_split2(x, 0.f, h2, l2);
+      hh = (unsigned short)(h2 & 0xFFFFu);
+      ll = (unsigned short)(l2 & 0xFFFFu);
+    } else {
+      split_bf16(x, hh, ll);
+    }
     row[ilv(c)] = hh;
     row[ilv(c) + 32] = ll;
   }

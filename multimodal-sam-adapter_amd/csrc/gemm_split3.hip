@@ -43,7 +43,8 @@ struct GemmArgs {
 
 // GEN = true compiles in the rarely used index arithmetic (pixel-shuffle store, broadcast residual): integer
 // divisions per output element that the common epilogue must not pay for.
-template <bool AP, bool GEN>
+// F16: the 16-bit hi/lo pairs are fp16 halves ("f3", common.h) -- A is split that way while staged, the weight planes come that way, fp16 MFMAs
+template <bool AP, bool GEN, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
 #define STORE_A(base, reg, i)                                                               \
   do {                                                                                      \
     uint2 hi_, lo_;                                                                         \
-    split4(reg, hi_, lo_);                                                                  \
+    if constexpr (F16) f3_split4(reg, hi_, lo_); else split4(reg, hi_, lo_);               \
     *reinterpret_cast<uint2*>((base) + 0 * PLANE_BYTES + a_lds_off + (i) * 512) = hi_;      \
     *reinterpret_cast<uint2*>((base) + 1 * PLANE_BYTES + a_lds_off + (i) * 512) = lo_;      \
   } while (0)
@@ -173,9 +174,15 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
+        if constexpr (F16) {
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[ni]), __builtin_bit_cast(f16x8, ah[mi]), acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[ni]), __builtin_bit_cast(f16x8, al[mi]), acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[ni]), __builtin_bit_cast(f16x8, ah[mi]), acc[ni][mi], 0, 0, 0);
+        } else {
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+        }
       }
     if (kt + 1 < nk) STORE_LDS(stage ^ 1);
     __syncthreads();
@@ -343,9 +350,10 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   MMSA_CHECK_ARG(!(rs_out && rn_mr), "gemm_split3: a GEMM either writes row statistics or normalises by them");
   const bool extras = rs_out || rn_mr;
   MMSA_CHECK_ARG(!extras || (ap && M >= 128), "gemm_split3: row statistics / row normalisation need activation planes and M >= 128");
-  MMSA_CHECK_ARG(fmt >= MMSA_FMT_B3 && fmt <= MMSA_FMT_H8C && cp_fmt >= 0 && MMSA_CP_BASE(cp_fmt) >= MMSA_FMT_B3 && MMSA_CP_BASE(cp_fmt) <= MMSA_FMT_H8C, "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
+  MMSA_CHECK_ARG(fmt >= MMSA_FMT_B3 && fmt <= MMSA_FMT_F3 && cp_fmt >= 0 && MMSA_CP_BASE(cp_fmt) >= MMSA_FMT_B3 && MMSA_CP_BASE(cp_fmt) <= MMSA_FMT_F3, "gemm_split3: bad plane format %d / %d", fmt, cp_fmt);
   MMSA_CHECK_ARG(MMSA_CP_SPLIT(cp_fmt) == 0 || (out_mode == 0 && MMSA_CP_SPLIT(cp_fmt) < N && MMSA_CP_BASE(cp_fmt) != MMSA_FMT_H8C), "gemm_split3: the output-format split %d needs a plain [M, N] bf16 hi/lo planes output with N=%d beyond it", MMSA_CP_SPLIT(cp_fmt), N);
-  MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || (ap && K % 64 == 0), "gemm_split3: h8 / h8c operands need A planes and K %% 64 == 0 (K=%d)", K);
+  MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_F3 || (ap && K % 64 == 0), "gemm_split3: h8 / h8c operands need A planes and K %% 64 == 0 (K=%d)", K);
+  MMSA_CHECK_ARG(fmt != MMSA_FMT_F3 || ap || !Cp, "gemm_split3: f3 weights with an fp32 A write fp32 outputs only");
   const bool h8c = fmt == MMSA_FMT_H8C, cp_h8c = MMSA_CP_BASE(cp_fmt) == MMSA_FMT_H8C;
   MMSA_CHECK_ARG((A || Ap) && Wp && (C || Cp), "gemm_split3: null pointer");
   MMSA_CHECK_ARG(!(A && Ap), "gemm_split3: pass either fp32 A or A planes, not both");
@@ -388,7 +396,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   const bool no_tiny = MMSA_KNOB("MMSA_GEMM_NO_TINY", 0) != 0;   // A/B aid (debug-knob builds)
   // routed by the problem's small dimension, NOT by the row count (rows scale with the image batch: a batch-dependent choice of
   // kernel would make results depend on how images are batched); M <= 16384 covers 32 images of the largest pooled map
-  if (!ap && !Cp && out_mode == 0 && resid_mod <= 0 && (N <= 64 || K <= 64) && M <= 16384 && !no_tiny && !extras) {
+  if (!ap && !Cp && out_mode == 0 && resid_mod <= 0 && (N <= 64 || K <= 64) && M <= 16384 && !no_tiny && !extras && fmt == MMSA_FMT_B3) {
     const int ncg = cdiv(N, 8);
     hipLaunchKernelGGL(gemm_tiny_kernel, dim3(cdiv((long)M * ncg, 4), batch), dim3(256), 0, stream, a, ncg);
     MMSA_CHECK_LAUNCH("gemm_split3(tiny)");
@@ -406,6 +414,9 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   if (ap) {
     if (gen) hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
     else hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  } else if (fmt == MMSA_FMT_F3) {
+    if (gen) hipLaunchKernelGGL((gemm_split3_kernel<false, true, true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+    else hipLaunchKernelGGL((gemm_split3_kernel<false, false, true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
   } else {
     if (gen) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
     else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
@@ -415,7 +426,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
 }
 
 // ---- pre-pack: fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad] (zero padded).
-// kind 0: bf16 hi/lo planes; 1: h8 activation rows (chunk = lo bytes | q(hi) bytes); 2: h8 WEIGHT rows (chunk = q(hi) | lo); 3: h8c planes
+// kind 0: bf16 hi/lo planes; 1: h8 activation rows (chunk = lo bytes | q(hi) bytes); 2: h8 WEIGHT rows (chunk = q(hi) | lo); 3: h8c planes; 4: f3 (fp16 hi/lo)
 // (dense: row-pair stride 3 * cols_pad; rows odd: the pair partner of the last row is not written): common.h
 __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
                                     unsigned short* __restrict__ out, int kind) {
@@ -433,6 +444,8 @@ __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int 
       split_bf16(x, h, l);
       row[ilv(c)] = h;
       row[ilv(c) + 32] = l;
+    } else if (kind == 4) {   // f3: the same layout with fp16 halves
+      store_planes1(row, c, x, MMSA_FMT_F3);
     } else {
       unsigned hi, lo8 = 0u, qh8 = 0u;
       h8_split2<false>(x, 0.f, hi, lo8, qh8);
@@ -447,7 +460,7 @@ __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int 
 extern "C" int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad,
                                  unsigned short* out, int kind, hipStream_t stream) {
   MMSA_CHECK_ARG(src && out && rows > 0 && cols > 0 && cols_pad >= cols && cols_pad % 32 == 0, "split_planes: bad args");
-  MMSA_CHECK_ARG(kind >= 0 && kind <= 3, "split_planes: kind %d (0 bf16 hi/lo, 1 h8 activation, 2 h8 weight, 3 h8c)", kind);
+  MMSA_CHECK_ARG(kind >= 0 && kind <= 4, "split_planes: kind %d (0 bf16 hi/lo, 1 h8 activation, 2 h8 weight, 3 h8c, 4 f3)", kind);
   MMSA_CHECK_ARG(kind != 3 || cols_pad % 64 == 0, "split_planes: h8c planes need cols_pad %% 64 == 0");
   const long total = (long)rows * cols_pad;
   int blocks = cdiv(total, 256);

@@ -33,7 +33,7 @@
 template <bool GEN, int ACT, bool PP, int NW, int FMT>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV2Args a) {
   static_assert(NW == 8 || (NW == 4 && !PP), "4-wave workgroups run the in-phase main loop");
-  static_assert(FMT == MMSA_FMT_B3 || (PP && NW == 8), "the h8 operand format runs on the ping-pong kernel");
+  static_assert(FMT == MMSA_FMT_B3 || (PP && NW == 8), "the h8 and f3 operand formats run on the ping-pong kernel");
   constexpr bool EPI_UNROLL = ACT >= 0;
   constexpr int V2_BM = NW * 32;
   constexpr int V2_A_BYTES = V2_BM * 128;
@@ -199,9 +199,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   } else {                                                                                                  \
     if (V2_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                      \
+      if constexpr (FMT == MMSA_FMT_F3) {   /* fp16 hi/lo pairs: the same three products on the fp16 MFMA */                 \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wl[ni]), __builtin_bit_cast(mx_h8, ah[mi]), acc[ni][mi], 0, 0, 0); \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wh[ni]), __builtin_bit_cast(mx_h8, al[mi]), acc[ni][mi], 0, 0, 0); \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wh[ni]), __builtin_bit_cast(mx_h8, ah[mi]), acc[ni][mi], 0, 0, 0); \
+      } else {                                                                                              \
       acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);          \
       acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);          \
       acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);          \
+      }                                                                                                     \
     }                                                                                                       \
     if (V2_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                          \
   }
@@ -564,7 +570,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   MMSA_CHECK_ARG(flavour == 0 || flavour == 4 || flavour == 8, "gemm(v2): flavour %d (0 = by shape, 4, 8)", flavour);
   // (not under a grid cap: a caller that runs concurrent chains gives each GEMM `max_grid` workgroups so that it holds that many CUs; 2 x
   // max_grid half-size workgroups would be spread over twice as many CUs and their 64 KiB each would shut the other chain's 144 KiB workgroups out)
-  const int nw = (h8 || rs_out || rn_mr) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) && max_grid <= 0 ? 4 : 8);
+  const int nw = (h8 || rs_out || rn_mr || fmt == MMSA_FMT_F3) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) && max_grid <= 0 ? 4 : 8);
   const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
   a.nbm = cdiv(M, bm);
   a.bn = V2_BN;
@@ -582,6 +588,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8)); \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
+  (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_F3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1) V2_ATTR(true, ACT_NONE)
 #undef V2_ATTR
@@ -634,6 +641,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \
   do {                                                                                                                     \
     if (fmt == MMSA_FMT_H8) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_H8>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);          \
+    else if (fmt == MMSA_FMT_F3) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_F3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);     \
     else if (nw == 4) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>), dim3(grid), dim3(256), V2_LDS_BYTES(4), stream, a);     \
     else if (pp) hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);     \
     else hipLaunchKernelGGL((gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>), dim3(grid), dim3(512), V2_LDS_BYTES(8), stream, a);            \

@@ -41,6 +41,8 @@ struct MlpFusedArgs {
 #define MF_BS_OFF (MF_HS_OFF + 32768)                   // b1 of every batch (<= 2048 floats)
 #define MF_LDS (MF_BS_OFF + 8192)                       // 160 KiB
 
+// F16: A, W1, W2 and the hidden image are fp16 hi/lo pairs ("f3" planes, common.h) and the products run on the fp16 MFMA; else bf16 hi/lo
+template <bool F16>
 __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
   constexpr int C = MF_C, HID = MF_HID;
   constexpr int NSTEP = 2 * (HID / 64);   // 12 steps per tile: (A, B) per 64-column hidden chunk
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-              acc_h[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc_h[mi][ni], 0, 0, 0);
-              acc_h[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc_h[mi][ni], 0, 0, 0);
-              acc_h[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc_h[mi][ni], 0, 0, 0);
+              acc_h[mi][ni] = (F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[ni]), __builtin_bit_cast(f16x8, ah[mi]), acc_h[mi][ni], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc_h[mi][ni], 0, 0, 0));
+              acc_h[mi][ni] = (F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[ni]), __builtin_bit_cast(f16x8, al[mi]), acc_h[mi][ni], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc_h[mi][ni], 0, 0, 0));
+              acc_h[mi][ni] = (F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[ni]), __builtin_bit_cast(f16x8, ah[mi]), acc_h[mi][ni], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc_h[mi][ni], 0, 0, 0));
             }
         }
         if (t + 2 < NSTEP) issue(t + 2, W1b, W2b, pf_slot);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
             float4 o = make_float4(acc_h[mi][ni][0] + bb.x, acc_h[mi][ni][1] + bb.y, acc_h[mi][ni][2] + bb.z, acc_h[mi][ni][3] + bb.w);
             o = gelu4(o);
             uint2 hh, ll;
-            split4(o, hh, ll);
+            if constexpr (F16) f3_split4(o, hh, ll); else split4(o, hh, ll);
             const int row = wm * 32 + mi * 16 + l15;
             const int chunk = ni * 2 + (g >> 1);                      // 16-byte chunk (8 values) of the 32-wide k-block
             const int sw = (row >> 1) & 7;
@@ -183,9 +185,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
             const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sb + kb2 * 12288 + (wn * (C / 2) + nj * 16) * 128 + frag_lo);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-              acc_o[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[mi], acc_o[mi][nj], 0, 0, 0);
-              acc_o[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[mi], acc_o[mi][nj], 0, 0, 0);
-              acc_o[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mi], acc_o[mi][nj], 0, 0, 0);
+              acc_o[mi][nj] = (F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl), __builtin_bit_cast(f16x8, ah[mi]), acc_o[mi][nj], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[mi], acc_o[mi][nj], 0, 0, 0));
+              acc_o[mi][nj] = (F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, al[mi]), acc_o[mi][nj], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[mi], acc_o[mi][nj], 0, 0, 0));
+              acc_o[mi][nj] = (F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, ah[mi]), acc_o[mi][nj], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mi], acc_o[mi][nj], 0, 0, 0));
             }
           }
         }
@@ -224,9 +226,10 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
 // x[b] <- x[b] + gamma[b] * (GELU(A[b] W1[b]^T + b1[b]) W2[b]^T + b2[b]) for b < batch; C = 96; rows M per batch.
 extern "C" int mmsa_convnext_mlp_fused(const unsigned short* Ap, long lda, long strideA, const unsigned short* W1p, long strideW1,
                                        const unsigned short* W2p, long strideW2, const float* b1, const float* b2, const float* gamma,
-                                       float* x, long ldx, long strideX, int M, int C, int batch, int max_grid, hipStream_t stream) {
+                                       float* x, long ldx, long strideX, int M, int C, int batch, int max_grid, int fmt, hipStream_t stream) {
   MMSA_CHECK_ARG(Ap && W1p && W2p && b1 && b2 && gamma && x && M > 0 && batch > 0, "convnext_mlp_fused: bad args");
   MMSA_CHECK_ARG(C == MF_C, "convnext_mlp_fused: C = %d not supported (%d)", C, MF_C);
+  MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_F3, "convnext_mlp_fused: planes format %d (bf16 hi/lo or f3)", fmt);
   MMSA_CHECK_ARG((long)batch * 4 * C <= 2048, "convnext_mlp_fused: batch * 4C = %ld > 2048 (bias staging)", (long)batch * 4 * C);
   MMSA_CHECK_ARG(lda >= 2L * C && (lda & 63) == 0 && (strideA & 63) == 0 && (strideW1 & 63) == 0 && (strideW2 & 63) == 0,
                  "convnext_mlp_fused: plane strides must be multiples of 64");
@@ -243,11 +246,13 @@ extern "C" int mmsa_convnext_mlp_fused(const unsigned short* Ap, long lda, long 
     int dev = 0;
     hipDeviceProp_t prop;
     num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS);
+    (void)hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS);
+    (void)hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS);
   }
   const int cus = (max_grid > 0 && max_grid < num_cus) ? max_grid : num_cus;
   const int grid = a.ntiles < cus ? a.ntiles : cus;
-  hipLaunchKernelGGL(mlp_fused_kernel, dim3(grid), dim3(512), MF_LDS, stream, a);
+  if (fmt == MMSA_FMT_F3) hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(grid), dim3(512), MF_LDS, stream, a);
+  else hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(grid), dim3(512), MF_LDS, stream, a);
   MMSA_CHECK_LAUNCH("convnext_mlp_fused");
   return MMSA_OK;
 }

@@ -123,7 +123,7 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
                                    unsigned short* yp, long ldp, int rows, int C,
                                    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap,
                                    int plane_fmt, hipStream_t stream) {
-  MMSA_CHECK_ARG(plane_fmt >= MMSA_FMT_B3 && plane_fmt <= MMSA_FMT_H8C, "layernorm_rows: bad plane format %d", plane_fmt);
+  MMSA_CHECK_ARG(plane_fmt >= MMSA_FMT_B3 && plane_fmt <= MMSA_FMT_F3, "layernorm_rows: bad plane format %d", plane_fmt);
   MMSA_CHECK_ARG(!yp || plane_fmt != MMSA_FMT_H8C || (map_mode == 0 && group_rows == 0 && ldp >= 3L * MMSA_PAD64(C)),
                  "layernorm_rows: h8c planes are a plain [rows, C] output (no patchify / row groups), ldp = pair stride >= 3 * pad64(C)");
   MMSA_CHECK_ARG(x && w && b && (y || yp) && rows > 0 && C > 0, "layernorm_rows: bad args");

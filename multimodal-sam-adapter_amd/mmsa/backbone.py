@@ -279,6 +279,12 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         """h8 sites with deep contractions travel as h8c planes (default); `model.h8c = False` / MMSA_H8C=0 keeps them on h8 line planes (A/B)."""
         return os.environ.get("MMSA_H8C", "1") != "0" and bool(getattr(self, "h8c", True))
 
+    def _cnx_f16_wanted(self):
+        """TwinConvNeXt GEMMs on fp16 hi/lo pairs (default) instead of bf16 hi/lo; `model.cnx_f16 = False` / MMSA_CNX_F16=0 for the A/B.  Not with
+        the opt-in ConvNeXt LayerNorm fold (its depthwise kernel writes bf16 hi/lo planes)."""
+        fold = bool(getattr(self, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
+        return os.environ.get("MMSA_CNX_F16", "1") != "0" and bool(getattr(self, "cnx_f16", True)) and not fold
+
     def _fold_ln_wanted(self, hidden=None):
         """Whether _pack folds the ViT blocks' LayerNorms into their consumer GEMMs (a pack-time setting: checkpoint.load_packed compares it)."""
         D, heads = self.cfg["embed_dim"], self.cfg["num_heads"]
@@ -373,16 +379,23 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 blk["relp"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_B3)
                 blk["relp16"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_H8) if blk["qkv_bp16"] is not None else None
         # --- TwinConvNeXt
+        cnx_f16 = self._cnx_f16_wanted()
+
         def cfmt(w2d):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path):
             # h8 operands for the pointwise convs whose two contraction lengths (C and 4C) are multiples of 64 and that do not run on the fused stage-0 kernel
             # ("cnx2": stage 2 alone -- the selective variant of tools/cnx_h8_study.py, measured and left off: DESIGN.md section 4.2)
             c_ = min(w2d.shape)
             on = "cnx" in h8_sites or ("cnx2" in h8_sites and c_ == self.channels[2])
-            return ops.FMT_H8 if (on and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_)) else ops.FMT_B3
+            if on and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_):
+                return ops.FMT_H8
+            # default (round 4): fp16 hi/lo pairs ("f3": 22 significant bits, the same three MFMAs per product as bf16 hi/lo) for the whole
+            # chain (stem, downsample and pointwise convs) -- its operand rounding is what GFFM amplifies (tools/f3_study.py)
+            return ops.FMT_F3 if cnx_f16 else ops.FMT_B3
         # ConvNeXt LayerNorm fold (round 3): OPT-IN (`model.fold_convnext_ln = True` or MMSA_FOLD_CNX_LN=1).  Built, tested, and measured at
         # ViT-L 1024^2: step -0.17 ms, golden probes 2.9e-4 -> 4.6e-4 (the chain's error is amplified ~15 x by GFFM, DESIGN.md sections 2 and 4.2):
         # not worth the margin.  Applies to the stages that run pointwise_conv1 as a GEMM (not the fused stage-0 pair), 64-channel chunks.
         want_cnx = bool(getattr(self, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
+        pk["cnx_f16"] = cnx_f16
 
         def fold_cnx(c_):
             return want_cnx and c_ % 64 == 0 and (4 * c_) % 128 == 0 and not ops.convnext_mlp_fused_supported(c_)
@@ -391,12 +404,13 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         pk["twin"] = {}
         for s in ("x", "y"):
             d = t + f"downsample_layers_{s}."
-            st = dict(stem=planes(sd[d + "0.0.weight"].reshape(self.channels[0], -1)), stem_b=sd[d + "0.0.bias"],
+            st = dict(stem=planes(sd[d + "0.0.weight"].reshape(self.channels[0], -1), fmt=ops.FMT_F3 if cnx_f16 else ops.FMT_B3), stem_b=sd[d + "0.0.bias"],
                       stem_nw=sd[d + "0.1.weight"], stem_nb=sd[d + "0.1.bias"], ds=[], stages=[], out_norm=[])
             for i in range(1, 4):
                 w = sd[d + f"{i}.1.weight"]  # [Cout, Cin, 2, 2] -> K order (kh, kw, cin)
                 st["ds"].append(dict(nw=sd[d + f"{i}.0.weight"], nb=sd[d + f"{i}.0.bias"],
-                                     w=planes(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)), b=sd[d + f"{i}.1.bias"]))
+                                     w=planes(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), fmt=ops.FMT_F3 if cnx_f16 else ops.FMT_B3),
+                                     b=sd[d + f"{i}.1.bias"]))
             for i in range(4):
                 blks = []
                 for j in range(self.depths[i]):
@@ -619,7 +633,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         dev = x.device
         x = x.contiguous().float()
         if (self._packed is None or self._packed.get("dev") != dev or tuple(self._packed.get("h8_sites", ())) != self._h8_sites()
-                or self._packed.get("h8c") != self._h8c_wanted()):
+                or self._packed.get("h8c") != self._h8c_wanted() or self._packed.get("cnx_f16") != self._cnx_f16_wanted()):
             self._packed = self._pack(dev)
             self._packed["dev"] = dev
         if self._ws is None or self._ws.device != dev:
@@ -1081,7 +1095,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 ds = st["ds"][i - 1]
                 cp = chans[i - 1]
                 Pp = B * sizes[i - 1][0] * sizes[i - 1][1]
-                pa = ws.planes(t + "patch", 2 * P, 4 * cp)
+                pa = ws.planes(t + "patch", 2 * P, 4 * cp, fmt=ds["w"].fmt)
                 ops.layernorm(cur, ds["nw"], ds["nb"], 1e-6, out_planes=pa, patchify=(sizes[i - 1][0], sizes[i - 1][1]),
                               group_rows=Pp, w_gstride=cp)
                 cur = ws.get(t + f"cur{i}", 2 * P, c)

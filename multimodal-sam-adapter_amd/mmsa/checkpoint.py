@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 8   # 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
+PACK_FORMAT = 9   # 9: the ConvNeXt planes' format (fp16 hi/lo pairs) among the settings; 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
 
 
 def unwrap_state_dict(ck):
@@ -180,7 +180,7 @@ def save_packed(model, path, device="cuda"):
     torch.save({"format": PACK_FORMAT, "cfg": model.cfg, "state_dict": sd, "packed": enc, "fingerprint": _fingerprint(sd),
                 "packed_checksum": _packed_checksum(enc),
                 "settings": {"h8_sites": list(model._h8_sites()), "h8c": bool(pk.get("h8c", False)), "share_c_norm": bool(pk.get("share_c_norm", True)), "fold_ln": bool(pk.get("fold_ln", False)),
-                             "fold_cnx_ln": bool(pk.get("fold_cnx_ln", False))}}, path)
+                             "fold_cnx_ln": bool(pk.get("fold_cnx_ln", False)), "cnx_f16": bool(pk.get("cnx_f16", False))}}, path)
 
 
 def load_packed(model, path, device="cuda"):
@@ -197,6 +197,7 @@ def load_packed(model, path, device="cuda"):
             "share_c_norm": os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(model, "share_c_norm", True))}
     want["fold_ln"] = bool(model._fold_ln_wanted())
     want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
+    want["cnx_f16"] = bool(model._cnx_f16_wanted())
     if blob.get("settings") != want:
         raise RuntimeError(f"{path}: packed with settings {blob.get('settings')}, the model runs {want}: repack")
     if blob["fingerprint"] != _fingerprint(blob["state_dict"]):

@@ -66,7 +66,7 @@ def _mat(t, name, dtype=torch.float32):
     return _chk(t, dtype, name), t.shape[0], t.shape[1], t.stride(0)
 
 
-FMT_B3, FMT_H8, FMT_H8C = 0, 1, 2   # MMSA_FMT_* (include/mmsa.h)
+FMT_B3, FMT_H8, FMT_H8C, FMT_F3 = 0, 1, 2, 3   # MMSA_FMT_* (include/mmsa.h); F3 = the B3 layout with fp16 halves (22 significant bits)
 
 
 class Planes:
@@ -182,6 +182,9 @@ def planes_to_float(pl, cols=None):
         ch = blk[:, :, 64:].reshape(r, w // 64, 4, 2, 8)                                    # chunk g: (lo | q(hi)) or (q(hi) | lo)
         lo = ch[:, :, :, 1 if pl.weight else 0].contiguous().view(torch.float8_e5m2).float().reshape(r, w // 64, 32)
         out = (hi + lo / 2048.0).reshape(r, w // 2)
+    elif pl.fmt == FMT_F3:
+        v = pl.p.contiguous().view(torch.float16).float().view(r, w // 64, 2, 32)
+        out = (v[:, :, 0] + v[:, :, 1]).reshape(r, w // 2)
     else:
         v = (pl.p.to(torch.int32) << 16).view(torch.float32).view(r, w // 64, 2, 32)
         out = (v[:, :, 0] + v[:, :, 1]).reshape(r, w // 2)
@@ -206,7 +209,7 @@ def split_planes(w2d, kpad=None, out=None, fmt=FMT_B3, weight=False):
             raise RuntimeError("mmsa.split_planes: dense h8c planes of the source's row count expected")
         kind = 3
     else:
-        kind = 0 if out.fmt == FMT_B3 else (2 if out.weight else 1)
+        kind = 0 if out.fmt == FMT_B3 else 4 if out.fmt == FMT_F3 else (2 if out.weight else 1)
     lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), kind, _stream())
     return out
 
@@ -226,7 +229,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
             raise RuntimeError(f"mmsa.gemm: A planes have {ka} columns but the packed weight expects K={w.kpad}")
         if a.fmt != w.fmt or a.weight or (w.fmt == FMT_H8 and not w.weight) or (w.fmt == FMT_H8C and w.weight):
             raise RuntimeError(f"mmsa.gemm: operand formats differ (A fmt {a.fmt}, W fmt {w.fmt} weight={w.weight})")
-    elif fmt != FMT_B3:
+    elif fmt not in (FMT_B3, FMT_F3):
         raise RuntimeError("mmsa.gemm: h8 weights need A as h8 planes")
     else:
         pa, ma, ka, lda = _mat(a, "A")
@@ -267,17 +270,17 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
 
 def convnext_mlp_fused(a, w1, w2, b1, b2, gamma, x, m, batch=1, stride_a=0, stride_w1=0, stride_w2=0, stride_x=0):
     """x[b] <- x[b] + gamma[b] * (gelu(a[b] @ w1[b].T + b1[b]) @ w2[b].T + b2[b]) in place (one kernel; C = 96).
-    a: bf16 hi/lo activation Planes; w1 [4C, C], w2 [C, 4C]: bf16 hi/lo weight Planes (first batch; batch strides in uint16 units)."""
+    a: bf16 hi/lo or f3 activation Planes; w1 [4C, C], w2 [C, 4C]: weight Planes of the same format (first batch; batch strides in uint16 units)."""
     pa, _, _, lda = a.mat("A")
     px, _, c, ldx = _mat(x, "x")
-    if a.fmt != FMT_B3 or w1.fmt != FMT_B3 or w2.fmt != FMT_B3:
-        raise RuntimeError("mmsa.convnext_mlp_fused: bf16 hi/lo planes expected")
+    if a.fmt not in (FMT_B3, FMT_F3) or w1.fmt != a.fmt or w2.fmt != a.fmt:
+        raise RuntimeError("mmsa.convnext_mlp_fused: bf16 hi/lo or f3 planes expected, the same format for A, W1 and W2")
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = _event(), _event()
         lib.call("mmsa_event_record", e0, _stream())
     lib.call("mmsa_convnext_mlp_fused", pa, lda, stride_a, w1.p.data_ptr(), stride_w1, w2.p.data_ptr(), stride_w2, _chk(b1), _chk(b2),
-             _chk(gamma), px, ldx, stride_x, m, c, batch, GEMM_MAX_GRID, _stream())
+             _chk(gamma), px, ldx, stride_x, m, c, batch, GEMM_MAX_GRID, a.fmt, _stream())
     if prof is not None:      # both contractions of the pair count towards the GEMM family (bench.py roofline)
         lib.call("mmsa_event_record", e1, _stream())
         prof.append((2.0 * 2.0 * m * c * 4 * c * batch, e0, e1, 4.0 * batch * (m * c * 3 + 2 * 4 * c * c)))

@@ -460,8 +460,9 @@ def test_gconv3_on_the_matrix_pipe(ops, cg, H, W):
     assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("fmt_name", ["b3", "f3"])
 @pytest.mark.parametrize("C,M", [(96, 1000), (96, 128), (96, 70000), (96, 33)])
-def test_convnext_mlp_fused(C, M):
+def test_convnext_mlp_fused(C, M, fmt_name):
     """mmsa_convnext_mlp_fused (TC:107-132 pointwise_conv1 -> GELU -> pointwise_conv2 -> gamma -> + residual, two batched streams)
     against fp64 torch and against the two separate GEMM launches it replaces."""
     import mmsa
@@ -478,21 +479,38 @@ def test_convnext_mlp_fused(C, M):
         h = F.gelu(a[s * M:(s + 1) * M].double() @ w1[s * 4 * C:(s + 1) * 4 * C].double().t() + b1[s * 4 * C:(s + 1) * 4 * C].double())
         y = h @ w2[s * C:(s + 1) * C].double().t() + b2[s * C:(s + 1) * C].double()
         ref[s * M:(s + 1) * M] = (x0[s * M:(s + 1) * M].double() + gam[s * C:(s + 1) * C].double() * y).float()
-    ap = ops.split_planes(a.to(DEV), kpad=ops.pad32(C))
-    w1p = ops.split_planes(w1.to(DEV)); w1p = ops.Planes(w1p.p, 4 * C, C, w1p.kpad)
-    w2p = ops.split_planes(w2.to(DEV)); w2p = ops.Planes(w2p.p, C, 4 * C, w2p.kpad)
+    fmt = ops.FMT_F3 if fmt_name == "f3" else ops.FMT_B3      # f3: fp16 hi/lo pairs, 22 significant bits (round 4: the model's default here)
+    ap = ops.split_planes(a.to(DEV), kpad=ops.pad32(C), fmt=fmt)
+    w1p = ops.split_planes(w1.to(DEV), fmt=fmt); w1p = ops.Planes(w1p.p, 4 * C, C, w1p.kpad, fmt)
+    w2p = ops.split_planes(w2.to(DEV), fmt=fmt); w2p = ops.Planes(w2p.p, C, 4 * C, w2p.kpad, fmt)
     x = x0.to(DEV).clone()
     ops.convnext_mlp_fused(ap, w1p, w2p, b1.to(DEV), b2.to(DEV), gam.to(DEV), x, M, batch=b, stride_a=M * 2 * ap.kpad,
                            stride_w1=4 * C * 2 * w1p.kpad, stride_w2=C * 2 * w2p.kpad, stride_x=M * C)
-    assert_close(x, ref, tol=3e-5, what="fused ConvNeXt MLP vs fp64")
+    assert_close(x, ref, tol=3e-5 if fmt == ops.FMT_B3 else 3e-6, what="fused ConvNeXt MLP vs fp64")
     # the pair of launches it replaces
-    hb = ops.alloc_planes(b * M, 4 * C, DEV)
+    hb = ops.alloc_planes(b * M, 4 * C, DEV, fmt=fmt)
     x2 = x0.to(DEV).clone()
     ops.gemm(ap, w1p, bias=b1.to(DEV), act="gelu", out_planes=hb, batch=b, m=M, stride_a=M * 2 * ap.kpad, stride_w=4 * C * 2 * w1p.kpad,
              stride_bias=4 * C, stride_cp=M * 2 * hb.kpad)
     ops.gemm(hb, w2p, x2, bias=b2.to(DEV), colscale=gam.to(DEV), resid=x2, batch=b, m=M, stride_a=M * 2 * hb.kpad, stride_w=C * 2 * w2p.kpad,
              stride_bias=C, stride_r=M * C, stride_c=M * C)
     assert_close(x, x2, tol=5e-6, what="fused vs the two GEMM launches")
+
+
+def test_gemm_f3_weights_fp32_activations():
+    """The ConvNeXt stem (TC:297-304 as a patch-matrix GEMM): fp32 A split to fp16 hi/lo while staged, f3 weight planes, batched per stream."""
+    import mmsa
+    ops = mmsa.ops
+    g = torch.Generator().manual_seed(191)
+    M, K, N, b = 1000, 48, 96, 2
+    a = torch.randn(b * M, 64, generator=g); a[:, K:] = 0
+    w = torch.randn(b * N, K, generator=g) / K ** 0.5
+    bias = torch.randn(b * N, generator=g)
+    wp = ops.split_planes(w.to(DEV), kpad=64, fmt=ops.FMT_F3); wp = ops.Planes(wp.p, N, K, wp.kpad, ops.FMT_F3)
+    out = torch.empty(b * M, N, device=DEV)
+    ops.gemm(a.to(DEV), wp, out, bias=bias.to(DEV), batch=b, m=M, stride_a=M * 64, stride_w=N * 2 * 64, stride_bias=N, stride_c=M * N)
+    ref = torch.cat([a[i * M:(i + 1) * M, :K].double() @ w[i * N:(i + 1) * N].double().t() + bias[i * N:(i + 1) * N].double() for i in range(b)], 0).float()
+    assert_close(out, ref, tol=2e-6, what="fp32-A gemm on f3 weights")
 
 
 def test_zero_bytes(ops):

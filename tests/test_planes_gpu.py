@@ -817,3 +817,62 @@ def test_gemm_layernorm_fold(ops, fmt_name, act):
     assert not torch.equal(out2.p, out.p)
     with pytest.raises(RuntimeError, match="row statistics"):
         ops.gemm(ap, w0p, x, bias=b0.to(DEV), act="gelu", rowstats_out=rs)
+
+
+# ---- f3 planes (round 4): the bf16 hi/lo layout with fp16 halves -- 22 significant bits, the same three MFMAs per product
+@pytest.mark.parametrize("M,N,K,act", [(512, 384, 1536, "none"), (300, 1536, 384, "gelu"), (96, 200, 96, "relu")])
+def test_gemm_f3_operands(ops, M, N, K, act):
+    """fp16 hi/lo operands: round trip of the planes (2^-21 relative), the GEMM against fp64 (an order of magnitude inside what bf16 hi/lo
+    gives on the same data), against its own emulation (fp32 accumulation order only), planes outputs in f3 and bf16 hi/lo, clamp at the fp16 range."""
+    a = torch.randn(M, K, generator=g(341)) * 1.7
+    w = torch.randn(N, K, generator=g(342)) / K ** 0.5
+    b = torch.randn(N, generator=g(343))
+    res = torch.randn(M, N, generator=g(344))
+    fact = {"none": lambda t: t, "gelu": F.gelu, "relu": F.relu}[act]
+    ref = fact(F.linear(a.double(), w.double(), b.double())).float() + res
+    ap = ops.split_planes(a.to(DEV), fmt=ops.FMT_F3)
+    wp = ops.split_planes(w.to(DEV), fmt=ops.FMT_F3)
+    back = planes_to_float(ap)[:, :K].cpu()
+    assert ((back - a).abs() <= a.abs() * 2.0 ** -21 + 1e-7).all(), "f3 planes carry 22 significant bits"
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(ap, wp, out, bias=b.to(DEV), act=act, resid=res.to(DEV))
+    assert_close(out, ref, tol=2e-6, what="f3 gemm vs fp64")
+    outb = torch.empty(M, N, device=DEV)
+    ops.gemm(ops.split_planes(a.to(DEV), kpad=ap.kpad), ops.split_planes(w.to(DEV)), outb, bias=b.to(DEV), act=act, resid=res.to(DEV))
+    e3 = ((out.cpu().double() - ref.double()).norm() / ref.double().norm()).item()
+    eb = ((outb.cpu().double() - ref.double()).norm() / ref.double().norm()).item()
+    assert e3 < 0.25 * eb, f"f3 {e3:.2e} should be well inside bf16 hi/lo {eb:.2e}"
+    for ofmt in (ops.FMT_F3, ops.FMT_B3):
+        outp = ops.alloc_planes(M, N, DEV, zero=True, fmt=ofmt)
+        ops.gemm(ap, wp, bias=b.to(DEV), act=act, resid=res.to(DEV), out_planes=outp)
+        assert_close(planes_to_float(outp), ref, tol=3e-6 if ofmt == ops.FMT_F3 else 2e-5, what=f"f3 gemm planes out fmt {ofmt}")
+        if ofmt == ops.FMT_F3:     # bit-identical to splitting the fp32 output of the same GEMM
+            assert torch.equal(planes_to_float(outp), planes_to_float(ops.split_planes(out, fmt=ops.FMT_F3)))
+    # f3 planes out of bf16 hi/lo operands, and values beyond the fp16 range are clamped, not turned into inf
+    outp = ops.alloc_planes(M, N, DEV, zero=True, fmt=ops.FMT_F3)
+    ops.gemm(ops.split_planes(a.to(DEV), kpad=ap.kpad), ops.split_planes(w.to(DEV)), bias=b.to(DEV), act=act, resid=res.to(DEV), out_planes=outp)
+    assert_close(planes_to_float(outp), ref, tol=2e-5, what="bf16 hi/lo gemm, f3 planes out")
+    big = torch.tensor([[1e6, -1e6, 70000.0, 3.0e-6, -2.0e-7, 1.0] + [0.0] * 26], device=DEV)
+    bp = planes_to_float(ops.split_planes(big, fmt=ops.FMT_F3)).cpu()[0]
+    assert torch.isfinite(bp).all() and bp[0] == 65504.0 and bp[1] == -65504.0 and bp[2] == 65504.0
+    assert abs(bp[3].item() - 3.0e-6) <= 6.1e-8 and abs(bp[4].item() + 2.0e-7) <= 6.1e-8 and bp[5] == 1.0
+
+
+def test_layernorm_and_batched_gemm_f3(ops):
+    """LayerNorm writing f3 planes (whole-line pair stores and the 4-column path) and the batched two-stream GEMM chain of a ConvNeXt block on them."""
+    rows, C = 640, 384
+    x = torch.randn(2 * rows, C, generator=g(351)) * 2 + 0.3
+    lw = torch.randn(2, C, generator=g(352)); lb = torch.randn(2, C, generator=g(353))
+    n = ops.alloc_planes(2 * rows, C, DEV, fmt=ops.FMT_F3)
+    ops.layernorm(x.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, out_planes=n, group_rows=rows, w_gstride=C)
+    ref = torch.cat([F.layer_norm(x[i * rows:(i + 1) * rows].double(), (C,), lw[i].double(), lb[i].double(), 1e-6) for i in range(2)], 0).float()
+    assert_close(planes_to_float(n), ref, tol=2e-6, what="layernorm f3 planes")
+    w1 = torch.randn(2, 4 * C, C, generator=g(354)) / C ** 0.5; b1 = torch.randn(2, 4 * C, generator=g(355))
+    w1p = [ops.split_planes(w1[i].to(DEV), fmt=ops.FMT_F3) for i in range(2)]
+    full = torch.cat([w1p[0].p, w1p[1].p], 0).contiguous()
+    wpl = ops.Planes(full[:4 * C], 4 * C, C, w1p[0].kpad, ops.FMT_F3, False)
+    h = ops.alloc_planes(2 * rows, 4 * C, DEV, fmt=ops.FMT_F3)
+    ops.gemm(n, wpl, bias=b1.reshape(-1).to(DEV), act="gelu", out_planes=h, batch=2, m=rows, stride_a=rows * 2 * n.kpad,
+             stride_w=4 * C * 2 * wpl.kpad, stride_bias=4 * C, stride_cp=rows * 2 * h.kpad)
+    href = torch.cat([F.gelu(F.linear(ref[i * rows:(i + 1) * rows].double(), w1[i].double(), b1[i].double())) for i in range(2)], 0).float()
+    assert_close(planes_to_float(h), href, tol=3e-6, what="batched f3 gemm + gelu, f3 planes out")

@@ -58,7 +58,7 @@ def neck_only(levels=(0, 1, 2, 3)):
     main = torch.cuda.current_stream()
     f = torch.cuda.Event(); f.record(main); joins = []
     for i in levels:
-        sn = m._side[i]; sn.wait_event(f)
+        sn = next(iter(m._sides.values()))[i]; sn.wait_event(f)
         with torch.cuda.stream(sn):
             out = c1 if i == 0 else cbuf[offs[i]:]
             m._neck_level(i, pk["neck"][i], tcat[i], B, sizes[i][0], sizes[i][1], chans[i], out, 0 if i == 0 else Nc * D, tcat_p[i])
@@ -82,7 +82,7 @@ print(f"eager: SPM {eager_time(_spm_joined):.2f} ms, conv {eager_time(conv_only)
 def both_independent():
     main = torch.cuda.current_stream()
     f = torch.cuda.Event(); f.record(main)
-    sn = m._side[0]; sn.wait_event(f)
+    sn = next(iter(m._sides.values()))[0]; sn.wait_event(f)
     with torch.cuda.stream(sn):
         m._neck_level(0, pk["neck"][0], tcat[0], B, sizes[0][0], sizes[0][1], chans[0], c1, 0, tcat_p[0])
         e = torch.cuda.Event(); e.record(sn)
