@@ -28,13 +28,15 @@
  *                   values, then four 16-byte chunks, chunk g = 8 bytes e5m2(lo * 2^11) + 8 bytes e5m2(hi) of k = 8g..8g+7 for an
  *                   ACTIVATION (A operand) row, the two halves swapped for a WEIGHT (W operand) row.  |x| is clamped to 57344.
  *      MMSA_FMT_F3  (round 4) the MMSA_FMT_B3 layout with fp16 halves: x = fp16(x) + fp16(x - fp16(x)), 22 significant bits instead of 16, the same
- *                   three MFMAs per product (on the fp16 MFMA); values are clamped to +-65504.  Read by mmsa_gemm_split3 with A planes (the
- *                   LDS-DMA kernel); written by it, by mmsa_layernorm_rows and by mmsa_split_planes (kind 4).  The TwinConvNeXt chain uses it.
+ *                   three MFMAs per product (on the fp16 MFMA); values are clamped to +-65504.  Read by mmsa_gemm_split3 (A as planes, or fp32 A
+ *                   with fp32 outputs) and mmsa_convnext_mlp_fused; written by the GEMM, by mmsa_layernorm_rows and by mmsa_split_planes (kind 4).
+ *                   The TwinConvNeXt chain uses it.
  *      MMSA_FMT_H8C the h8 arithmetic on 3 bytes per element (round 4), laid out for the LDS-DMA operand stream of the GEMM: q(hi) is not
  *                   stored (the e5m2 image of an fp16 value is its top byte; the GEMM takes it in registers) and rows are stored in PAIRS --
  *                   pair j of a [rows, K] matrix (K padded to a multiple of 64, rows to even) occupies `ld` uint16 (>= 3 K):
  *                   [row 2j: K fp16 hi][row 2j+1: K fp16 hi][K / 64 lines of 128 bytes: chunk c = {row 2j: 64 lo bytes | row 2j+1: 64 lo bytes}],
- *                   a row's 64 lo bytes of a chunk = 4 groups g of 16 bytes = e5m2(lo * 2^11) of k = 64c + 8g .. +7, then of k = 64c + 32 + 8g .. +7.
+ *                   a row's 64 lo bytes of a chunk = 4 groups g of 16 bytes = e5m2(lo * 2^11 * 1.09375) of k = 64c + 8g .. +7, then of k = 64c + 32 + 8g .. +7
+ *                   (the factor 1.09375 makes up for q(hi) being the TRUNCATED top byte of hi in this format: csrc/common.h MMSA_H8C_LO_COMP).
  *                   Every `ld*` of h8c planes is the row-PAIR stride; activations and weights share the layout.  1.5 cache lines per row and
  *                   64 k-values where MMSA_FMT_H8 has 2: the GEMM's L2 -> LDS stream is what bounds its k loop (csrc/gemm_h8c.hip).
  *    `mmsa_split_planes` converts fp32; producer kernels emit the format of their `*_fmt` argument (h8c: mmsa_gemm_split3, mmsa_layernorm_rows,

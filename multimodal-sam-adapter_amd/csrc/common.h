@@ -153,6 +153,10 @@ enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2, MMSA_FMT_F3 = 3 };
 #define MMSA_H8_MAX 57344.0f
 #define MMSA_H8_LO_SCALE 2048.0f          // 2^11
 #define MMSA_H8_MFMA_SCALE 0x74747474     // e8m0 127 - 11 in every byte: the block scale that undoes MMSA_H8_LO_SCALE
+// h8c planes: q(hi) is the TRUNCATED top byte of the fp16 value (taken in registers), i.e. on average 9 % short of hi -- every cross term hi x lo would come
+// out 9 % small, which is the larger part of that format's error.  The lo bytes of h8c planes are therefore stored scaled by 2^11 x 1.09375: the mean of
+// trunc(hi) x 1.09375 lo is hi x lo again (random 512 x 1024 x 512 products: 3.11e-5 -> 2.13e-5 relative, rounded q(hi): 2.08e-5; profiles/r04_f3_study.txt).
+#define MMSA_H8C_LO_COMP 1.09375f
 typedef __attribute__((ext_vector_type(2))) _Float16 mmsa_h2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // operand of v_mfma_f32_16x16x32_f16
 // two floats -> fp16 hi pair + fp16 lo pair (lo = a - hi, itself rounded to fp16: 22 significant bits together)
@@ -191,23 +195,25 @@ __device__ __forceinline__ void split4_fmt(const float4 v, uint2& hi, uint2& lo,
 }
 
 // two floats -> hi (2 packed fp16), lo8 / qh8 (2 e5m2 bytes each, written into the low or high half of `lo8` / `qh8`)
-template <bool UPPER>
+template <bool UPPER, bool COMP = false>
 __device__ __forceinline__ void h8_split2(float a, float b, unsigned& hi, unsigned& lo8, unsigned& qh8) {
   a = __builtin_amdgcn_fmed3f(a, -MMSA_H8_MAX, MMSA_H8_MAX);
   b = __builtin_amdgcn_fmed3f(b, -MMSA_H8_MAX, MMSA_H8_MAX);
   const mmsa_f32x2 v = {a, b};
   const mmsa_h2 h = __builtin_convertvector(v, mmsa_h2);            // round to nearest even
   const mmsa_f32x2 hf = __builtin_convertvector(h, mmsa_f32x2);
-  const float la = (a - hf.x) * MMSA_H8_LO_SCALE, lb = (b - hf.y) * MMSA_H8_LO_SCALE;   // exact
+  constexpr float ls_ = COMP ? MMSA_H8_LO_SCALE * MMSA_H8C_LO_COMP : MMSA_H8_LO_SCALE;
+  const float la = (a - hf.x) * ls_, lb = (b - hf.y) * ls_;   // (exact without COMP)
   hi = __builtin_bit_cast(unsigned, h);
   lo8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(la, lb, (int)lo8, UPPER);
   qh8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(hf.x, hf.y, (int)qh8, UPPER);
 }
 // four floats -> 4 fp16 (8 bytes), 4 lo bytes, 4 q(hi) bytes
+template <bool COMP = false>
 __device__ __forceinline__ void h8_split4(const float4 v, uint2& hi, unsigned& lo8, unsigned& qh8) {
   lo8 = 0u; qh8 = 0u;
-  h8_split2<false>(v.x, v.y, hi.x, lo8, qh8);
-  h8_split2<true>(v.z, v.w, hi.y, lo8, qh8);
+  h8_split2<false, COMP>(v.x, v.y, hi.x, lo8, qh8);
+  h8_split2<true, COMP>(v.z, v.w, hi.y, lo8, qh8);
 }
 // byte offset, inside its row, of the 4-byte group holding the lo bytes of columns c .. c+3 (c % 4 == 0) of an ACTIVATION row;
 // the q(hi) bytes sit 8 bytes further
@@ -303,7 +309,7 @@ __host__ __device__ __forceinline__ int h8c_lo_off(int k) { return ((k >> 6) << 
 // 4 consecutive columns c .. c+3 (c % 4 == 0) of one row
 __device__ __forceinline__ void h8c_store4(const H8cRow r, int c, const float4 v) {
   uint2 hi; unsigned lo8, qh8;
-  h8_split4(v, hi, lo8, qh8);
+  h8_split4<true>(v, hi, lo8, qh8);
   *reinterpret_cast<uint2*>(r.hi + c) = hi;
   *reinterpret_cast<unsigned*>(r.lo + h8c_lo_off(c)) = lo8;
 }
@@ -312,7 +318,7 @@ __device__ __forceinline__ void h8c_store4(const H8cRow r, int c, const float4 v
 template <int XOR>
 __device__ __forceinline__ void h8c_store8_pair(const H8cRow r, int c8, const float4 v, bool odd, bool do_store) {
   uint2 hi; unsigned lo8, qh8;
-  h8_split4(v, hi, lo8, qh8);
+  h8_split4<true>(v, hi, lo8, qh8);
   const uint2 snd = odd ? hi : make_uint2(lo8, 0u);
   uint2 rcv;
   rcv.x = __shfl_xor(snd.x, XOR, 64);
@@ -324,7 +330,7 @@ __device__ __forceinline__ void h8c_store8_pair(const H8cRow r, int c8, const fl
 // one element (ragged edges; rare)
 __device__ __forceinline__ void h8c_store1(const H8cRow r, int c, float x) {
   unsigned hi, lo8 = 0u, qh8 = 0u;
-  h8_split2<false>(x, 0.f, hi, lo8, qh8);
+  h8_split2<false, true>(x, 0.f, hi, lo8, qh8);
   r.hi[c] = (unsigned short)(hi & 0xFFFFu);
   r.lo[h8c_lo_off(c)] = (unsigned char)(lo8 & 0xFFu);
 }

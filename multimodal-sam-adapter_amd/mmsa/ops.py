@@ -175,7 +175,7 @@ def planes_to_float(pl, cols=None):
         hi = by[:, :4 * kp].contiguous().view(torch.float16).float().reshape(2 * r, kp)
         lo = by[:, 4 * kp:].reshape(r, kp // 64, 2, 4, 2, 8).permute(0, 2, 1, 4, 3, 5)        # [pair, row, chunk, k-tile, g, e]
         lo = lo.contiguous().view(torch.float8_e5m2).float().reshape(2 * r, kp)
-        return (hi + lo / 2048.0)[:pl.n, :(pl.k if cols is None else cols)]
+        return (hi + lo / (2048.0 * 1.09375))[:pl.n, :(pl.k if cols is None else cols)]   # csrc/common.h MMSA_H8C_LO_COMP
     if pl.fmt == FMT_H8:
         blk = pl.p.contiguous().view(torch.uint8).view(r, w // 64, 128)
         hi = blk[:, :, :64].contiguous().view(torch.float16).float()                       # [r, nb, 32]

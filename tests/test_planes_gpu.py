@@ -560,11 +560,15 @@ def test_gemm_h8_exact_on_integers_and_cross_terms(ops):
 # ---------------------------------------------------------------------------------------------------------------------------
 # "h8c" operand planes (round 4; csrc/common.h, csrc/gemm_h8c.hip): the h8 arithmetic on 3 bytes per element, rows stored in pairs, q(hi) taken
 # in registers as the fp16 value's top byte (truncation)
+H8C_LO_COMP = 1.09375
+
+
 def _h8c_emulated_product(a, w):
-    """hi.hi exactly + the two cross terms with q(hi) = the fp16 hi value truncated to its top byte (an e5m2) and lo rounded to e5m2."""
+    """hi.hi exactly + the two cross terms with q(hi) = the fp16 hi value truncated to its top byte (an e5m2) and lo rounded to e5m2 after the
+    scaling by 2^11 x 1.09375 that makes up for the truncation's mean (csrc/common.h MMSA_H8C_LO_COMP; the MFMA's block scale undoes the 2^11)."""
     ah = a.clamp(-57344, 57344).half()
     wh = w.clamp(-57344, 57344).half()
-    al, wl = (a - ah.float()) * 2048, (w - wh.float()) * 2048
+    al, wl = (a - ah.float()) * (2048 * H8C_LO_COMP), (w - wh.float()) * (2048 * H8C_LO_COMP)
     q = lambda t: t.to(torch.float8_e5m2).float()
     trunc = lambda h: (h.view(torch.int16) & -256).view(torch.float16).float()
     return ah.double() @ wh.double().t() + (trunc(ah).double() @ q(wl).double().t() + q(al).double() @ trunc(wh).double().t()) / 2048
@@ -582,7 +586,7 @@ def test_split_planes_h8c_roundtrip_and_layout(ops):
     assert torch.equal(hi[:37, :150].float(), x.half().float())
     # lo lines: chunk c of pair j = [row 2j: 64 B | row 2j+1: 64 B]; a row's 64 B = 4 groups g of [k = 64c + 8g .. +7 | k = 64c + 32 + 8g .. +7]
     lo = raw[:, 4 * 192:].reshape(19, 3, 2, 4, 2, 8)
-    want = ((x - x.half().float()) * 2048).to(torch.float8_e5m2).float()
+    want = ((x - x.half().float()) * (2048 * H8C_LO_COMP)).to(torch.float8_e5m2).float()
     r, k = 36, 64 + 32 + 8 * 2 + 5                                         # row 36 (pair 18, first row), chunk 1, second k-tile, group 2, byte 5
     assert lo[18, 1, 0, 2, 1, 5].view(torch.float8_e5m2).float() == want[r, k]
     r, k = 7, 3                                                             # row 7 (pair 3, second row), chunk 0, first k-tile, group 0, byte 3
@@ -636,13 +640,13 @@ def test_gemm_h8c_exact_on_integers_and_cross_terms(ops):
     M, N, K = 512, 256, 256
     a = torch.randint(-8, 9, (M, K), generator=g(246)).float()
     w = torch.randint(-8, 9, (N, K), generator=g(247)).float()
-    w[:, 0] += 100 * torch.arange(N)              # asymmetric: catches row/column swaps
+    w[:, 0] = 16.0 * torch.arange(N)              # asymmetric: catches row/column swaps (multiples of 16 up to 4080: exact in fp16, lo = 0)
     out = torch.empty(M, N, device=DEV)
     ops.gemm(ops.split_planes(a.to(DEV), fmt=ops.FMT_H8C), ops.split_planes(w.to(DEV), fmt=ops.FMT_H8C), out)
     assert torch.equal(out.cpu(), a @ w.t())
     u = torch.randint(-1, 2, (M, K), generator=g(248)).float()
     v = torch.randint(-1, 2, (N, K), generator=g(249)).float()
-    a2, w2 = 1 + u * 2 ** -12, 1 + v * 2 ** -12      # hi = 1 (its top byte too), lo = +-2^-12: exact in e5m2 after the 2^11 scaling
+    a2, w2 = 1 + u * 2 ** -12, 1 + v * 2 ** -12      # hi = 1 (its top byte too), lo = +-2^-12: +-0.547 after the 2^11 x 1.09375 scaling, which e5m2 rounds to +-0.5
     ops.gemm(ops.split_planes(a2.to(DEV), fmt=ops.FMT_H8C), ops.split_planes(w2.to(DEV), fmt=ops.FMT_H8C), out)
     exact = (K + (u.sum(1)[:, None] + v.sum(1)[None, :]) * 2 ** -12).double()
     assert (out.cpu().double() - exact).abs().max() <= 1e-6
