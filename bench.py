@@ -594,7 +594,7 @@ def main():
             "metric": f"images/sec encoder fwd @{size}x{size} RGB+LiDAR {arch}" if not STUB else "stub (no GPU): control path of the N > 1 bench",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8c / h8 planes, ViT / interaction / up-conv GEMMs) and bf16 hi/lo x3 (ConvNeXt, neck); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, bf16 hi/lo (and bf16 hi/lo block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
+            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8c / h8 planes, ViT / interaction / up-conv GEMMs) fp16 hi/lo pairs x3 (TwinConvNeXt: f3 planes) and bf16 hi/lo x3 (neck, head); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, bf16 hi/lo (and bf16 hi/lo block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else

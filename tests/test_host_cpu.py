@@ -424,3 +424,36 @@ def test_planes_with_a_column_split_host_logic():
     got = ops.planes_to_float(ops.Planes(p, 2, 96, 96, ops.FMT_B3, split=64))
     assert torch.equal(got[:, :64], x[:, :64].bfloat16().float() + (x[:, :64] - x[:, :64].bfloat16().float()).bfloat16().float())
     assert (got[:, 64:] - x[:, 64:]).abs().max() <= 2.0 ** -13 * x.abs().max()
+
+
+def test_f3_and_h8c_planes_host_logic():
+    """The two plane formats of round 4 on the host side (no GPU: torch ops only): shapes / strides ops.Planes derives, the GEMM's cp_fmt encoding,
+    and the decode helper on hand-packed rows -- f3 = the bf16 hi/lo layout with fp16 halves; h8c = row pairs, lo bytes scaled by 2^11 * 1.09375
+    (csrc/common.h MMSA_H8C_LO_COMP: what makes up for the truncated q(hi))."""
+    from mmsa import ops
+    assert (ops.FMT_B3, ops.FMT_H8, ops.FMT_H8C, ops.FMT_F3) == (0, 1, 2, 3)
+    pl = ops.alloc_planes(6, 96, "cpu", fmt=ops.FMT_F3)
+    assert tuple(pl.p.shape) == (6, 192) and pl.fmt == ops.FMT_F3 and ops.cp_format(pl) == ops.FMT_F3 and pl.rows(2, 4).fmt == ops.FMT_F3
+    assert ops.planes_shape(6, 96, ops.FMT_F3) == ops.planes_shape(6, 96, ops.FMT_B3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, generator=g) * 3
+    x[0, :4] = torch.tensor([3.0e-6, -2.0e-7, 1.0, 1000.5])
+    p = torch.zeros(2, 128, dtype=torch.int16)
+    for blk in range(2):
+        v = x[:, 32 * blk:32 * blk + 32]
+        hi = v.half()
+        p[:, 64 * blk:64 * blk + 32] = hi.view(torch.int16)
+        p[:, 64 * blk + 32:64 * blk + 64] = (v - hi.float()).half().view(torch.int16)
+    got = ops.planes_to_float(ops.Planes(p, 2, 64, 64, ops.FMT_F3))
+    assert ((got - x).abs() <= x.abs() * 2.0 ** -21 + 6.1e-8).all()
+    # h8c: one row pair, K = 64: [row 0: 64 fp16][row 1: 64 fp16][one 128-byte line: row 0's 64 lo bytes | row 1's], a row's lo bytes = 4 groups of
+    # [k = 8g .. 8g+7 | k = 32 + 8g .. 32 + 8g + 7]
+    hp = ops.alloc_planes(2, 64, "cpu", fmt=ops.FMT_H8C)
+    assert tuple(hp.p.shape) == (1, 192) and hp.kpad == 64 and hp.batch_stride(2) == 192
+    hi = x.half()
+    lo = ((x - hi.float()) * (2048.0 * 1.09375)).to(torch.float8_e5m2).view(torch.uint8)            # [2, 64]
+    line = lo.view(2, 2, 4, 8).permute(0, 2, 1, 3).reshape(2, 64)                                  # [row][g][k-tile][e]
+    raw = torch.cat([hi.view(torch.uint8).reshape(-1), line.reshape(-1)]).view(torch.int16).view(1, 192)
+    got = ops.planes_to_float(ops.Planes(raw, 2, 64, 64, ops.FMT_H8C))
+    assert torch.equal(got, hi.float() + lo.view(torch.float8_e5m2).float() / (2048.0 * 1.09375))
+    assert (got - x).abs().max() <= 2.0 ** -13 * x.abs().max()
