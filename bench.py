@@ -536,7 +536,7 @@ def main():
                 wrep, _, _ = capture(local_step)
             wdt = timed(wrep)
             worst = {"value": round(a.batch * a.steps / wdt, 3), "unit": "images/s", "ms_per_step": round(wdt / a.steps * 1e3, 3),
-                     "formats": "every GEMM and attention operand bf16 hi/lo (h8_sites = (), attention_precision = 'b3'); same step, same graphs / chains form",
+                     "formats": "every GEMM and attention operand a 16-bit hi/lo PAIR, three MFMAs per product (h8_sites = (), attention_precision = 'b3': fp16 pairs in the ViT blocks, the attention kernels and the TwinConvNeXt chain, bf16 pairs in the interaction / neck / head GEMMs); same step, same graphs / chains form",
                      "vs_value": round(a.batch * a.steps / wdt / value, 4)}
             del wrep
         finally:
@@ -594,7 +594,7 @@ def main():
             "metric": f"images/sec encoder fwd @{size}x{size} RGB+LiDAR {arch}" if not STUB else "stub (no GPU): control path of the N > 1 bench",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8c / h8 planes, ViT / interaction / up-conv GEMMs) fp16 hi/lo pairs x3 (TwinConvNeXt: f3 planes) and bf16 hi/lo x3 (neck, head); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, bf16 hi/lo (and bf16 hi/lo block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
+            "dtype": "split-operand MFMA: fp16 hi + e5m2 cross terms (h8c / h8 planes, ViT / interaction / up-conv GEMMs) fp16 hi/lo pairs x3 (TwinConvNeXt: f3 planes) and bf16 hi/lo x3 (neck, head); attention blocks with the rel-pos terms fused: every contraction on one fp16 MFMA (q, k, v, P rounded to fp16) in the blocks whose measured max |logit| is below 8, fp16 hi/lo pairs (and fp16 hi/lo pair block GEMMs) in the others (config.attention_blocks); fp32 accumulate, fp32 activations", "data": "synthetic",
             "config": {"workload": f"{a.config}: SAM ViT-L encoder + RGB+LiDAR adapter forward, 1024x1024, batch {a.batch} per GPU"
                        if headline else f"{a.config} (NOT the BASELINE headline workload)",
                        "stage": "encoder forward only" if head is None else

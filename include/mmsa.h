@@ -116,7 +116,7 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * fmt = format of the A and W planes (MMSA_FMT_H8 / MMSA_FMT_H8C: A must come as planes, K % 64 == 0; H8C also M >= 128; lda / ldcp of h8c planes =
  * row-pair strides >= 3 K / 3 pad64(N)); cp_fmt = format written to `Cp`:
  * bits 0..7 MMSA_FMT_*, bits 8.. = split / 32 -- columns >= split (a multiple of 32; 0 = none) are written as MMSA_FMT_H8 planes
- * whatever the base format (the qkv projection: q and k bf16 hi/lo, v with an fp16 hi part for the attention kernels' v_fmt = 1).
+ * whatever the base format (the qkv projection: q and k as f3 planes, v with an fp16 hi part for the attention kernels' v_fmt = 1).
  * max_grid > 0 caps the number of persistent workgroups (a caller running independent chains on concurrent streams gives each
  * its share of the CUs); 0 = all CUs.  Results do not depend on it. */
 /* LayerNorm folded into a producer / consumer pair of GEMMs (base/image_encoder.py:396-421: x -> norm1 -> qkv, x -> norm2 -> lin1): three
@@ -152,7 +152,8 @@ int mmsa_convnext_mlp_fused(const uint16_t* Ap, long lda, long strideA, const ui
                             int M, int C, int batch, int max_grid, int fmt, mmsa_stream_t stream);
 
 /* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
- * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows; 3: h8c planes [ceil(rows / 2), 3*cols_pad] (cols_pad % 64 == 0; activations and weights). */
+ * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows; 3: h8c planes [ceil(rows / 2), 3*cols_pad] (cols_pad % 64 == 0; activations and weights);
+ * 4: f3 (fp16 hi/lo pairs in the bf16 hi/lo layout). */
 int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes, int kind,
                       mmsa_stream_t stream);
 
@@ -161,7 +162,7 @@ int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pa
  * |logit| it scores -- scale * q.k + the rel-pos terms, natural units, over existing keys (pad tokens of a window included, they are
  * attended to) and live queries -- into it with an atomic max (never lowered; the caller zeroes it).  The reference computes attention
  * in fp32 (IE:488-499) and needs no such word; this library chooses the operand precision of a block's attention (v_fmt) from it:
- * the host reads it after the step and moves a block whose logits outgrow fp16 operands to bf16 hi/lo ones (mmsa/backbone.py). */
+ * the host reads it after the step and moves a block whose logits outgrow single fp16 operands to fp16 hi/lo PAIRS (f3 planes; mmsa/backbone.py). */
  * qkv [B*H*W, ldq] = q|k|v, channel = head*head_dim + c; qkv_bias [3*D]; rp from mmsa_relpos_bias;
  * window_size 0 = global.  out [B*H*W, ldo]. head_dim in {32, 64}. */
 int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo, int B,
@@ -170,7 +171,7 @@ int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const floa
 int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* bias_planes, const float* rp,
                           uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim,
                           int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
-                          int v_fmt /* 0: qkv_planes / bias_planes are bf16 hi/lo planes; 1 (this entry): their v columns are h8 planes (fp16 hi,
+                          int v_fmt /* 0: qkv_planes / bias_planes (and the rel-pos planes of the fused entries) are MMSA_FMT_F3 planes -- fp16 hi/lo pairs, three fp16 MFMAs per product; round 4: bf16 hi/lo planes before, same layout, NOT accepted any more; 1 (this entry): their v columns are h8 planes (fp16 hi,
                                        as the qkv GEMM writes them with cp_fmt = MMSA_FMT_B3 | (2D/32) << 8): P V runs on the fp16 MFMA with
                                        P rounded to fp16; 2 (the two fused rel-pos entries below): qkv_planes, bias_planes AND relpos_planes
                                        are h8 planes throughout (and the window kernel's selector holds fp16 ones): every contraction of

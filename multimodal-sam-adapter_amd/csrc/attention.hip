@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       v0.x *= a.scale; v0.y *= a.scale; v0.z *= a.scale; v0.w *= a.scale;
       v1.x *= a.scale; v1.y *= a.scale; v1.z *= a.scale; v1.w *= a.scale;
       uint2 h0, l0, h1, l1;
-      split4(v0, h0, l0);
-      split4(v1, h1, l1);
+      f3_split4(v0, h0, l0);
+      f3_split4(v1, h1, l1);
       uint4 hh4 = make_uint4(h0.x, h0.y, h1.x, h1.y), ll4 = make_uint4(l0.x, l0.y, l1.x, l1.y);
       qh[sub][ks] = __builtin_bit_cast(bf16x8, hh4);
       ql_[sub][ks] = __builtin_bit_cast(bf16x8, ll4);
@@ -207,9 +207,9 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
             const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rr + 32);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[sub][ks], acc[sub], 0, 0, 0);
-              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql_[sub][ks], acc[sub], 0, 0, 0);
-              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[sub][ks], acc[sub], 0, 0, 0);
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rl_), __builtin_bit_cast(f16x8, qh[sub][ks]), acc[sub], 0, 0, 0);
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, ql_[sub][ks]), acc[sub], 0, 0, 0);
+              acc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[sub][ks]), acc[sub], 0, 0, 0);
             }
           }
         }
@@ -313,11 +313,11 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
         const int c = squart * (HD / 4) + 4 * i;                                             \
         uint2 h, l;                                                                          \
-        split4(rk[i], h, l);                                                                 \
+        f3_split4(rk[i], h, l);                                                              \
         const int ko = (c >> 3) * (64 * 16) + skey * 16 + (c & 7) * 2;                       \
         *reinterpret_cast<uint2*>(Khi + ko) = h;                                             \
         *reinterpret_cast<uint2*>(Klo + ko) = l;                                             \
-        split4(rv[i], h, l);                                                                 \
+        f3_split4(rv[i], h, l);                                                              \
         const int vo = skey * VSTR + c * 2;                                                  \
         *reinterpret_cast<uint2*>(Vhi + vo) = h;                                             \
         *reinterpret_cast<uint2*>(Vlo + vo) = l;                                             \
@@ -362,9 +362,9 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
           const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(Klo + off);
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub) {
-            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[sub][ks], s[sub][t], 0, 0, 0);
-            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql_[sub][ks], s[sub][t], 0, 0, 0);
-            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[sub][ks], s[sub][t], 0, 0, 0);
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kl_), __builtin_bit_cast(f16x8, qh[sub][ks]), s[sub][t], 0, 0, 0);
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, ql_[sub][ks]), s[sub][t], 0, 0, 0);
+            s[sub][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[sub][ks]), s[sub][t], 0, 0, 0);
           }
         }
       }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
           const float p1 = __builtin_amdgcn_exp2f(s[sub][t][r + 1] - m_sub);
           psum += p0 + p1;
           if constexpr (VF) { hp[u] = pack_f16(p0, p1); lp[u] = 0u; }
-          else split2(p0, p1, hp[u], lp[u]);
+          else split2_f16(p0, p1, hp[u], lp[u]);
         }
         ph[sub][s2] = __builtin_bit_cast(bf16x8, hh);
         pl[sub][s2] = __builtin_bit_cast(bf16x8, ll);
@@ -476,9 +476,9 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
           const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub) {
-            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[sub][s2], o[sub][d], 0, 0, 0);
-            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[sub][s2], o[sub][d], 0, 0, 0);
-            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[sub][s2], o[sub][d], 0, 0, 0);
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl), __builtin_bit_cast(f16x8, ph[sub][s2]), o[sub][d], 0, 0, 0);
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, pl[sub][s2]), o[sub][d], 0, 0, 0);
+            o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph[sub][s2]), o[sub][d], 0, 0, 0);
           }
         }
       }
@@ -599,7 +599,7 @@ extern "C" int mmsa_attention_planes(const unsigned short* qkv_p, long ldq, cons
                                      int heads, int head_dim, int window_size, float scale, int out_fmt, int v_fmt, float* max_abs_logit,
                                      hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && rp && out_p, "attention_planes: null pointer");
-  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "attention_planes: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_F3, "attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG((heads * head_dim) % 32 == 0, "attention_planes: embed dim must be a multiple of 32");
@@ -615,7 +615,7 @@ extern "C" int mmsa_global_attention_planes(const unsigned short* qkv_p, long ld
                                             int heads, int head_dim, float scale, int out_fmt, int v_fmt, float* max_abs_logit,
                                             hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_p && bias_p && relpos_planes && out_p, "global_attention_planes: null pointer");
-  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "global_attention_planes: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_F3, "global_attention_planes: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(((((uintptr_t)qkv_p) | ((uintptr_t)bias_p) | ((uintptr_t)relpos_planes) | ((uintptr_t)out_p)) & 127) == 0 && (ldq & 63) == 0 && (ldo & 63) == 0,
                  "global_attention_planes: planes must be 128-byte aligned with ld %% 64 == 0");
   MMSA_CHECK_ARG(head_dim == 64 && W == 64 && H <= 64 && (H % 4) == 0, "global_attention_planes: needs head_dim 64 and a W = 64, H <= 64 (multiple of 4) grid");
@@ -664,11 +664,13 @@ __global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ q
         const unsigned short* qq = qp + ((long)b * T + tok) * ldq + ilv(head * HD + c);
         const uint2 h = *reinterpret_cast<const uint2*>(qq);
         const uint2 l = *reinterpret_cast<const uint2*>(qq + 32);
-        float4 v;
-        v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
-        v.y = __uint_as_float(h.x & 0xFFFF0000u) + __uint_as_float(l.x & 0xFFFF0000u);
-        v.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
-        v.w = __uint_as_float(h.y & 0xFFFF0000u) + __uint_as_float(l.y & 0xFFFF0000u);
+        float4 v;   // fp16 hi/lo pairs ("f3" planes: the attention kernels' hi/lo operand format since round 4)
+        const mmsa_h2 h0_ = __builtin_bit_cast(mmsa_h2, h.x), h1_ = __builtin_bit_cast(mmsa_h2, h.y);
+        const mmsa_h2 l0_ = __builtin_bit_cast(mmsa_h2, l.x), l1_ = __builtin_bit_cast(mmsa_h2, l.y);
+        v.x = (float)h0_.x + (float)l0_.x;
+        v.y = (float)h0_.y + (float)l0_.y;
+        v.z = (float)h1_.x + (float)l1_.x;
+        v.w = (float)h1_.y + (float)l1_.y;
         *reinterpret_cast<float4*>(sQ + t * RS + c) = v;
       } else {
         *reinterpret_cast<float4*>(sQ + t * RS + c) = *reinterpret_cast<const float4*>(qkv + qo);

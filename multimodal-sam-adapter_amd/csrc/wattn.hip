@@ -227,9 +227,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
             tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[ks]), tt[t], 0, 0, 0);
           } else {
             const bf16x8 rl_ = *reinterpret_cast<const bf16x8*>(rb + frag_lo);
-            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl_, qh[ks], tt[t], 0, 0, 0);
-            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, ql[ks], tt[t], 0, 0, 0);
-            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh_, qh[ks], tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rl_), __builtin_bit_cast(f16x8, qh[ks]), tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, ql[ks]), tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, rh_), __builtin_bit_cast(f16x8, qh[ks]), tt[t], 0, 0, 0);
           }
         }
       }
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
           split2_f16(b1.x, b1.y, hh.z, ll.z);
           split2_f16(b1.z, b1.w, hh.w, ll.w);
         } else {
-          split2(b0.x, b0.y, hh.x, ll.x);
-          split2(b0.z, b0.w, hh.y, ll.y);
-          split2(b1.x, b1.y, hh.z, ll.z);
-          split2(b1.z, b1.w, hh.w, ll.w);
+          split2_f16(b0.x, b0.y, hh.x, ll.x);
+          split2_f16(b0.z, b0.w, hh.y, ll.y);
+          split2_f16(b1.x, b1.y, hh.z, ll.z);
+          split2_f16(b1.z, b1.w, hh.w, ll.w);
         }
         bqh = __builtin_bit_cast(bf16x8, hh);
         bql = __builtin_bit_cast(bf16x8, ll);
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
           s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bql), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bqh), s[t], 0, 0, 0);
         } else {
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bql, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e_, bqh, s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bql), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, e_), __builtin_bit_cast(f16x8, bqh), s[t], 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -298,9 +298,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[ks]), s[t], 0, 0, 0);
           } else {
             const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(kb + frag_lo);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], s[t], 0, 0, 0);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], s[t], 0, 0, 0);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kl_), __builtin_bit_cast(f16x8, qh[ks]), s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, ql[ks]), s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kh_), __builtin_bit_cast(f16x8, qh[ks]), s[t], 0, 0, 0);
           }
         }
         if (t & 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 13 tiles' fragment reads (spills at 128 VGPRs)
@@ -377,16 +377,16 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
           hh.x = pack_f16(s[2 * g][0], s[2 * g][1]);
           hh.y = pack_f16(s[2 * g][2], s[2 * g][3]);
         } else {
-          split2(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
-          split2(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
+          split2_f16(s[2 * g][0], s[2 * g][1], hh.x, ll.x);
+          split2_f16(s[2 * g][2], s[2 * g][3], hh.y, ll.y);
         }
         if (2 * g + 1 < 13) {
           if constexpr (VF) {
             hh.z = pack_f16(s[2 * g + 1][0], s[2 * g + 1][1]);
             hh.w = pack_f16(s[2 * g + 1][2], s[2 * g + 1][3]);
           } else {
-            split2(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
-            split2(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
+            split2_f16(s[2 * g + 1][0], s[2 * g + 1][1], hh.z, ll.z);
+            split2_f16(s[2 * g + 1][2], s[2 * g + 1][3], hh.w, ll.w);
           }
         } else {
           hh.z = hh.w = ll.z = ll.w = 0u;   // keys 208..223 do not exist
@@ -407,9 +407,9 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
             const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff));
             const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vlo + voff + second));
             const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d], 0, 0, 0);
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d], 0, 0, 0);
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl), __builtin_bit_cast(f16x8, ph), o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, pl), o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph), o[d], 0, 0, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -442,7 +442,7 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
                                             int B, int H, int W, int heads, int head_dim, int window_size, float scale,
                                             int out_fmt, int v_fmt, float* max_abs_logit, hipStream_t stream) {
   MMSA_CHECK_ARG(qkv_planes && bias_planes && relpos_planes && selector && out_planes, "window_attention: null pointer");
-  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "window_attention: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_F3, "window_attention: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(v_fmt == 0 || v_fmt == 2, "window_attention: v_fmt %d (0 = bf16 hi/lo planes; 2 = qkv, bias and rel-pos planes in the h8 format and an fp16 selector: every contraction on the fp16 MFMA)", v_fmt);
   MMSA_CHECK_ARG(B > 0 && H > 0 && W > 0 && heads > 0, "window_attention: bad shape");
   MMSA_CHECK_ARG(head_dim == 64, "window_attention: head_dim %d not supported by this kernel (64)", head_dim);

@@ -340,7 +340,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         hidden_ = sd["blocks.0.mlp.lin1.weight"].shape[0]
         # ... as h8c planes (3 bytes per element, csrc/gemm_h8c.hip: a shorter operand stream and balanced matrix phases) where every contraction of
         # the block is at least 512 deep (few k-tile pairs per output tile leave that kernel's straight-line loop nothing to run), h8 line planes otherwise
-        vfmt = ops.FMT_B3
+        vfmt = ops.FMT_F3   # the hi/lo pair format of the ViT blocks (h8 off, or a block moved off fp16 attention): fp16 hi/lo pairs, like the attention kernels' own
         if "vit" in h8_sites and D % 64 == 0 and Da % 64 == 0 and hidden_ % 64 == 0:
             vfmt = ops.FMT_H8C if (min(D, Da, hidden_) >= 512 and self._h8c_wanted()) else ops.FMT_H8
         pk["vit_fmt"] = vfmt
@@ -360,12 +360,12 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # k = v of pad tokens; with the fp16 P V of the attention kernels (the "attnv" site, a default; MMSA_H8 without it: bf16 hi/lo pairs) the v third
                 # of the qkv planes -- these bias rows and the qkv GEMM's output -- is h8-encoded (ops.Planes.split)
                 qkv_bp=(ops.split_planes_qkv(qkv_bias.reshape(1, -1).contiguous(), Da) if ("attnv" in h8_sites and Da % 32 == 0)
-                        else ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da)),
+                        else ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_F3)),
                 # ... and for the kernels with the rel-pos terms fused (head_dim 64) the whole row, the qkv GEMM's whole output and the
                 # rel-pos tables are h8 planes: every contraction of those kernels runs on the fp16 hi parts (v_fmt = 2)
                 qkv_bp16=(ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_H8) if "attnv" in h8_sites else None),
                 # ... and plain bf16 hi/lo planes for a block whose logit range rules fp16 operands out (attention_precision, _attn_mode)
-                qkv_bp_b3=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da),
+                qkv_bp_b3=ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_F3),
                 proj_b=sd[b + "attn.proj.bias"], lin1_b=sd[b + "mlp.lin1.bias"], lin2_b=sd[b + "mlp.lin2.bias"],
                 rph=pad_cols(sd[b + "attn.rel_pos_h"]), rpw=pad_cols(sd[b + "attn.rel_pos_w"]),
                 ws=0 if i in cfg["global_attn_indexes"] else cfg["window_size"], index=i))
@@ -376,7 +376,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 L = 2 * wsz - 1
                 th = blk["rph"] if blk["rph"].shape[0] == L else _linear_resize_rows(blk["rph"], L)
                 tw = blk["rpw"] if blk["rpw"].shape[0] == L else _linear_resize_rows(blk["rpw"], L)
-                blk["relp"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_B3)
+                blk["relp"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_F3)
                 blk["relp16"] = ops.window_relpos_planes(th, tw, wsz, fmt=ops.FMT_H8) if blk["qkv_bp16"] is not None else None
         # --- TwinConvNeXt
         cnx_f16 = self._cnx_f16_wanted()
@@ -609,7 +609,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 # global block on a 64-wide grid: rel-pos terms computed inside the attention kernel from the packed tables
                 th = blk["rph"] if blk["rph"].shape[0] == 2 * Hp - 1 else _linear_resize_rows(blk["rph"], 2 * Hp - 1)
                 tw = blk["rpw"] if blk["rpw"].shape[0] == 2 * Wp - 1 else _linear_resize_rows(blk["rpw"], 2 * Wp - 1)
-                relg = (ops.global_relpos_planes(th, tw, fmt=ops.FMT_B3),
+                relg = (ops.global_relpos_planes(th, tw, fmt=ops.FMT_F3),
                         ops.global_relpos_planes(th, tw, fmt=ops.FMT_H8) if blk["qkv_bp16"] is not None else None)
                 g["rel"].append(None)
             else:
@@ -837,7 +837,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             else:
                 ops.layernorm(x, bp["n1w"], bp["n1b"], 1e-6, out_planes=n)
         all16 = fused and f16            # the fused kernels: every contraction on fp16 hi parts of h8 planes (v_fmt = 2), or none (0)
-        qkv = ws.planes("blk_qkv", B * T, 3 * Da, fmt=ops.FMT_H8 if all16 else ops.FMT_B3)
+        qkv = ws.planes("blk_qkv", B * T, 3 * Da, fmt=ops.FMT_H8 if all16 else ops.FMT_F3)
         if all16:
             bias_p = bp["qkv_bp16"]
         elif f16 and not fused:          # the kernel with a rel-pos prepass: the qkv GEMM writes the v columns as h8 planes (fp16 P V only, v_fmt = 1)
@@ -932,12 +932,13 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 moved.append(bp["index"])
                 if reroute:
                     bp["amode"] = "b3"
-                    if bp["qkv"].fmt != ops.FMT_B3:
+                    if bp["qkv"].fmt != ops.FMT_F3:
                         # the projections around those logits must not lose them either: q and k from 2^-15.6 products turn a logit of 48 into
                         # an error of ~1e-3 before the exponential, and what proj / lin1 / lin2 lose reaches the NEXT block's q and k.  The
-                        # whole block moves to bf16 hi/lo operands (2^-17 per product), repacked here from the state dict.
+                        # whole block moves to hi/lo PAIR operands -- fp16 pairs since round 4 (f3 planes, 2^-22 per product; bf16 pairs before:
+                        # 2^-17, a floor of 2^-17 x the logit) --, repacked here from the state dict.
                         dev = pk["attn_guard"].device
-                        bp.update(self._block_gemm_planes(self._pack_state_dict(dev), bp["index"], ops.FMT_B3, pk["fold_ln"], dev))
+                        bp.update(self._block_gemm_planes(self._pack_state_dict(dev), bp["index"], ops.FMT_F3, pk["fold_ln"], dev))
             elif bp.get("amode") is None:
                 bp["amode"] = "f16"
         return moved

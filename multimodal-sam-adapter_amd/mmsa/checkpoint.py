@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 9   # 9: the ConvNeXt planes' format (fp16 hi/lo pairs) among the settings; 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
+PACK_FORMAT = 10   # 10: the attention path's hi/lo planes (bias rows, rel-pos tables, fallback block weights) are fp16 pairs; 9: the ConvNeXt planes' format (fp16 hi/lo pairs) among the settings; 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
 
 
 def unwrap_state_dict(ck):
@@ -172,8 +172,8 @@ def save_packed(model, path, device="cuda"):
                 for k in ("amode", "max_logit"):
                     if k in bo:
                         bp[k] = bo[k]
-                if bo.get("amode") == "b3" and bp["qkv"].fmt != ops.FMT_B3:
-                    bp.update(model._block_gemm_planes(sd_dev, bp["index"], ops.FMT_B3, pk["fold_ln"], dev))
+                if bo.get("amode") == "b3" and bp["qkv"].fmt != ops.FMT_F3:
+                    bp.update(model._block_gemm_planes(sd_dev, bp["index"], ops.FMT_F3, pk["fold_ln"], dev))
         torch.cuda.synchronize(dev)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     enc = _enc(pk)

@@ -151,8 +151,8 @@ def planes_shape(rows, cols, fmt):
 
 def alloc_planes(rows, cols, device, zero=False, fmt=FMT_B3, split=0):
     f = torch.zeros if zero else torch.empty
-    if split and (split % 32 or fmt != FMT_B3 or not 0 < split < cols):
-        raise RuntimeError(f"mmsa.alloc_planes: split={split} must be a multiple of 32 inside a bf16 hi/lo matrix of {cols} columns")
+    if split and (split % 32 or fmt not in (FMT_B3, FMT_F3) or not 0 < split < cols):
+        raise RuntimeError(f"mmsa.alloc_planes: split={split} must be a multiple of 32 inside a bf16 hi/lo or f3 matrix of {cols} columns")
     tr, tc, kp = planes_shape(rows, cols, fmt)
     return Planes(f(tr, tc, dtype=torch.int16, device=device), rows, cols, kp, fmt, split=split)
 
@@ -166,7 +166,7 @@ def planes_to_float(pl, cols=None):
     """Debug/test helper: reconstruct hi + lo as fp32 [rows, cols] (torch ops; not used on the product path)."""
     r, w = pl.p.shape
     if pl.split:   # bf16 hi/lo columns below the split, h8 (activation chunk order) from it on
-        lo_part = planes_to_float(Planes(pl.p[:, :2 * pl.split], pl.n, pl.split, pl.split, FMT_B3))
+        lo_part = planes_to_float(Planes(pl.p[:, :2 * pl.split], pl.n, pl.split, pl.split, pl.fmt))
         hi_part = planes_to_float(Planes(pl.p[:, 2 * pl.split:], pl.n, pl.kpad - pl.split, pl.kpad - pl.split, FMT_H8))
         return torch.cat([lo_part, hi_part], 1)[:, :(pl.k if cols is None else cols)]
     if pl.fmt == FMT_H8C:
@@ -398,7 +398,7 @@ def relpos_bias(qkv, rh, rw, rp, b, h, w, heads, hd, ws):
 
 
 def _v_fmt(qkv, qkv_bias, d, fused=False, rel=None):
-    """v_fmt argument of the attention kernels from the planes' own description (include/mmsa.h): 0 = plain bf16 hi/lo planes;
+    """v_fmt argument of the attention kernels from the planes' own description (include/mmsa.h): 0 = plain f3 (fp16 hi/lo) planes;
     1 = the v columns (from 2*D on) of BOTH the qkv planes and the bias planes are h8-encoded (Planes.split; the entry with a rel-pos
     prepass); 2 = qkv, bias and rel-pos planes are h8 planes throughout (the fused rel-pos entries: every contraction on fp16)."""
     if qkv.fmt == FMT_H8 or qkv_bias.fmt == FMT_H8 or (rel is not None and rel.fmt == FMT_H8):
@@ -407,19 +407,22 @@ def _v_fmt(qkv, qkv_bias, d, fused=False, rel=None):
             raise RuntimeError("mmsa attention: h8 planes need the fused rel-pos entry with qkv, bias AND rel-pos planes in the h8 (activation) format")
         return 2
     if qkv.split != qkv_bias.split or qkv.split not in (0, 2 * d) or (fused and qkv.split):
-        raise RuntimeError(f"mmsa attention: qkv planes (split {qkv.split}) and bias planes (split {qkv_bias.split}) must both be bf16 hi/lo "
+        raise RuntimeError(f"mmsa attention: qkv planes (split {qkv.split}) and bias planes (split {qkv_bias.split}) must both be f3 (fp16 hi/lo) "
                            f"planes, either plain or -- for the entry with a rel-pos prepass -- with the v columns from {2 * d} on as h8 planes")
+    if qkv.fmt != FMT_F3 or qkv_bias.fmt != FMT_F3 or (rel is not None and rel.fmt != FMT_F3):
+        raise RuntimeError("mmsa attention: the hi/lo operand form of the attention kernels reads f3 planes (fp16 hi/lo pairs: ops.FMT_F3) since round 4 -- "
+                           "qkv, bias and rel-pos planes; bf16 hi/lo planes have the same layout and would be misread")
     return 1 if qkv.split else 0
 
 
 def split_planes_qkv(x2d, d):
-    """fp32 [N, 3*d] (q | k | v) -> qkv Planes with q, k as bf16 hi/lo planes and v as h8 planes (Planes.split = 2*d): the layout the
+    """fp32 [N, 3*d] (q | k | v) -> qkv Planes with q, k as fp16 hi/lo (f3) planes and v as h8 planes (Planes.split = 2*d): the layout the
     qkv GEMM writes for the attention kernels' fp16 P V.  Also for the [1, 3*d] bias row (pad tokens: k = v = bias)."""
     if (2 * d) % 32 or d % 32:
         raise RuntimeError("mmsa.split_planes_qkv: embed dim must be a multiple of 32")
-    qk = split_planes(x2d[:, :2 * d].contiguous())
+    qk = split_planes(x2d[:, :2 * d].contiguous(), fmt=FMT_F3)
     v = split_planes(x2d[:, 2 * d:].contiguous(), fmt=FMT_H8)
-    return Planes(torch.cat([qk.p, v.p], 1).contiguous(), x2d.shape[0], 3 * d, 3 * d, FMT_B3, split=2 * d)
+    return Planes(torch.cat([qk.p, v.p], 1).contiguous(), x2d.shape[0], 3 * d, 3 * d, FMT_F3, split=2 * d)
 
 
 def _guard(g):
@@ -486,7 +489,7 @@ def window_selector(ws, device, f16=False):
     if key not in _SELECTORS:
         sel = torch.zeros(208, 32, dtype=torch.int16)
         j = torch.arange(min(ws * ws, 208))
-        one = 0x3C00 if f16 else 0x3F80
+        one = 0x3C00     # fp16 1.0: every form of the kernel runs fp16 MFMAs (hi/lo pairs or hi only) since round 4
         sel[j, j // ws] = one
         sel[j, 14 + j % ws] = one
         _SELECTORS[key] = sel.to(device)

@@ -74,10 +74,10 @@ def test_window_bookkeeping_bit_exact_fused_kernel(golden_dir, H, W, ws, vf):
         qp = ops.split_planes(qkv.to(DEV), fmt=ops.FMT_H8)
         bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd, fmt=ops.FMT_H8)
     else:
-        qp = ops.split_planes(qkv.to(DEV))
-        bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)    # pad slots: k = v = bias = 0
+        qp = ops.split_planes(qkv.to(DEV), fmt=ops.FMT_F3)       # the kernels' hi/lo form reads fp16 pairs (f3 planes)
+        bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd, fmt=ops.FMT_F3)    # pad slots: k = v = bias = 0
     relp = ops.window_relpos_planes(torch.zeros(2 * ws - 1, hd, device=DEV), torch.zeros(2 * ws - 1, hd, device=DEV), ws,
-                                    fmt=ops.FMT_H8 if vf else ops.FMT_B3)
+                                    fmt=ops.FMT_H8 if vf else ops.FMT_F3)
     out = ops.alloc_planes(B * H * W, hd, DEV)
     ops.window_attention(qp, bias_p, relp, out, B, H, W, 1, hd, ws, hd ** -0.5)
     got = ops.planes_to_float(out).cpu()
@@ -100,8 +100,8 @@ def test_window_bookkeeping_bit_exact_generic_kernel(golden_dir, H, W, ws):
     win = g[f"wp_{H}_{W}_{ws}"]
     B, hd = 2, 32
     qkv, expect = _expected_and_qkv(win, B, H, W, ws, hd, amp=8.0, max_corr=0.75)     # logits: 32*64/sqrt(32) = 362 on the match, <= 272 elsewhere
-    qp = ops.split_planes(qkv.to(DEV))
-    bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd)
+    qp = ops.split_planes(qkv.to(DEV), fmt=ops.FMT_F3)
+    bias_p = ops.split_planes(torch.zeros(1, 3 * hd, device=DEV), kpad=3 * hd, fmt=ops.FMT_F3)
     rp = torch.zeros(B * H * W, 2 * ws, device=DEV)
     out = ops.alloc_planes(B * H * W, hd, DEV)
     ops.attention(qp, bias_p, rp, out, B, H, W, 1, hd, ws, hd ** -0.5)

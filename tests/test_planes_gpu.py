@@ -119,7 +119,7 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table, vf):
         else:
             ref = att(x)
     T = H * W
-    qkv = ops.alloc_planes(B * T, 3 * D, DEV, split=2 * D if vf else 0)
+    qkv = ops.alloc_planes(B * T, 3 * D, DEV, fmt=ops.FMT_F3, split=2 * D if vf else 0)     # the kernels' hi/lo form: fp16 pairs (f3 planes)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
     if vf:   # the GEMM's split output against a host-side split of the same matrix: q | k bf16 hi/lo, v fp16 hi + e5m2 lo
         qkv_f = (x.view(-1, D) @ sd["qkv.weight"].t() + sd["qkv.bias"]).to(DEV)
@@ -134,9 +134,12 @@ def test_attention_planes(ops, H, W, heads, hd, ws, table, vf):
     ops.relpos_bias(qkv, rh, rw, rp, B, H, W, heads, hd, ws)
     ao = ops.alloc_planes(B * T, D, DEV)
     bias_row = sd["qkv.bias"].reshape(1, -1).contiguous().to(DEV)
-    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D)
+    biasp = ops.split_planes_qkv(bias_row, D) if vf else ops.split_planes(bias_row, kpad=3 * D, fmt=ops.FMT_F3)
     gw = torch.zeros(1, device=DEV)
     ops.attention(qkv, biasp, rp, ao, B, H, W, heads, hd, ws, hd ** -0.5, max_logit=gw)
+    if not vf:   # bf16 hi/lo planes have the same layout and would be misread: refused
+        with pytest.raises(RuntimeError):
+            ops.attention(qkv, ops.split_planes(bias_row, kpad=3 * D), rp, ao, B, H, W, heads, hd, ws, hd ** -0.5)
     out = torch.empty(B * T, D, device=DEV)
     ops.gemm(ao, ops.split_planes(sd["proj.weight"].to(DEV)), out, bias=sd["proj.bias"].to(DEV))
     assert_close(out.view(B, H, W, D), ref, what=f"attention planes {H}x{W} ws={ws} vf={vf}")
@@ -187,7 +190,7 @@ def test_window_attention_fused_relpos(ops, H, W, heads, ws, vf):
         xw, pad_hw = R.window_partition(x, ws)
         ref = R.window_unpartition(att(xw), ws, pad_hw, (H, W))
     T = H * W
-    pf = ops.FMT_H8 if vf else ops.FMT_B3
+    pf = ops.FMT_H8 if vf else ops.FMT_F3      # hi/lo form: fp16 pairs (f3 planes) since round 4
     qkv = ops.alloc_planes(B * T, 3 * D, DEV, fmt=pf)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
     relp = ops.window_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), ws, fmt=pf)
@@ -326,7 +329,7 @@ def test_global_attention_fused_relpos(ops, H, vf):
     with torch.no_grad():
         ref = att(x)
     T = H * W
-    pf = ops.FMT_H8 if vf else ops.FMT_B3     # vf: h8 planes throughout, every contraction of the kernel on the fp16 MFMA (v_fmt = 2)
+    pf = ops.FMT_H8 if vf else ops.FMT_F3     # vf: h8 planes throughout, every contraction of the kernel on the fp16 MFMA (v_fmt = 2)
     qkv = ops.alloc_planes(B * T, 3 * D, DEV, fmt=pf)
     ops.gemm(x.view(-1, D).to(DEV), ops.split_planes(sd["qkv.weight"].to(DEV)), bias=sd["qkv.bias"].to(DEV), out_planes=qkv)
     relg = ops.global_relpos_planes(sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), fmt=pf)
