@@ -391,17 +391,20 @@ def test_planes_with_a_column_split_host_logic():
         with pytest.raises(RuntimeError):
             ops.alloc_planes(4, 96, "cpu", **bad)
     d = 32
-    qkv, bias = ops.alloc_planes(8, 3 * d, "cpu", split=2 * d), ops.alloc_planes(1, 3 * d, "cpu", split=2 * d)
+    f3 = lambda r, c, **kw: ops.alloc_planes(r, c, "cpu", fmt=ops.FMT_F3, **kw)     # the attention kernels' hi/lo form reads fp16 pairs (round 4)
+    qkv, bias = f3(8, 3 * d, split=2 * d), f3(1, 3 * d, split=2 * d)
     assert ops._v_fmt(qkv, bias, d) == 1
-    assert ops._v_fmt(ops.alloc_planes(8, 3 * d, "cpu"), ops.alloc_planes(1, 3 * d, "cpu"), d) == 0
+    assert ops._v_fmt(f3(8, 3 * d), f3(1, 3 * d), d) == 0
     with pytest.raises(RuntimeError):
-        ops._v_fmt(qkv, ops.alloc_planes(1, 3 * d, "cpu"), d)
+        ops._v_fmt(qkv, f3(1, 3 * d), d)
+    with pytest.raises(RuntimeError):                                   # bf16 hi/lo planes: same layout, would be misread -- refused
+        ops._v_fmt(ops.alloc_planes(8, 3 * d, "cpu"), ops.alloc_planes(1, 3 * d, "cpu"), d)
     with pytest.raises(RuntimeError):                                   # the split form is not for the fused rel-pos entries
-        ops._v_fmt(qkv, bias, d, fused=True, rel=ops.alloc_planes(64, 64, "cpu"))
+        ops._v_fmt(qkv, bias, d, fused=True, rel=f3(64, 64))
     h = lambda r, c: ops.alloc_planes(r, c, "cpu", fmt=ops.FMT_H8)
     assert ops._v_fmt(h(8, 3 * d), h(1, 3 * d), d, fused=True, rel=h(64, 64)) == 2
-    for args in ((h(8, 3 * d), h(1, 3 * d), d), (h(8, 3 * d), ops.alloc_planes(1, 3 * d, "cpu"), d, True, h(64, 64)),
-                 (h(8, 3 * d), h(1, 3 * d), d, True, ops.alloc_planes(64, 64, "cpu"))):
+    for args in ((h(8, 3 * d), h(1, 3 * d), d), (h(8, 3 * d), f3(1, 3 * d), d, True, h(64, 64)),
+                 (h(8, 3 * d), h(1, 3 * d), d, True, f3(64, 64))):
         with pytest.raises(RuntimeError):
             ops._v_fmt(*args)
     # hand-packed row: two bf16 hi/lo blocks, one h8 block (32 fp16 hi, then four 16-byte chunks: 8 e5m2 bytes of lo * 2^11 | 8 of hi)
