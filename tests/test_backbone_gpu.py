@@ -44,6 +44,20 @@ def test_tiny_models_vs_golden_and_oracle(golden_dir, name):
         assert_close(got, gold, what=f"{name} f{i+1} vs golden")
 
 
+@pytest.mark.parametrize("scale", [255.0, 1.0 / 255.0])
+def test_input_scale_within_the_fp16_based_operand_formats(scale):
+    """The fp16-based operand formats (f3 pairs in the TwinConvNeXt chain from the stem on, h8 / h8c in the ViT) clamp at +-65504 and lose relative
+    precision below 6e-5: un-normalised inputs (0..255 images, metre-valued LiDAR) and tiny ones must come out like the fp32 oracle's -- the first
+    LayerNorm of either path removes the scale, so what is tested is the patchify / stem GEMM on the raw values."""
+    cfg, orc, m = _build("tiny256")
+    x = make_input(cfg) * scale
+    fs, _ = m(x.to(DEV))
+    ref, _ = orc(x)
+    for i, (f, r) in enumerate(zip(fs, ref)):
+        assert torch.isfinite(f).all()
+        assert_close(f, r, what=f"tiny256, input x {scale:g}: f{i+1} vs oracle")
+
+
 @pytest.mark.parametrize("flag", ["with_cffn", "use_extra_extractor", "add_vit_feature"])
 def test_constructor_switches_one_at_a_time(flag):
     """Each of the three switches alone (tiny256_plain pins all three off together against the reference's golden; the oracle's
