@@ -508,9 +508,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
     const int st_cur = st == 0 ? V2_NST - 1 : st - 1;   // ring slot of the k-tile just consumed: free until the next DMA into it (issued after the next barrier)
 
     if (V2_DBG(a) == 2 || V2_DBG(a) == 5 || V2_DBG(a) >= 64) { tile += G; continue; }
+    {
+      // the epilogue sees the lane id through an opaque copy (as in gemm_h8c.hip): what it derives from it -- row / column indices, 64-bit
+      // addresses -- is then computed per tile instead of being hoisted above the tile loop, where those values were live across the k loops
+      // and pushed loop invariants into scratch (round 4 ISA: 143-184 scratch instructions in the h8-line flavours; a scratch reload in
+      // front of an LDS-DMA instruction is an s_waitcnt vmcnt(0), i.e. a drain of the prefetch stream)
+      int lane_o_ = lane;
+      asm volatile("" : "+v"(lane_o_));
+      const int lane = lane_o_, l15 = lane_o_ & 15, g = lane_o_ >> 4;
 #define EPI_STAGING_BASE (smem + st_cur * V2_STAGE)
 #include "gemm_v2_epilogue.inc"
 #undef EPI_STAGING_BASE
+    }
     if constexpr (PP) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // slot st_cur (epilogue staging of every wave) is free again: group 0 DMAs into it next

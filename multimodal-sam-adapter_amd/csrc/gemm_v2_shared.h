@@ -2,6 +2,7 @@
 // geometry, tile order.  See gemm_v2.hip for the design notes.
 #pragma once
 #include "common.h"
+#include <type_traits>
 typedef __attribute__((ext_vector_type(8))) int mx_v8i;       // operand of the block-scaled fp8 MFMA (32 bytes per lane)
 typedef __attribute__((ext_vector_type(8))) _Float16 mx_h8;  // operand of the f16 MFMA
 

@@ -883,3 +883,101 @@ def test_layernorm_and_batched_gemm_f3(ops):
              stride_w=4 * C * 2 * wpl.kpad, stride_bias=4 * C, stride_cp=rows * 2 * h.kpad)
     href = torch.cat([F.gelu(F.linear(ref[i * rows:(i + 1) * rows].double(), w1[i].double(), b1[i].double())) for i in range(2)], 0).float()
     assert_close(planes_to_float(h), href, tol=3e-6, what="batched f3 gemm + gelu, f3 planes out")
+
+
+# ---- round 5: the register-resident tile epilogue (csrc/gemm_epilogue_regs.inc)
+_REGS_CASES = [
+    # (operand fmt, output kind, plane fmt out, act, resid, strip sums, row-norm)   -- one per compile-time variant the model runs
+    ("h8c", "P", "h8c", "gelu", False, False, True),     # lin1 (IE:162-167) with norm2 folded in
+    ("h8c", "P", "h8c", "none", False, False, False),
+    ("h8c", "P", "h8", "none", False, False, True),      # qkv (IE:488) with norm1 folded in, h8 line planes for the attention kernels
+    ("h8c", "P", "h8", "gelu", False, False, False),
+    ("f3", "P", "f3", "gelu", False, False, False),      # ConvNeXt pointwise_conv1 (TC:107-109)
+    ("b3", "P", "b3", "none", False, False, False),
+    ("h8c", "CP", "h8c", "none", True, True, False),     # proj / lin2 (IE:499,167): the residual stream's producers
+    ("f3", "CP", "f3", "none", True, True, False),       # the same for a block that fell back to fp16 pairs
+    ("h8c", "C", None, "none", True, False, False),      # extractor output projection, ConvFFN fc2 (AM:447-451)
+    ("f3", "C", None, "none", True, False, False),       # ConvNeXt pointwise_conv2 + gamma + residual (TC:110-132)
+    ("h8", "C", None, "none", False, False, False),      # value / offset projections, fc1
+]
+
+
+@pytest.mark.parametrize("case", _REGS_CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_gemm_register_epilogue_variants(ops, case):
+    """Every compile-time variant of the register-resident epilogue on INTERIOR tiles (M % 256 == 0, N % 128 == 0, several tiles per
+    workgroup, two batches with per-batch bias / colscale) against float64 -- and bit for bit against the LDS-staged epilogue, which the
+    same rows take when they are launched as a ragged matrix (M = 200 < one tile): both epilogues apply the same operations in the same
+    order to the same accumulators.  Strip sums: different summation order, so within fp32 rounding."""
+    fmt_name, outk, pfmt_name, act, use_res, use_rs, use_rn = case
+    FM = {"b3": ops.FMT_B3, "h8": ops.FMT_H8, "h8c": ops.FMT_H8C, "f3": ops.FMT_F3}
+    fmt = FM[fmt_name]
+    B, M, N, K = 2, 768, 384, 256
+    a = torch.randn(B * M, K, generator=g(501)) * 1.3
+    w = torch.randn(B * N, K, generator=g(502)) / K ** 0.5
+    bias = torch.randn(B * N, generator=g(503))
+    cs = 0.5 + torch.rand(B * N, generator=g(504))
+    res = torch.randn(B * M, N, generator=g(505))
+    mr = torch.stack([torch.randn(B * M, generator=g(506)) * 0.2, 0.5 + torch.rand(B * M, generator=g(507))], 1).contiguous()
+    csum = torch.randn(B * N, generator=g(508))
+    fact = {"none": lambda t: t, "gelu": F.gelu}[act]
+    ad, wd = a.to(DEV), w.to(DEV)
+    ap = ops.split_planes(ad, kpad=K, fmt=fmt)
+    wp_all = ops.split_planes(wd, fmt=fmt, weight=fmt == ops.FMT_H8)
+    wp = ops.Planes(wp_all.p, N, K, wp_all.kpad, fmt, fmt == ops.FMT_H8)
+    af, wf = planes_to_float(ap)[:, :K].double().cpu(), planes_to_float(wp_all)[:, :K].double().cpu()   # the operands as the kernel sees them
+    acc = torch.stack([af[b * M:(b + 1) * M] @ wf[b * N:(b + 1) * N].t() for b in range(B)]).view(B * M, N)
+    bb, cc = bias.double().view(B, 1, N).expand(B, M, N).reshape(B * M, N), cs.double().view(B, 1, N).expand(B, M, N).reshape(B * M, N)
+    if use_rn:
+        pre = mr[:, 1:2].double() * (acc - mr[:, 0:1].double() * csum.double().view(B, 1, N).expand(B, M, N).reshape(B * M, N)) + bb
+    else:
+        pre = acc + bb
+    ref = fact(pre) * cc * 0.75
+    if use_res:
+        ref = ref + res.double()
+    ref = ref.float()
+
+    def run(rows, m_arg, batch):
+        kw = dict(bias=bias.to(DEV), colscale=cs.to(DEV), alpha=0.75, act=act, batch=batch, m=m_arg, stride_a=ap.batch_stride(M), stride_w=wp_all.batch_stride(N), stride_bias=N)
+        out = outp = rs = None
+        if "C" in outk:
+            out = torch.full((B * M, N), float("nan"), device=DEV)
+            kw.update(out=out, stride_c=M * N)
+        if "P" in outk:
+            outp = ops.alloc_planes(B * M, N, DEV, zero=True, fmt=FM[pfmt_name])
+            kw.update(out_planes=outp, stride_cp=outp.batch_stride(M))
+        if use_res:
+            kw.update(resid=res.to(DEV), stride_r=M * N)
+        if use_rs:
+            rs = torch.full((B * M, 2 * (N // 64)), float("nan"), device=DEV)
+            kw.update(rowstats_out=rs)
+        if use_rn:
+            kw.update(row_norm=(mr.to(DEV), csum.to(DEV)))
+        ops.gemm(ap, wp, **kw)
+        return out, outp, rs
+
+    out, outp, rs = run(B * M, M, B)
+    ctol = {"b3": 3e-5, "f3": 3e-6, "h8": 1e-4, "h8c": 1e-4}     # the operand format's own product error (cross terms on e5m2, no lo x lo term)
+    ptol = {"b3": 3e-5, "f3": 3e-6, "h8": 1.5e-4, "h8c": 1.5e-4}   # + the rounding of the stored planes
+    if out is not None:
+        assert_close(out, ref, tol=ctol[fmt_name], what=f"{case}: fp32 output vs float64 on the kernel's operands")
+    if outp is not None:
+        assert_close(planes_to_float(outp), ref, tol=max(ptol[pfmt_name], ctol[fmt_name]), what=f"{case}: planes output")
+        if out is not None:   # the planes are the split of the stored fp32 values
+            assert torch.equal(planes_to_float(outp), planes_to_float(ops.split_planes(out, fmt=FM[pfmt_name])))
+    if rs is not None:
+        x = out.double().view(B * M, N // 64, 64)
+        want = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).view(B * M, -1).float()
+        assert_close(rs, want, tol=2e-6, what=f"{case}: strip sums")
+    # the staged epilogue on the same rows: batch 0 only, its first 200 rows as a ragged one-tile-row matrix (200 < 256: no interior tile)
+    if True:
+        out2, outp2, rs2 = run(200, 200, 1)
+        if out is not None:
+            assert torch.equal(out2[:200], out[:200]), f"{case}: register and staged epilogues differ (fp32)"
+        if outp is not None:
+            assert torch.equal(planes_to_float(outp2)[:200], planes_to_float(outp)[:200]), f"{case}: register and staged epilogues differ (planes)"
+        if rs is not None:
+            assert_close(rs2[:200], rs[:200], tol=2e-6, what=f"{case}: strip sums, staged vs register epilogue")
+    again = run(B * M, M, B)
+    for t0, t1 in zip((out, outp.p if outp is not None else None, rs), (again[0], again[1].p if again[1] is not None else None, again[2])):
+        if t0 is not None:
+            assert torch.equal(t0, t1), f"{case}: not reproducible"
