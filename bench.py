@@ -42,6 +42,11 @@ Extra objects:
                   |logit| any attention block scored and whether every block stayed inside its operand precision's range.
   worst_case_precision -- the same step with EVERY GEMM and attention operand in the bf16 hi/lo format (MMSA_H8=none, attention 'b3'):
                   what a checkpoint whose logits leave the fp16 range in every block would run.
+  eager_plugin_api -- the call a reference user makes (segmentors/encoder_decoder.py:63-69): `backbone(x)` + head eagerly, no graph, the
+                  attention guard in its default "sync" mode; its logits equal the replayed graph's bit for bit.
+  config4_frame -- BASELINE configs[3]: one 1080x1920 frame through mmsa.inference.SlideRunner (six 1024^2 windows, two concurrent chains) ->
+                  class map, frames/s; the map equals slide_inference + argmax_map bit for bit.
+  vith1024     -- the pinnable half of BASELINE configs[4] (SAM ViT-H behind the same adapter), one HIP graph, golden probes checked.
 Counter-derived fields (roofline.traffic, roofline.mfma_counters, hbm_kernels) come from committed profiles and carry the digest of the
 kernel sources they were measured on; a profile whose digest is not that of the sources in the tree is reported as stale, not attached.
 
@@ -78,6 +83,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the eager_plugin_api / config4_frame / vith1024 lines of the default single-GPU run")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed graph-vs-eager / golden-probe checks")
     ap.add_argument("--default-init", action="store_true", help="A/B aid: default-init weights instead of the seeded live generator")
     ap.add_argument("--no-head", action="store_true", help="time the encoder forward only (no decode head, no all-gather)")
@@ -519,6 +525,34 @@ def main():
                             "sites issue 3 bf16 MFMAs per algorithmic product, h8 sites 1 fp16 MFMA + the two cross terms on one block-scaled fp8 MFMA at "
                             "twice the rate (2 units)"}
 
+    # ---- the path a reference user calls: EncoderDecoder.extract_feat runs `backbone(img)` eagerly (segmentors/encoder_decoder.py:63-69)
+    # and the decode head on its result -- no graph, no chains, the backbone's attention guard in its default "sync" mode (one 4 * depth-byte read-back and a
+    # host sync per forward, and a re-run if a block had to be re-routed).  Same weights, same resident input, same step as `value`.
+    extras = not a.no_extras and not STUB and world == 1 and rank == 0 and a.config == "vitl1024" and not a.no_graph
+    eager_api = None
+    if extras:
+        assert model.attention_guard == "sync"
+        for _ in range(2):
+            eo = local_step()
+        torch.cuda.synchronize()
+        n_e = max(5, a.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n_e):
+            eo = local_step()
+        torch.cuda.synchronize()
+        edt_ = (time.perf_counter() - t0) / n_e
+        same_e = None
+        if verified is not None and head is not None and graphed:
+            replay()
+            torch.cuda.synchronize()
+            same_e = bool(torch.equal(eo, local_out))
+            if not same_e:
+                raise SystemExit("[bench] the eager plugin call does not return the replayed step's logits")
+        eager_api = {"value": round(a.batch / edt_, 3), "unit": "images/s", "ms_per_step": round(edt_ * 1e3, 3), "steps": n_e,
+                     "call": "backbone(x) -> SegformerHead(feats), eager launches on the current stream, attention_guard = 'sync' (read-back + host sync per forward)",
+                     "vs_value": round(a.batch / edt_ / value, 4),
+                     "verified": {"logits_equal_the_replayed_graphs_bitwise": same_e}}
+
     worst = None
     if model is not None and world == 1 and not a.no_roofline and os.environ.get("MMSA_H8") is None and os.environ.get("MMSA_ATTN") is None:
         # every operand of every GEMM and attention kernel as a bf16 hi/lo pair: the operand formats a checkpoint with peaky attention in every
@@ -545,6 +579,108 @@ def main():
             else:
                 model.h8_sites = keep_sites
             model.attention_precision = keep_prec
+
+    # ---- BASELINE configs[3]: one 1080 x 1920 RGB+Event frame, sliding-window inference (crop 1024, stride 640: six windows, ED:191-234) through
+    # mmsa.inference.SlideRunner -- the windows cut by one kernel, encoder + head as two concurrent chains of three, overlap-average + resize + argmax
+    # in one kernel -> class map.  Verified against the plain functions (slide_inference + argmax_map: pinned on the reference's own
+    # slide_inference by tests/golden/slide.npz) bit for bit, every pixel covered.
+    frame_line = None
+    if extras and head is not None:
+        import mmsa.inference as inf
+        try:
+            del replay
+        except NameError:
+            pass
+        chains = None
+        torch.cuda.empty_cache()
+        gf = torch.Generator().manual_seed(4321)                     # synthetic frame of the MUSES geometry: RGB ~ N(0, 1), aux = sparse 5 % U(0, 1)
+        frame = torch.randn(1, 6, 1080, 1920, generator=gf)
+        frame[:, 3:] = (torch.rand(1, 3, 1080, 1920, generator=gf) < 0.05).float() * torch.rand(1, 3, 1080, 1920, generator=gf)
+        frame = frame.to(dev)
+        sr = inf.SlideRunner(model, head, frame, (1024, 1024), (640, 640), chains=2)
+        cm, unc = sr.run().outputs()
+        torch.cuda.synchronize()
+        want = inf.argmax_map(inf.slide_inference(model, head, frame, (1024, 1024), (640, 640), max_batch=3))
+        torch.cuda.synchronize()
+        ok_f = bool(torch.equal(cm, want)) and int(unc.item()) == 0 and tuple(cm.shape) == (1, 1080, 1920)
+        if not ok_f:
+            raise SystemExit("[bench] SlideRunner class map differs from slide_inference + argmax_map")
+        n_f = 5
+        sr.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_f):
+            fr = sr.run()
+        fr.outputs()                       # waits for the last frame's guard copy (raises if a frame ran out of the fp16 attention range)
+        torch.cuda.synchronize()
+        fdt = (time.perf_counter() - t0) / n_f
+        frame_line = {"value": round(1.0 / fdt, 3), "unit": "frames/s", "ms_per_frame": round(fdt * 1e3, 2), "crops_per_s": round(6.0 / fdt, 2), "frames": n_f,
+                      "workload": "BASELINE configs[3]: 1080x1920 frame -> 6 windows 1024^2 (stride 640), ViT-L encoder + SegformerHead + overlap average + x4 resize + argmax -> uint8 class map",
+                      "verified": {"class_map_equals_slide_inference_plus_argmax_bitwise": ok_f, "uncovered_pixels": int(unc.item()), "attention_guard": "every frame inspected (FrameResult.outputs)"}}
+        del sr, cm, want, frame
+        torch.cuda.empty_cache()
+
+    # ---- the pinnable half of BASELINE configs[4]: SAM ViT-H (1280 wide, 32 blocks, head_dim 80 zero-padded to 96) behind the same RGB+LiDAR adapter, batch 2,
+    # one HIP graph, golden probes of the imported reference on image 0 (tests/golden/model_vith1024.npz).  The 3-modality / fp8 half has no reference.
+    vith_line = None
+    if extras and head is not None:
+        import numpy as np
+        try:
+            hc = CONFIGS["vith1024"]
+            model = None
+            torch.cuda.empty_cache()
+            mh = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **hc["kwargs"]))
+            mh.load_state_dict(seeded_state_dict(mh, seed=hc["seed"]))
+            hkw_h = dict(HEAD_CONFIGS["head_vitl"]["kwargs"])
+            hkw_h["in_channels"] = [hc["kwargs"]["embed_dim"]] * 4
+            hh = mmsa.build_head(dict(type="SegformerHead", **hkw_h))
+            hh.load_state_dict(seeded_state_dict(hh, seed=HEAD_CONFIGS["head_vitl"]["seed"]))
+            mh.emit_planes = True
+            xh = make_input(hc, batch=a.batch, seed=1234).to(dev)
+            xh[0].copy_(make_input(hc, batch=1)[0].to(dev))          # image 0 = the golden input
+            hfe = [None]
+
+            def hstep():
+                hfe[0] = mh(xh)[0]
+                return hh(hfe[0])
+            for _ in range(2):
+                hstep()
+            torch.cuda.synchronize()
+            if mh.check_attention_guard():
+                hstep()
+                torch.cuda.synchronize()
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph):
+                hstep()
+            gph.replay()
+            torch.cuda.synchronize()
+            n_h = 3
+            t0 = time.perf_counter()
+            for _ in range(n_h):
+                gph.replay()
+            torch.cuda.synchronize()
+            hdt = (time.perf_counter() - t0) / n_h
+            gh = np.load(os.path.join(ROOT, "tests", "golden", "model_vith1024.npz"))
+            worst_h = 0.0
+            for i in range(4):
+                f0 = hfe[0][i][0]
+                pi = probe_index(f0.numel(), 2048, seed=100 + i).to(dev)
+                got = f0.flatten()[pi].double().cpu()
+                ref = torch.from_numpy(gh[f"f{i+1}_probe"]).double()
+                worst_h = max(worst_h, float((got - ref).norm() / ref.norm()), float((got - ref).abs().max() / ref.abs().max()))
+            still_h = mh.check_attention_guard(reroute=False)
+            if not worst_h <= 1e-3 or still_h:
+                raise SystemExit(f"[bench] ViT-H line: golden probes {worst_h:.3e} (gate 1e-3), blocks out of the fp16 attention range {still_h}")
+            vith_line = {"value": round(a.batch / hdt, 3), "unit": "images/s", "ms_per_step": round(hdt * 1e3, 3), "replays": n_h,
+                         "workload": f"SAM ViT-H encoder (embed 1280, depth 32, head_dim 80 -> 96 zero-padded) + RGB+LiDAR adapter + SegformerHead, 1024x1024, batch {a.batch}, one HIP graph",
+                         "verified": {"replayed_graph_vs_reference_golden_probes_max_rel": round(worst_h, 7), "golden": "image 0: tests/golden/model_vith1024.npz",
+                                      "blocks_out_of_fp16_attention_range": still_h}}
+            del gph, mh, hh, xh
+            torch.cuda.empty_cache()
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            vith_line = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.config == "vitl1024":
@@ -608,6 +744,7 @@ def main():
             "encoder_only": encoder_only,
             "end_to_end_algorithmic_tflops": round(value * fpi / 1e12, 1) if fpi else None,
             "chains_probe_ms": chain_probe, "replay_ms": replay_ms, "attention_guard": guard, "worst_case_precision": worst,
+            "eager_plugin_api": eager_api, "config4_frame": frame_line, "vith1024": vith_line,
             "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         try:   # RCCL prints a banner through C stdio; flush it so that the JSON line is the LAST line of stdout

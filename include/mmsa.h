@@ -51,6 +51,9 @@ extern "C" {
 
 typedef void* mmsa_stream_t; /* hipStream_t */
 
+/* mmsa_version() returns the MMSA_ABI_VERSION (mmsa_version.h) the library was built with; a binding must refuse a library whose number differs from
+ * the header it was written against (mmsa/lib.py does) -- argument lists are not self-describing through a C ABI. */
+#include "mmsa_version.h"
 int mmsa_version(void);
 const char* mmsa_last_error(void);
 
@@ -113,7 +116,7 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
  * A is EITHER fp32 (`A`, split to hi/lo while staged) OR interleaved activation planes (`Ap`, written by the
  * producing kernel; lda/strideA then count uint16 elements, lda >= 2K).  W: interleaved planes, row stride 2K.
  * The result goes to fp32 `C`, to planes `Cp` (row stride ldcp >= 2*N rounded up to 64), or both.
- * fmt = format of the A and W planes (MMSA_FMT_H8 / MMSA_FMT_H8C: A must come as planes, K % 64 == 0; H8C also M >= 128; lda / ldcp of h8c planes =
+ * fmt = format of the A and W planes (MMSA_FMT_H8 / MMSA_FMT_H8C: A must come as planes, K % 64 == 0, any M -- rows beyond M are clamped on the way in and masked on the way out; lda / ldcp of h8c planes =
  * row-pair strides >= 3 K / 3 pad64(N)); cp_fmt = format written to `Cp`:
  * bits 0..7 MMSA_FMT_*, bits 8.. = split / 32 -- columns >= split (a multiple of 32; 0 = none) are written as MMSA_FMT_H8 planes
  * whatever the base format (the qkv projection: q and k as f3 planes, v with an fp16 hi part for the attention kernels' v_fmt = 1).
@@ -172,7 +175,7 @@ int mmsa_attention_planes(const uint16_t* qkv_planes, long ldq, const uint16_t* 
                           uint16_t* out_planes, long ldo, int B, int H, int W, int heads, int head_dim,
                           int window_size, float scale, int out_fmt /* MMSA_FMT_* of out_planes */,
                           int v_fmt /* 0: qkv_planes / bias_planes (and the rel-pos planes of the fused entries) are MMSA_FMT_F3 planes -- fp16 hi/lo pairs, three fp16 MFMAs per product; round 4: bf16 hi/lo planes before, same layout, NOT accepted any more; 1 (this entry): their v columns are h8 planes (fp16 hi,
-                                       as the qkv GEMM writes them with cp_fmt = MMSA_FMT_B3 | (2D/32) << 8): P V runs on the fp16 MFMA with
+                                       as the qkv GEMM writes them with cp_fmt = MMSA_FMT_F3 | (2D/32) << 8): P V runs on the fp16 MFMA with
                                        P rounded to fp16; 2 (the two fused rel-pos entries below): qkv_planes, bias_planes AND relpos_planes
                                        are h8 planes throughout (and the window kernel's selector holds fp16 ones): every contraction of
                                        the kernel is one fp16 MFMA on the hi parts */,

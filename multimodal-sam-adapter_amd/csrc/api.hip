@@ -1,5 +1,6 @@
 // Library-level entry points: version and thread-local error string.
 #include "common.h"
+#include "../../include/mmsa_version.h"
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -12,7 +13,7 @@ void mmsa_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mmsa_last_error(void) { return g_err; }
-extern "C" int mmsa_version(void) { return 100; }  // 0.1.0
+extern "C" int mmsa_version(void) { return MMSA_ABI_VERSION; }   // include/mmsa.h; mmsa/lib.py refuses a library whose number differs from the one it was written for
 
 // HIP-event helpers so bench.py can time kernels on the launch stream without torch.cuda.Event.
 extern "C" int mmsa_event_create(void** ev) {
@@ -42,11 +43,8 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern) {
   if (lds_words[(threadIdx.x * 97) % (160 * 1024 / 4)] != pattern) asm volatile("s_nop 0");   // keep the stores
 }
 extern "C" int mmsa_debug_poison_lds(unsigned pattern, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  static MmsaPerDevice per_dev_ = {};
+  (void)mmsa_per_device(per_dev_, [] { (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 160 * 1024, stream, pattern);
   MMSA_CHECK_LAUNCH("debug_poison_lds");
   return MMSA_OK;

@@ -407,3 +407,22 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time PER-DEVICE launch setup.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of a kernel, and the CU
+// count is a property of the device: a process that packs a model on a second device (mmsa/backbone.py supports it) must not run there on the first device's
+// settings -- a > 64 KiB LDS launch would fail, or the persistent grid would be sized for the wrong chip.  `st` = a call site's zero-initialised table;
+// `setup()` runs the first time the current device is seen there; returns the current device's CU count.  (Idempotent, so a race between two host
+// threads is benign; devices beyond the table run setup() on every call.)
+#define MMSA_MAX_DEVICES 16
+struct MmsaPerDevice { int cus[MMSA_MAX_DEVICES]; };
+template <class F>
+static inline int mmsa_per_device(MmsaPerDevice& st, F&& setup) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  if (dev < MMSA_MAX_DEVICES && st.cus[dev] > 0) return st.cus[dev];
+  setup();
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev < MMSA_MAX_DEVICES) st.cus[dev] = n;
+  return n;
+}

@@ -388,9 +388,8 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   if (k == 7 && (y || yp) && act == ACT_NONE && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)bias)) & 15) == 0 &&
       (!extras || ((C & 63) == 0 && (H & 7) == 0 && (W & 7) == 0))) {
     if (y && !extras && (C & 31) == 0 && (H & 15) == 0 && (W & 15) == 0 && MMSA_KNOB("MMSA_DWCONV7_BLK", 1) != 0) {
-      static const bool attr_ = [] { (void)hipFuncSetAttribute((const void*)dwconv7_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW7B_LDS); return true; }();
-      (void)attr_;
-      static const int num_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+      static MmsaPerDevice per_dev_ = {};
+      const int num_cus = mmsa_per_device(per_dev_, [] { (void)hipFuncSetAttribute((const void*)dwconv7_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW7B_LDS); });
       const int txy = (W >> 4) * (H >> 4), nchunk = C >> 5;
       const long nt = (long)txy * nchunk * B;
       MMSA_CHECK_ARG(nt < (1L << 30), "dwconv_nhwc: too many tiles");

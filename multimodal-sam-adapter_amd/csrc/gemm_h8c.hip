@@ -58,6 +58,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
   { const int xcd = rb & 7, q = G >> 3, r = G & 7; rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (rb >> 3); }
   const int my_tiles = (a.ntiles - rb + G - 1) / G;
   if (my_tiles <= 0) return;
+  V2_SLACK_STAGGER(a, rb, G)
   const int total = my_tiles * np;            // pairs this workgroup walks: one continuous DMA stream across its output tiles
 
   // ---- DMA lane mapping.  HI: one instruction = 8 rows x 128 B (a row's 64-k chunk), lane -> (row = lane >> 3, LDS slot = lane & 7), the
@@ -285,13 +286,12 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
 
 // Launch (called by mmsa_gemm_v2_launch in gemm_v2.hip, which builds the argument block, the tile order and the grid).
 int mmsa_gemm_h8c_dispatch(const GemmV2Args& a, int grid, bool gen, int act, hipStream_t stream) {
-  static const bool attr_set = [] {
+  static MmsaPerDevice per_dev_ = {};   // the kernels' LDS attribute, once per device (common.h)
+  (void)mmsa_per_device(per_dev_, [] {
 #define HC_ATTR(GEN_, ACT_) (void)hipFuncSetAttribute((const void*)gemm_h8c_kernel<GEN_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, HC_LDS_TOTAL);
     HC_ATTR(false, ACT_NONE) HC_ATTR(false, ACT_GELU) HC_ATTR(false, ACT_RELU) HC_ATTR(false, -1) HC_ATTR(true, -1) HC_ATTR(true, ACT_NONE)
 #undef HC_ATTR
-    return true;
-  }();
-  (void)attr_set;
+  });
 #define HC_LAUNCH(GEN_, ACT_) hipLaunchKernelGGL((gemm_h8c_kernel<GEN_, ACT_>), dim3(grid), dim3(512), HC_LDS_TOTAL, stream, a)
   if (gen) {
     if (act == ACT_NONE) HC_LAUNCH(true, ACT_NONE);

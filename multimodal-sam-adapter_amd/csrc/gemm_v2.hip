@@ -61,6 +61,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
   }
   const int my_tiles = (a.ntiles - rb + G - 1) / G;   // tiles rb, rb+G, ...
   if (my_tiles <= 0) return;
+  V2_SLACK_STAGGER(a, rb, G)
   CLK_SAMPLE(0)
   const int total = my_tiles * nk;
 
@@ -588,11 +589,9 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
 #ifdef MMSA_DEBUG_KNOBS
   a.debug = MMSA_KNOB("MMSA_GEMM_DEBUG", 0);
 #endif
-  // CU count of the device + the kernels' LDS attributes: set once per process (immutable afterwards)
-  static const int num_cus = [] {
-    int dev = 0, n = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+  // CU count of the current device + the kernels' LDS attributes: set once per DEVICE (common.h mmsa_per_device)
+  static MmsaPerDevice per_dev_ = {};
+  const int num_cus = mmsa_per_device(per_dev_, [] {
 #define V2_ATTR(GEN_, ACT_)                                                                                                   \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8)); \
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, true, 8, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(8));  \
@@ -601,8 +600,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<GEN_, ACT_, false, 4, MMSA_FMT_B3>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES(4));
     V2_ATTR(false, ACT_NONE) V2_ATTR(false, ACT_GELU) V2_ATTR(false, ACT_RELU) V2_ATTR(false, -1) V2_ATTR(true, -1) V2_ATTR(true, ACT_NONE)
 #undef V2_ATTR
-    return n;
-  }();
+  });
   // max_grid > 0: at most that many persistent workgroups -- a caller that runs independent chains on concurrent streams gives each
   // GEMM its share of the CUs, so that the kernels of two chains are resident together (one 144 KiB workgroup fits a CU).  The tile
   // shape below is chosen for THAT many CUs (the value of an output element does not depend on the shape of its tile).
@@ -643,7 +641,17 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   // with 1) do, and leave 44 CUs to whatever runs on the other streams (the concurrent chain, the neck levels)
   const int slots_ = cus * wg_per_cu;
   const int rounds_ = cdiv(a.ntiles, slots_);
-  const int grid = cdiv(a.ntiles, rounds_);
+  int grid = cdiv(a.ntiles, rounds_);
+  // slack stagger (gemm_v2_shared.h): two or more rounds that do not come out even -> one workgroup per slot, the ones with a tile fewer start late.
+  // Estimated tile period in shader cycles: the k loop's measured cycles per k-tile (pair) + an epilogue.
+  a.stagger = 0;
+#ifndef MMSA_GEMM_STAGGER
+#define MMSA_GEMM_STAGGER 0   // 1 (A/B builds): on.  Measured no gain (profiles/r05_epilogue_regs.txt): off
+#endif
+  if (MMSA_GEMM_STAGGER && MMSA_KNOB("MMSA_GEMM_STAGGER", 1) && nw == 8 && rounds_ >= 2 && a.ntiles % slots_ != 0) {
+    grid = slots_;
+    a.stagger = h8c ? (K >> 6) * 3800 + 16000 : (K >> 5) * (fmt == MMSA_FMT_H8 ? 1700 : 1900) + 16000;
+  }
   const bool gen = out_mode != 0 || resid_mod > 0;
   if (h8c) return mmsa_gemm_h8c_dispatch(a, grid, gen, act, stream);
   const bool pp = MMSA_KNOB("MMSA_GEMM_PP", 1) != 0;   // 0 (debug-knob builds): every wave in phase (A/B timing)

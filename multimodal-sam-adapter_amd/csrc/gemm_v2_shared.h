@@ -31,6 +31,8 @@ struct GemmV2Args {
   //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
   float* rs_out; int rs_strips;
   const float* rn_mr; const float* rn_cs;
+  int stagger;   // > 0 (set by the launcher, see "slack stagger" there): estimated shader cycles of one tile period; workgroups that walk one tile fewer than the
+                 // longest ones start late by a fraction of it (V2_SLACK_STAGGER below)
 #ifdef MMSA_DEBUG_KNOBS
   int debug;   // MMSA_GEMM_DEBUG (timing experiments, debug-knob builds only: tools/build_variant.sh -DMMSA_DEBUG_KNOBS): 1 = no global stores, 2 = no epilogue at all, 3 = every k-tile re-reads k-tile 0 (L2-resident operands), 4 = every DMA piece of a wave re-reads the same 1 KiB (L1-resident operand stream), 5 = 4 + 2, 10 = epilogue without its global stores
 #endif
@@ -58,6 +60,22 @@ struct GemmV2Args {
 #ifndef V2_SETPRIO
 #define V2_SETPRIO 0   // s_setprio(1) around the MFMA chunks: measured no effect on this kernel (same-box A/B)
 #endif
+
+// Slack stagger (round 5).  When the tiles do not divide evenly among the persistent workgroups, most workgroups walk one tile fewer than the longest ones and
+// have one tile period of slack.  Started together, all workgroups reach their epilogues together, and the epilogues of the adapter-token GEMMs (read-modify-write
+// of the 176 MB fp32 token tensor) run at the chip's HBM + Infinity-Cache limit in bursts while the k loops in between use none of it
+// (profiles/r05_epilogue_regs.txt: extractor output projection 137 us = 87 us of k loops + 6 x 8.3 us of epilogue bursts at ~8 TB/s).  The workgroups with
+// slack therefore start late by (2 i + 1) / 32 of the estimated tile period, i = their index mod 16: their epilogues spread over the others' k loops and nobody
+// finishes later than the longest workgroups do anyway.  A pure timing change: which workgroup computes a tile never changes its value.
+#define V2_SLACK_STAGGER(a_, rb_, G_)                                                                       \
+  if ((a_).stagger > 0) {                                                                                   \
+    const int rem_ = (a_).ntiles % (G_);                                                                    \
+    if (rem_ > 0 && (rb_) >= rem_) {                                                                        \
+      const unsigned long long d_ = ((unsigned long long)(a_).stagger * (unsigned)((((rb_) - rem_) & 15) * 2 + 1)) >> 5;  \
+      const unsigned long long t0_ = __builtin_readcyclecounter();                                          \
+      while (__builtin_readcyclecounter() - t0_ < d_) __builtin_amdgcn_s_sleep(8);                          \
+    }                                                                                                       \
+  }
 
 #define GLDS16(gptr, lptr)                                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \

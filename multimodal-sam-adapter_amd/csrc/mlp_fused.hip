@@ -241,14 +241,11 @@ extern "C" int mmsa_convnext_mlp_fused(const unsigned short* Ap, long lda, long 
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.x = x; a.ldx = ldx; a.strideX = strideX; a.M = M; a.batch = batch;
   a.tiles_per_batch = cdiv(M, 128);
   a.ntiles = a.tiles_per_batch * batch;
-  static int num_cus = 0;
-  if (num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  static MmsaPerDevice per_dev_ = {};
+  const int num_cus = mmsa_per_device(per_dev_, [] {
     (void)hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS);
     (void)hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS);
-  }
+  });
   const int cus = (max_grid > 0 && max_grid < num_cus) ? max_grid : num_cus;
   const int grid = a.ntiles < cus ? a.ntiles : cus;
   if (fmt == MMSA_FMT_F3) hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(grid), dim3(512), MF_LDS, stream, a);

@@ -466,15 +466,12 @@ extern "C" int mmsa_window_attention_planes(const unsigned short* qkv_planes, lo
       mmsa_set_error("window_attention: index arithmetic not exact for window_size %d", window_size);
       return MMSA_ERR_ARG;
     }
-  // (cached per process: the launch attributes and the CU count of the current device -- immutable once set)
-  static const int num_cus = [] {
+  // (cached per device: the launch attributes and the CU count of the current device -- common.h mmsa_per_device)
+  static MmsaPerDevice per_dev_ = {};
+  const int num_cus = mmsa_per_device(per_dev_, [] {
     (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
     (void)hipFuncSetAttribute((const void*)wattn_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
-    return 256;
-  }();
+  });
   const int nWin = cdiv(H, window_size) * a.nWw;
   const int nitems = nWin * heads * B;
   // Grid: a workgroup walks items g, g + G, g + 2G, ... of a list that holds the interior windows first and the windows that

@@ -506,14 +506,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # --- interactions
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
 
-        def ifmt(w2d, site="inter"):   # operand format of one GEMM of a site group: h8c / h8 when selected and the contraction length allows it
+        def ifmt(w2d, site="inter", h8c_ok=True):   # operand format of one GEMM of a site group: h8c / h8 when selected and the contraction length allows it
             kk = ops.pad32(w2d.shape[1])
             if site not in h8_sites or kk % 64:
                 return ops.FMT_B3
-            return ops.FMT_H8C if (kk >= 512 and self._h8c_wanted()) else ops.FMT_H8
+            return ops.FMT_H8C if (h8c_ok and kk >= 512 and self._h8c_wanted()) else ops.FMT_H8
 
-        def iplanes(w2d, site="inter"):
-            return planes(w2d, fmt=ifmt(w2d, site))
+        def iplanes(w2d, site="inter", h8c_ok=True):
+            return planes(w2d, fmt=ifmt(w2d, site, h8c_ok))
 
         # Injector i normalises the adapter tokens c with its feat_norm, extractor i normalises the SAME c (the injector only
         # updates x) with its query_norm: two LayerNorm passes over the largest token matrix of the path (Nc = 21504 rows per
@@ -545,7 +545,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 dw = sd[b + "ffn.dwconv.dwconv.weight"]
                 ep.update(fc1=iplanes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
                           dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
-                          fc2=iplanes(sd[b + "ffn.fc2.weight"]), fc2_b=sd[b + "ffn.fc2.bias"],
+                          # fc2's A operand is written by the 3 x 3 depthwise conv (mmsa_dwconv_nhwc), which emits bf16 hi/lo and h8 LINE planes only:
+                          # a hidden width >= 512 (cffn_ratio 0.5 at embed_dim 1024; the reference's configs stay <= 320) must not pick h8c here
+                          fc2=iplanes(sd[b + "ffn.fc2.weight"], h8c_ok=False), fc2_b=sd[b + "ffn.fc2.bias"],
                           ffw=sd[b + "ffn_norm.weight"], ffb=sd[b + "ffn_norm.bias"])
             return ep
 
@@ -911,19 +913,27 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             return pol
         return bp.get("amode") or "f16"
 
+    def attention_guard_words(self):
+        """The device tensor [depth] fp32 the attention kernels fold their largest |logit| into (None before the first forward): graph owners copy it to
+        pinned memory behind a replay and hand the values to check_attention_guard(vals=...) (mmsa.Chains)."""
+        return self._packed["attn_guard"] if self._packed is not None else None
+
     @torch.no_grad()
-    def check_attention_guard(self, reroute=True):
-        """Read the per-block logit guard words (host sync) and fold them into the blocks' `max_logit`.  With `attention_precision =
-        "auto"` a block that runs fp16 attention and has seen a logit above ATTN_F16_MAX_LOGIT is moved to bf16 hi/lo operands (attention
-        kernels and the block's four GEMM weights, repacked here) when `reroute`.  Returns the list of block indices that were (or, with
-        reroute=False, would have to be) moved: non-empty means the outputs of the batches since the last check were computed on fp16
-        attention beyond the threshold -- run them again (forward() does by itself), and capture graphs again."""
+    def check_attention_guard(self, reroute=True, vals=None):
+        """Read the per-block logit guard words (host sync; or take `vals`, a host copy of them made behind the passes in question) and fold them into
+        the blocks' `max_logit`.  With `attention_precision = "auto"` a block that runs fp16 attention and has seen a logit above ATTN_F16_MAX_LOGIT is
+        moved to fp16 hi/lo PAIR operands (f3 planes, clamped at +-65504: the attention kernels' q / k / v, the bias rows, the rel-pos tables and the block's
+        four GEMM weights, repacked here) when `reroute`.  Returns the list of block indices that were (or, with reroute=False, would have to be) moved:
+        non-empty means the outputs of the batches since the last check were computed on fp16 attention beyond the threshold -- run them again
+        (forward() does by itself), and capture graphs again."""
         pk = self._packed
         if pk is None:
             return []
-        vals = pk["attn_guard"].tolist()      # device -> host: waits for the work queued so far
+        if vals is None:
+            vals = pk["attn_guard"].tolist()      # device -> host: waits for the work queued so far
         auto = self._attn_policy() == "auto"
         moved = []
+        sd_dev = None     # the float parameters on the device, built once for all the blocks that move in this call (ADVICE r04)
         for bp, v in zip(pk["blocks"], vals):
             bp["max_logit"] = max(float(v), bp.get("max_logit", 0.0))
             if not auto or bp["qkv_bp16"] is None:
@@ -938,7 +948,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                         # whole block moves to hi/lo PAIR operands -- fp16 pairs since round 4 (f3 planes, 2^-22 per product; bf16 pairs before:
                         # 2^-17, a floor of 2^-17 x the logit) --, repacked here from the state dict.
                         dev = pk["attn_guard"].device
-                        bp.update(self._block_gemm_planes(self._pack_state_dict(dev), bp["index"], ops.FMT_F3, pk["fold_ln"], dev))
+                        if sd_dev is None:
+                            sd_dev = self._pack_state_dict(dev)
+                        bp.update(self._block_gemm_planes(sd_dev, bp["index"], ops.FMT_F3, pk["fold_ln"], dev))
             elif bp.get("amode") is None:
                 bp["amode"] = "f16"
         return moved

@@ -17,15 +17,46 @@ import torch
 from . import ops
 
 
+class AttentionRangeError(RuntimeError):
+    """A replayed pass ran fp16 attention on logits beyond its range (backbone.ATTN_F16_MAX_LOGIT): the outputs of the passes named in the message are
+    invalid.  The blocks concerned have been moved to fp16 hi/lo pairs and the graphs captured again: replay those passes."""
+
+
+class Replay:
+    """What Chains.replay() returns: the outputs of ONE pass, readable only once the attention logit guard of that pass has been inspected.  A captured
+    graph cannot branch, so a replay cannot re-route a block whose logits outgrew single fp16 operands the way an eager forward does; instead every
+    pass is followed by an asynchronous copy of the guard words (4 bytes per ViT block) into pinned memory, and `outputs()` waits for THAT copy -- not
+    for the device -- and raises AttentionRangeError instead of handing out tensors computed out of range."""
+
+    def __init__(self, owner, seq):
+        self._owner, self.seq = owner, seq
+
+    def outputs(self):
+        """logits [B, classes, H/4, W/4] (Chains with a head) or the per-chain feature lists; verified."""
+        self._owner._verify(self.seq)
+        return self._owner.logits if self._owner.head is not None else self._owner.feats
+
+    @property
+    def unverified(self):
+        """The same tensors without the check -- for owners that inspect the guard themselves after a timing loop (bench.py) or enqueue further
+        kernels on them before the pass is verified (SlideRunner); whatever is READ from them must be verified first."""
+        return self._owner.logits if self._owner.head is not None else self._owner.feats
+
+
 class Chains:
-    def __init__(self, backbone, head=None, n=2, emit_planes=True):
+    def __init__(self, backbone, head=None, n=2, emit_planes=True, check_every=1):
         if n < 1:
             raise ValueError("mmsa.Chains: n must be >= 1")
+        if check_every < 1:
+            raise ValueError("mmsa.Chains: check_every must be >= 1")
         self.backbone, self.head, self.n = backbone, head, n
         self.emit_planes = emit_planes and head is not None
         self.graphs, self.streams, self.feats = [], [], []
         self.logits = None
         self.x = None
+        # guard bookkeeping: pass numbers are 1, 2, ...; `_clean_upto` = last pass known to have run in range, `_bad` = [(first, last)] invalid passes
+        self.check_every = check_every
+        self._seq, self._clean_upto, self._bad, self._pending, self._pool = 0, 0, [], [], []
 
     def _step(self, i, xs):
         """One chain's work on its slice: backbone (+ head into its slice of the shared logits tensor)."""
@@ -96,11 +127,16 @@ class Chains:
         """Enqueue one pass over the batch: every chain starts behind the current stream's work.  join=True: the current stream then
         waits for all chains (the outputs are ready for whatever it does next).  join=False: the chains free-run -- consecutive
         replays queue up per chain and nothing orders chain A's pass k against chain B's (measured within 1 % of the joined form);
-        call join() before reading the outputs."""
+        call join() before reading the outputs.
+        Returns a `Replay`: `.outputs()` hands the tensors out once that pass's guard words have been inspected (see Replay).  Passes whose
+        guard copies have already arrived are inspected HERE first: if one of them ran out of range this call raises AttentionRangeError
+        (blocks re-routed, graphs captured again) before enqueuing anything."""
+        self._inspect(wait_for=0)
         main = torch.cuda.current_stream(self.x.device)
         start = torch.cuda.Event()
         start.record(main)
         self._done = []
+        self._seq += 1
         for g, s in zip(self.graphs, self.streams):
             s.wait_event(start)
             with torch.cuda.stream(s):
@@ -110,22 +146,82 @@ class Chains:
             self._done.append(done)
         if join:
             self.join()
-        return self.logits if self.head is not None else self.feats
-
-    @torch.no_grad()
-    def check_guard(self, recapture=True):
-        """Read the backbone's attention logit guard (host sync: call it after the replays whose outputs matter).  [] = every block ran
-        inside its operand precision's range.  Otherwise the listed blocks have been moved to bf16 hi/lo operands: the outputs of the
-        replays since the last check were computed on fp16 attention beyond the threshold, and the graphs are stale -- with
-        `recapture` they are captured again here (same static input buffer), so the next replay() is valid."""
-        torch.cuda.synchronize(self.x.device)
-        moved = self.backbone.check_attention_guard()
-        if moved and recapture:
-            self.capture(self.x)
-        return moved
+        return Replay(self, self._seq)
 
     def join(self):
-        """Make the current stream wait for the chains' last enqueued pass."""
+        """Make the current stream wait for the chains' last enqueued pass -- and, every `check_every`-th pass, enqueue the copy of the guard words
+        behind it (one 4 * depth-byte device-to-host copy into pinned memory + an event; nothing waits for it here)."""
         main = torch.cuda.current_stream(self.x.device)
         for e in getattr(self, "_done", []):
             main.wait_event(e)
+        words = self.backbone.attention_guard_words()
+        if self._done and words is not None and self._seq % self.check_every == 0 and not (self._pending and self._pending[-1][0] == self._seq):
+            host = self._pool.pop() if self._pool else torch.empty(words.numel(), dtype=words.dtype).pin_memory()
+            host.copy_(words, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._pending.append((self._seq, ev, host))
+
+    @torch.no_grad()
+    def _inspect(self, wait_for):
+        """Look at the guard copies that have arrived (and WAIT for the first one that covers pass `wait_for`, if > 0).  The words only ever
+        grow (the kernels fold maxima into them), so a copy taken after pass j speaks for every pass up to j."""
+        moved_at = None
+        while self._pending:
+            seq, ev, host = self._pending[0]
+            if not ev.query():
+                if not (wait_for > 0 and self._clean_upto < wait_for):
+                    break
+                ev.synchronize()
+            self._pending.pop(0)
+            moved = self.backbone.check_attention_guard(vals=host.tolist())
+            self._pool.append(host)
+            if moved:
+                self._bad.append((self._clean_upto + 1, self._seq))    # everything enqueued since the last clean inspection ran on the stale graphs
+                self._clean_upto = self._seq
+                for _, _, h in self._pending:
+                    self._pool.append(h)
+                self._pending = []
+                moved_at = (seq, moved)
+                break
+            self._clean_upto = max(self._clean_upto, seq)
+        if moved_at is not None:
+            first, last = self._bad[-1]
+            torch.cuda.synchronize(self.x.device)
+            self.capture(self.x)
+            raise AttentionRangeError(f"mmsa.Chains: ViT block(s) {moved_at[1]} scored attention logits beyond the fp16 range (seen after pass {moved_at[0]}): "
+                                      f"the outputs of passes {first}..{last} are invalid.  The blocks now run on fp16 hi/lo pairs and the graphs have been "
+                                      "captured again -- replay those passes.")
+
+    def _verify(self, seq):
+        """Raise unless pass `seq` is known to have run inside the attention kernels' operand range."""
+        for a, b in self._bad:
+            if a <= seq <= b:
+                raise AttentionRangeError(f"mmsa.Chains: pass {seq} ran fp16 attention out of range (passes {a}..{b} are invalid): replay it")
+        if seq <= self._clean_upto:
+            return
+        if not any(s >= seq for s, _, _ in self._pending):   # no copy covers it (check_every > 1, join=False without join()): read the words now
+            moved = self.check_guard()
+            if moved:
+                raise AttentionRangeError(f"mmsa.Chains: ViT block(s) {moved} ran fp16 attention out of range in pass {seq}; blocks re-routed, graphs captured again: replay it")
+            return
+        self._inspect(wait_for=seq)
+        self._verify(seq)
+
+    @torch.no_grad()
+    def check_guard(self, recapture=True):
+        """Read the backbone's attention logit guard NOW (host sync: waits for everything enqueued).  [] = every block ran inside its operand
+        precision's range in all passes so far.  Otherwise the listed blocks have been moved to fp16 hi/lo pairs: the outputs of the
+        passes since the last clean check were computed on fp16 attention beyond the threshold (their Replay.outputs() will raise), and the
+        graphs are stale -- with `recapture` they are captured again here (same static input buffer), so the next replay() is valid."""
+        torch.cuda.synchronize(self.x.device)
+        moved = self.backbone.check_attention_guard()
+        for _, _, h in self._pending:
+            self._pool.append(h)
+        self._pending = []
+        if moved:
+            self._bad.append((self._clean_upto + 1, self._seq))
+        self._clean_upto = self._seq
+        if moved and recapture:
+            self.capture(self.x)
+        return moved

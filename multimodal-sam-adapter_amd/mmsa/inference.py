@@ -254,13 +254,30 @@ def argmax_map(seg_logit):
     return out
 
 
+class FrameResult:
+    """What SlideRunner.run() returns: the class map of ONE frame, readable once the attention logit guard of its pass has been inspected
+    (mmsa.chains.Replay; a pass that ran fp16 attention out of range raises mmsa.chains.AttentionRangeError instead)."""
+
+    def __init__(self, runner, replay):
+        self._runner, self._replay = runner, replay
+
+    def outputs(self):
+        """(class map uint8 [B, H, W], uncovered-pixel flag) -- verified.  Both are the runner's static buffers: read them before the next run()."""
+        self._replay._owner._verify(self._replay.seq)
+        return self._runner.out, self._runner.unc
+
+    @property
+    def unverified(self):
+        return self._runner.out, self._runner.unc
+
+
 class SlideRunner:
     """Throughput form of slide_class_map for a fixed frame geometry: the frame's windows are cut by one kernel, go through the
     encoder + head as `chains` concurrent sub-batches (mmsa.Chains: one HIP graph per chain, shared packed weights) and one kernel
     (mmsa_slide_argmax) turns the head-resolution logits into the class map.  Same class map as slide_inference + argmax_map, bit
     for bit.  `frame` is the static [B, 6, H, W] buffer the runner reads on every run()."""
 
-    def __init__(self, backbone, head, frame, crop_size, stride, chains=2):
+    def __init__(self, backbone, head, frame, crop_size, stride, chains=2, check_every=1):
         import ctypes
         from .chains import Chains
         _check(frame)
@@ -278,25 +295,29 @@ class SlideRunner:
             chains = 1
         with torch.cuda.device(self.frame.device):
             self.crops = _crops(self.frame, self.jobs, self.crop_size)          # also the static input buffer of the chains
-            self.chains = Chains(backbone, head, n=chains).capture(self.crops)
+            self.chains = Chains(backbone, head, n=chains, check_every=check_every).capture(self.crops)
             self.tab = (ctypes.c_int * (3 * n))(*[v for b, (y1, x1, _, _) in self.jobs for v in (b, y1, x1)])
             self.out = torch.empty(B, H, W, dtype=torch.uint8, device=self.frame.device)
             self.unc = torch.zeros(1, dtype=torch.int32, device=self.frame.device)
 
     @torch.no_grad()
     def run(self):
-        """-> (class map uint8 [B, H, W], uncovered-pixel flag); asynchronous on the current stream."""
+        """Enqueue one frame on the current stream (asynchronous) -> FrameResult; `.outputs()` = (class map uint8 [B, H, W], uncovered-pixel flag) once the
+        attention logit guard of this pass has been inspected.  The inspection costs one 4 * depth-byte copy per `check_every` frames and an event wait,
+        no device sync; a frame that scored logits beyond the fp16 range raises mmsa.chains.AttentionRangeError from outputs() -- or from the next run(),
+        whichever comes first -- after the blocks concerned have been moved to fp16 hi/lo pairs and the graphs captured again: run that frame again."""
         with torch.cuda.device(self.frame.device):
             _crops(self.frame, self.jobs, self.crop_size, out=self.crops)
-            lg = self.chains.replay()
+            rp = self.chains.replay()
+            lg = rp.unverified          # the argmax kernel below is enqueued behind the pass; nothing is read on the host before outputs() verifies it
             B, H, W = self.out.shape
             self.unc.zero_()
             lib.call("mmsa_slide_argmax", lg.data_ptr(), len(self.jobs), lg.shape[1], lg.shape[2], lg.shape[3], self.tab, self.out.data_ptr(),
                      B, H, W, self.crop_size[0], self.crop_size[1], self.unc.data_ptr(), ops._stream())
-        return self.out, self.unc
+        return FrameResult(self, rp)
 
     def check_guard(self):
-        """Chains.check_guard for the runner's chains: [] = the frames since the last check ran inside the attention kernels' operand range;
-        otherwise the listed ViT blocks were moved to bf16 hi/lo operands, the graphs were captured again and run() must be repeated for
-        those frames (the class maps returned for them came from fp16 attention beyond its threshold)."""
+        """Chains.check_guard for the runner's chains (host sync): [] = the frames since the last check ran inside the attention kernels' operand range;
+        otherwise the listed ViT blocks were moved to fp16 hi/lo pairs, the graphs were captured again and run() must be repeated for
+        those frames (their FrameResult.outputs() raise)."""
         return self.chains.check_guard()

@@ -85,6 +85,14 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = _RESTYPES.get(_name, c_int)
 
 
+# The C ABI is not self-describing: a library built from another tree (MMSA_LIB variants, a stale in-tree .so) may export every symbol and still take
+# different argument lists.  include/mmsa.h MMSA_ABI_VERSION is bumped with every such change; this binding was written for:
+ABI_VERSION = 101
+if _lib.mmsa_version() != ABI_VERSION:
+    raise RuntimeError(f"{LIB_PATH}: ABI version {_lib.mmsa_version()} but mmsa/lib.py binds version {ABI_VERSION} (include/mmsa.h MMSA_ABI_VERSION): "
+                       "rebuild with python multimodal-sam-adapter_amd/build.py")
+
+
 def last_error() -> str:
     return _lib.mmsa_last_error().decode()
 

@@ -49,6 +49,9 @@ CONFIGS = {
     # peaky attention at ViT-L: the seeded weights with the q / k rows of every qkv projection x 3 (tests/weights.py
     # peaky_attention): max |logit| ~ 30-40, where fp16 attention operands leave the gate and the blocks must run bf16 hi/lo
     "vitl1024_peaky": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9, qk_scale=3.0),
+    # a MIXED precision state at ViT-L: q / k x 3 in 6 of the 24 blocks only (two of them global blocks) -- the guard moves those six to
+    # fp16 hi/lo pairs, the other eighteen stay on single fp16 operands, in one forward
+    "vitl1024_mixed": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9, qk_scale=3.0, qk_blocks=[2, 5, 9, 14, 19, 23]),
     "vith1024": dict(kwargs=_VITH, batch=1, seed=17, in_seed=18),
     "vitl800": dict(kwargs=_VITL800, batch=1, seed=19, in_seed=20, type="SAMAdapterbimodalMixModNewInTwinConvNEWwithcp"),
 }

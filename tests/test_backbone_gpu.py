@@ -78,6 +78,29 @@ def test_constructor_switches_one_at_a_time(flag):
         assert_close(f, r, what=f"{flag}=False f{i+1} vs oracle")
 
 
+def test_convffn_hidden_width_512_keeps_a_format_its_producer_writes():
+    """with a ConvFFN hidden width >= 512 (here embed_dim 256 x cffn_ratio 2) the packed fc2 weight would qualify for h8c planes, but
+    its A operand comes from the 3 x 3 depthwise conv (AM:459-470), which writes bf16 hi/lo and h8 line planes only: the pack keeps fc2 on h8
+    lines and the forward runs -- against the oracle built the same way."""
+    import mmsa
+    from mmsa import ops
+    kw = dict(CONFIGS["tiny256"]["kwargs"], embed_dim=256, num_heads=4, cffn_ratio=2.0)
+    torch.manual_seed(0)
+    orc = R.OracleEncoder(**kw)
+    sd = seeded_state_dict(orc, seed=41)
+    orc.load_state_dict(sd)
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **kw))
+    m.load_state_dict(sd, strict=True)
+    x = make_input(dict(kwargs=kw, in_seed=42))
+    fs, _ = m(x.to(DEV))
+    ext = m._packed["inter"][0]["ext"][0]
+    assert ext["fc2"].kpad == 512 and ext["fc2"].fmt == ops.FMT_H8, "fc2 (K = 512) stays on h8 line planes"
+    assert ext["fc1"].fmt == ops.FMT_H8, "fc1 (K = 256) is below the h8c threshold"
+    ref, _ = orc(x)
+    for i, (f, r) in enumerate(zip(fs, ref)):
+        assert_close(f, r, what=f"cffn hidden 512 f{i+1} vs oracle")
+
+
 def test_fewer_than_128_token_rows_with_the_layernorm_fold():
     """a model whose ViT LayerNorms are folded into the qkv / lin1 GEMMs (embed_dim 128, 2 heads of 64) on ONE 128 x 128 image has
     B * T = 64 token rows -- below what the row-normalising GEMM epilogue takes.  The forward then runs the same folded weights behind a
@@ -204,6 +227,27 @@ def test_vitl1024_peaky_attention_against_the_reference(golden_dir):
     assert all(lg <= m.ATTN_F16_MAX_LOGIT for mode, lg in modes if mode == "f16"), modes
     for i, f in enumerate(fs):
         _check_probes(f[0], g, i, f"vitl1024 peaky attention ({nb3} of {len(modes)} blocks on bf16 hi/lo) f{i+1} probes")
+
+
+def test_vitl1024_mixed_precision_state_against_the_reference(golden_dir):
+    """a MIXED state at ViT-L pinned against the reference -- q / k x 3 in blocks 2, 5, 9, 14, 19, 23 only (5 and 23 are global
+    blocks; golden probes from the imported reference on those weights, tests/golden/model_vitl1024_mixed.npz).  One forward: the guard moves exactly
+    those six blocks to fp16 hi/lo pairs (attention kernels and their four GEMMs), the other eighteen stay on single fp16 operands next to them,
+    and the outputs hold the 1e-3 gate."""
+    import mmsa
+    from tests.weights import peaky_attention
+    cfg = CONFIGS["vitl1024_mixed"]
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    sd = peaky_attention(seeded_state_dict(m, seed=cfg["seed"]), cfg["kwargs"]["embed_dim"], cfg["qk_scale"], cfg["qk_blocks"])
+    m.load_state_dict(sd, strict=True)
+    g = np.load(os.path.join(golden_dir, "model_vitl1024_mixed.npz"))
+    fs, _ = m(make_input(cfg).to(DEV))
+    modes = m.attention_modes()
+    assert [i for i, (mode, _) in enumerate(modes) if mode == "b3"] == cfg["qk_blocks"], modes
+    assert all(lg > 2 * m.ATTN_F16_MAX_LOGIT for i, (_, lg) in enumerate(modes) if i in cfg["qk_blocks"]), modes
+    assert all(lg <= m.ATTN_F16_MAX_LOGIT for i, (_, lg) in enumerate(modes) if i not in cfg["qk_blocks"]), modes
+    for i, f in enumerate(fs):
+        _check_probes(f[0], g, i, f"vitl1024 mixed state (6 of 24 blocks on fp16 pairs) f{i+1} probes")
 
 
 def test_rejects_wrong_inputs():

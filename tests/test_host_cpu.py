@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(mmsa.lib.raw, name), f"{name} declared in include/mmsa.h but not exported"
     assert declared == set(mmsa.lib.SIGNATURES), "ctypes signature table and header disagree"
-    assert mmsa.lib.version() >= 100
+    assert mmsa.lib.version() == mmsa.lib.ABI_VERSION == int(re.search(r"#define MMSA_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "mmsa_version.h")).read()).group(1))
 
 
 def test_state_dict_contract_with_the_constructor_switches_off(golden_dir):

@@ -186,7 +186,7 @@ def test_concurrent_chains_equal_one_chain_bit_for_bit(models, nch):
     for rep in range(3):
         if rep == 2:
             x.copy_(make_input(cfg, batch=2 * nch, seed=32).to(DEV))     # the graphs read the caller's buffer
-        logits = ch.replay()
+        logits = ch.replay().outputs()       # verified: waits for this pass's guard copy, not for the device
         torch.cuda.synchronize()
         for c in range(nch):      # chain c == a plain forward + head of its own slice
             fs, _ = m(x[2 * c:2 * c + 2])
@@ -197,7 +197,7 @@ def test_concurrent_chains_equal_one_chain_bit_for_bit(models, nch):
                 assert torch.equal(ch.feats[c][k], fs[k])
     assert mmsa.ops.GEMM_MAX_GRID == 0 and getattr(h, "buf_tag", "") == ""      # nothing left switched on
     enc = mmsa.Chains(m, None, n=nch).capture(x)                               # encoder-only chains
-    feats = enc.replay()
+    feats = enc.replay().outputs()
     torch.cuda.synchronize()
     for c in range(nch):
         fs, _ = m(x[2 * c:2 * c + 2])
@@ -205,6 +205,57 @@ def test_concurrent_chains_equal_one_chain_bit_for_bit(models, nch):
             assert torch.equal(feats[c][k], fs[k])
     with pytest.raises(RuntimeError):
         mmsa.Chains(m, None, n=nch).capture(x[:nch + 1])
+
+
+def test_chains_refuse_unchecked_outputs(models):
+    """a captured graph cannot re-route a block whose attention logits outgrow single fp16 operands, so Chains.replay() returns a
+    handle and `outputs()` hands tensors out only after THAT pass's guard words have been inspected (an asynchronous 4 * depth-byte copy into pinned
+    memory behind every pass).  A guard word beyond the threshold -- written here the way the attention kernels' atomic max would -- makes outputs()
+    raise, moves the block to fp16 hi/lo pairs, captures the graphs again; the next pass is valid, the bad one stays refused.  Same for SlideRunner."""
+    import mmsa
+    import mmsa.inference as inf
+    from mmsa.chains import AttentionRangeError
+    cfg, _, _, m0, h = models
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))      # own instance: this test changes block modes
+    m.load_state_dict(m0.state_dict())
+    x = make_input(cfg, batch=2, seed=41).to(DEV)
+    ch = mmsa.Chains(m, h, n=2).capture(x)
+    r1 = ch.replay()
+    good = r1.outputs().clone()
+    assert all(mode == "f16" for mode, _ in m.attention_modes())
+    m.attention_guard_words()[1] = 3.0 * m.ATTN_F16_MAX_LOGIT      # "block 1 scored a logit of 24 in the next pass"
+    r2 = ch.replay()
+    with pytest.raises(AttentionRangeError, match=r"block\(s\) \[1\]"):
+        r2.outputs()
+    assert m.attention_modes()[1][0] == "b3" and m.attention_modes()[0][0] == "f16"
+    with pytest.raises(AttentionRangeError):
+        r2.outputs()                       # the invalid pass stays refused
+    r3 = ch.replay()                       # graphs were captured again on the re-routed block
+    out3 = r3.outputs()
+    fs, _ = m(x[:1])
+    torch.cuda.synchronize()
+    assert torch.equal(out3[:1], h(fs)) and out3.shape == good.shape       # block 1 now runs on pairs: the eager path's bits
+    assert r1.outputs() is ch.logits       # a pass verified before stays verified
+    # the same without reading outputs(): the NEXT replay() notices the arrived copy and raises before enqueuing anything
+    m.attention_guard_words()[3] = 2.0 * m.ATTN_F16_MAX_LOGIT
+    ch.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(AttentionRangeError, match=r"block\(s\) \[3\]"):
+        ch.replay()
+    assert ch.replay().outputs() is ch.logits
+    # check_every > 1: a pass without a copy of its own is verified by a synchronous read
+    ch5 = mmsa.Chains(m, h, n=2, check_every=5).capture(x)
+    assert ch5.replay().outputs() is ch5.logits and not ch5._pending
+    # SlideRunner: FrameResult.outputs() goes through the same check
+    frame = torch.randn(1, 6, 300, 420, generator=torch.Generator().manual_seed(5)).to(DEV)
+    sr = inf.SlideRunner(m, h, frame, (256, 256), (160, 160), chains=2)
+    cm, unc = sr.run().outputs()
+    m.attention_guard_words()[0] = 2.0 * m.ATTN_F16_MAX_LOGIT
+    fr = sr.run()
+    with pytest.raises(AttentionRangeError):
+        fr.outputs()
+    cm2, _ = sr.run().outputs()
+    assert cm2.shape == cm.shape
 
 
 def test_slide_runner_equals_slide_inference(models):
@@ -218,7 +269,7 @@ def test_slide_runner_equals_slide_inference(models):
     for rep in range(3):
         if rep == 2:
             frame.copy_(torch.randn(1, 6, 300, 420, generator=g).to(DEV))
-        cm, unc = sr.run()
+        cm, unc = sr.run().outputs()
         torch.cuda.synchronize()
         # the plain function on the chains' own sub-batch size: at this toy size the row count decides which GEMM kernel runs (not the
         # same bits for another batch size -- tests/test_backbone_gpu.py; at ViT-L sizes there is one kernel per shape)

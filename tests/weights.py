@@ -59,12 +59,15 @@ def seeded_state_dict(model, seed=0):
     return out
 
 
-def peaky_attention(sd, embed_dim, factor):
+def peaky_attention(sd, embed_dim, factor, blocks=None):
     """`sd` with the q and k rows of every attn.qkv projection (weight and bias, the first 2 * embed_dim rows: IE:488 memory order) scaled
     by `factor`: attention logits factor^2 times larger, everything else unchanged -- the fixtures with peaky attention (released SAM
-    checkpoints are peakier than the seeded generator above) are captured from the reference with these weights."""
+    checkpoints are peakier than the seeded generator above) are captured from the reference with these weights.  `blocks`: only these
+    block indices (a MIXED state: some blocks on single fp16 operands, the others on pairs), None = all."""
     out = dict(sd)
     for k in sd:
+        if blocks is not None and not any(k.startswith(f"blocks.{i}.") for i in blocks):
+            continue
         if k.endswith("attn.qkv.weight") or k.endswith("attn.qkv.bias"):
             v = sd[k].clone()
             v[:2 * embed_dim] *= factor

@@ -75,7 +75,7 @@ def main():
     try:   # throughput form: the six windows as two concurrent chains of three (mmsa.inference.SlideRunner)
         sr = inf.SlideRunner(m, h, frame, (1024, 1024), (640, 640), chains=2)
         for _ in range(2):
-            rcm, runc = sr.run()
+            rcm, runc = sr.run().outputs()
         torch.cuda.synchronize()
         assert int(runc.item()) == 0 and torch.equal(rcm, want), "SlideRunner class map differs"
         t0 = time.perf_counter()

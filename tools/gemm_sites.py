@@ -1,6 +1,6 @@
 """Stand-alone timing of the model's GEMM SITES with their real epilogue configuration (operand format, LayerNorm-fold extras, plane
 format of the output, residual, per-column scale, batch) -- what tools/gemm_shapes.py measures inside a forward, without the forward:
-    python tools/gemm_sites.py [lib.so ...]        (no argument: the in-tree library)
+    python tools/gemm_sites.py [--rounds 3] [--only lin1,qkv] [lib.so[:VAR=val+VAR2=val] ...]        (no library: the in-tree one)
 Each library is timed in its own process (MMSA_LIB), the libraries interleaved over --rounds rounds; random-normal operands (the clock the
 chip holds depends on the data).  us per launch, median of the rounds; ViT-L 1024^2, batch 2 (BASELINE configs[1]).
 Reference call sites: IE:154-167,488,499 (lin1 / lin2 / qkv / proj), TC:107-111 (pw1 / pw2), AM:447-451 (fc1 / fc2),
@@ -100,15 +100,17 @@ if __name__ == "__main__":
     for rnd in range(rounds):
         for lib in libs:
             env = dict(os.environ)
-            if lib:
-                env["MMSA_LIB"] = os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib
+            path, _, sets = lib.partition(":")      # "ab/lib.so:VAR=1+VAR2=x": environment of that library's worker (debug-knob builds)
+            env.update(dict(kv.split("=", 1) for kv in sets.split("+") if kv))
+            if path:
+                env["MMSA_LIB"] = os.path.join(ROOT, path) if not os.path.isabs(path) else path
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "worker"] + only, env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:
                 print(f"{lib or 'in-tree'}: FAILED\n{out.stderr[-1500:]}", flush=True)
                 continue
             runs[lib].append([float(x) for x in line[0].split()[1:]])
-    print(f"{'site':9s} {'M x N x K (batch)':26s} " + " ".join(f"{(os.path.basename(l) or 'in-tree')[:18]:>18s}" for l in libs) + ("   ratio to first" if len(libs) > 1 else ""))
+    print(f"{'site':9s} {'M x N x K (batch)':26s} " + " ".join(f"{(os.path.basename(l.replace('libmmsa_', '').replace('.so', '')) or 'in-tree')[:18]:>18s}" for l in libs) + ("   ratio to first" if len(libs) > 1 else ""))
     tot = {lib: 0.0 for lib in libs}
     for i, s in enumerate(SITES):
         med = {lib: (statistics.median(r[i] for r in runs[lib]) if runs[lib] else float("nan")) for lib in libs}

@@ -116,7 +116,7 @@ def gen_model(name, full):
     shapes = [list(v.shape) for v in ref.state_dict().values()]
     sd = seeded_state_dict(ref, seed=cfg["seed"])
     if cfg.get("qk_scale"):
-        sd = peaky_attention(sd, cfg["kwargs"]["embed_dim"], cfg["qk_scale"])
+        sd = peaky_attention(sd, cfg["kwargs"]["embed_dim"], cfg["qk_scale"], cfg.get("qk_blocks"))
     ref.load_state_dict(sd)
     x = make_input(cfg)
     with torch.no_grad():
@@ -323,6 +323,7 @@ def main():
         gen_model("vitl1024", full=False)
         gen_model("vitl1024_b", full=False)
         gen_model("vitl1024_peaky", full=False)
+        gen_model("vitl1024_mixed", full=False)
 
 
 if __name__ == "__main__":
