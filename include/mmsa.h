@@ -41,6 +41,12 @@
  *                   64 k-values where MMSA_FMT_H8 has 2: the GEMM's L2 -> LDS stream is what bounds its k loop (csrc/gemm_h8c.hip).
  *    `mmsa_split_planes` converts fp32; producer kernels emit the format of their `*_fmt` argument (h8c: mmsa_gemm_split3, mmsa_layernorm_rows,
  *    the three attention entries, mmsa_msda_fused, mmsa_split_planes).
+ *  - Clamp watch (round 5).  The fp16-based formats clamp what they cannot hold (h8 / h8c: |x| > 57344, f3: |x| > 65504; bf16 hi/lo planes have fp32's
+ *    range).  The entries that convert UNBOUNDED fp32 values to planes -- mmsa_gemm_split3, mmsa_layernorm_rows, mmsa_split_planes, mmsa_msda_fused,
+ *    mmsa_dwconv_nhwc -- take `clamp_max`, an optional DEVICE float (NULL = no watch): a launch that had to clamp folds the largest |value| it met beyond
+ *    the format's range into it with an atomic max (never lowered; the caller zeroes it).  0 after a forward = every operand plane holds its value.  The
+ *    attention entries need none (their outputs are convex combinations of v, which the qkv GEMM's watch has seen).  The reference computes in fp32
+ *    and has no such range; mmsa/backbone.py reads the word with the attention guard words and refuses a forward that clamped.
  */
 #ifndef MMSA_H
 #define MMSA_H
@@ -104,7 +110,7 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
                     const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
                     uint16_t* out_planes, long ldop /* optional operand planes output */, int out_fmt /* MMSA_FMT_* */, int batch,
                     int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
-                    mmsa_stream_t stream);
+                    float* clamp_max /* optional clamp watch word of out_planes, see Conventions */, mmsa_stream_t stream);
 
 /* --- GEMM (replaces F.linear / 1x1 conv / patchify conv / ConvTranspose2d 2x2 s2) ---------------------------
  * C = beta*resid + colscale[n] * alpha * act(A[M,K] W[N,K]^T + bias[n]); batch > 1 = strided batched (strides in
@@ -143,7 +149,7 @@ int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
                      uint16_t* Cp, long ldcp, long strideCp, int M, int N, int K,
                      int batch, int act, float alpha, int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt,
                      int max_grid, float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum, int flavour,
-                     mmsa_stream_t stream);
+                     float* clamp_max /* optional clamp watch word of the planes output, see Conventions */, mmsa_stream_t stream);
 
 /* ConvNeXt pointwise pair of the narrow stages as ONE kernel (TC:107-132): x[b] <- x[b] + gamma[b] * (GELU(A[b] W1[b]^T + b1[b]) W2[b]^T
  * + b2[b]); A = LayerNorm output as bf16 hi/lo planes [M, C] (row stride lda, batch stride strideA, uint16 units), W1 [4C, C] and
@@ -158,7 +164,7 @@ int mmsa_convnext_mlp_fused(const uint16_t* Ap, long lda, long strideA, const ui
  * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows; 3: h8c planes [ceil(rows / 2), 3*cols_pad] (cols_pad % 64 == 0; activations and weights);
  * 4: f3 (fp16 hi/lo pairs in the bf16 hi/lo layout). */
 int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad, uint16_t* planes, int kind,
-                      mmsa_stream_t stream);
+                      float* clamp_max /* optional clamp watch word, see Conventions */, mmsa_stream_t stream);
 
 /* --- attention (IE:465-501 incl. window_partition/unpartition IE:504-551 and rel-pos IE:587-623) -------------
  * Attention logit guard: the planes entries take `max_abs_logit`, an optional DEVICE float (NULL = none).  The launch folds the largest
@@ -199,7 +205,8 @@ int mmsa_relpos_bias_planes(const uint16_t* qkv_planes, long ldq, const float* R
 int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps, float* y, long ldy,
                         float* y2, long ldy2, uint16_t* y_planes, long ldp /* optional interleaved planes of y */,
                         int rows, int C, int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol,
-                        int y_wrap, int plane_fmt /* MMSA_FMT_* of y_planes */, mmsa_stream_t stream);
+                        int y_wrap, int plane_fmt /* MMSA_FMT_* of y_planes */, float* clamp_max /* optional clamp watch word, see Conventions */,
+                        mmsa_stream_t stream);
 
 /* out (double) [B,3,C]: sum_p x, sum_p x^2, sum_p wrow[p]*x over the HW rows of each image (wrow may be NULL). */
 int mmsa_colstats(const float* x, long ldx, long strideB, const float* wrow, int B, int HW, int C, double* out,
@@ -222,7 +229,7 @@ int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, co
                      int imgs_per_group /* > 0: image group g = b / imgs_per_group uses w + g*k*k*C, bias + g*C */,
                      float* rowstats /* optional, 7x7 only (C % 64 == 0, H, W % 8 == 0): per pixel and 64-channel chunk (sum, sum of squares) of the
                                         output, [B*H*W][C/64][2]: the strip sums of the LayerNorm fold (mmsa_rowstats_finalize) */,
-                     mmsa_stream_t stream);
+                     float* clamp_max /* optional clamp watch word, see Conventions */, mmsa_stream_t stream);
 int mmsa_gconv_nhwc(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int B, int H,
                     int W, int G, int cin_g, int cout_g, int k, int act, mmsa_stream_t stream);
 /* gated pair stage of the neck Mlp (AM:127-132): y = gelu(dw3x3(x)[:, :C]) * dw3x3(x)[:, C:], x token-major [B*H*W, 2C], the

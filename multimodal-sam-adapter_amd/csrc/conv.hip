@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, long ldy, long ystrideB,
                                                           unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
-                                                          int B, int H, int W, int C, int k, int act) {
+                                                          int B, int H, int W, int C, int k, int act, float* __restrict__ clamp_max) {
   // one thread per (pixel, 4 channels); blockIdx.y = image row (b*H + h): 32-bit index arithmetic only
   const int c4n = C >> 2;
   const int pad = k >> 1;
@@ -41,7 +41,12 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(const float* __restric
     acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
     const long oo = (long)b * ystrideB + ((long)hh * W + ww) * ldy + c;
     if (y) *reinterpret_cast<float4*>(y + oo) = acc;
-    if (yp) store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);   // operand planes, either format
+    if (yp) {   // operand planes, either format (+ clamp watch: common.h)
+      float cw_ = 0.f;
+      clamp_see(cw_, acc);
+      clamp_report(clamp_max, cw_, mmsa_clamp_limit(yp_fmt));
+      store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);
+    }
   }
 }
 
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
                                                             float* __restrict__ y, long ldy, long ystrideB,
                                                             unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
                                                             float* __restrict__ rs, int rs_strips,
-                                                            int H, int W, int C, int tilesX, int imgs_per_group, long w_gstride) {
+                                                            int H, int W, int C, int tilesX, int imgs_per_group, long w_gstride, float* __restrict__ clamp_max) {
   constexpr int TW = 14, CB = 64;
   // XCD-contiguous tiles (common.h): the tiles of a (channel chunk, image) -- whose halos overlap -- stay on one XCD's L2
   const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());
@@ -153,7 +158,12 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const float* __restr
     if (y && gx < W) *reinterpret_cast<float4*>(y + (long)b * ystrideB + ((long)gy * W + gx) * ldy + c) = acc[p];
     if (yp || rs) {   // kernel-uniform; the launcher guarantees full tiles and full 64-channel chunks here
       const long pix = (long)gy * W + gx;
-      if (yp) store_planes8_pair<1>(yp + (long)b * pstrideB + pix * ldp, c & ~7, acc[p], yp_fmt, (cv & 1) != 0, true);
+      if (yp) {
+        float cw_ = 0.f;   // clamp watch (common.h)
+        clamp_see(cw_, acc[p]);
+        clamp_report(clamp_max, cw_, mmsa_clamp_limit(yp_fmt));
+        store_planes8_pair<1>(yp + (long)b * pstrideB + pix * ldp, c & ~7, acc[p], yp_fmt, (cv & 1) != 0, true);
+      }
       if (rs) {     // the 16 lanes cv = 0..15 of this strip hold the pixel's 64 channels of the chunk
         float s1 = (acc[p].x + acc[p].y) + (acc[p].z + acc[p].w);
         float s2 = fmaf(acc[p].x, acc[p].x, acc[p].y * acc[p].y) + fmaf(acc[p].z, acc[p].z, acc[p].w * acc[p].w);
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(256) void dwconv3_nhwc_kernel(const float* __restri
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ y, long ldy, long ystrideB,
                                                            unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
-                                                           int B, int H, int W, int C, int act) {
+                                                           int B, int H, int W, int C, int act, float* __restrict__ clamp_max) {
   const int c4n = C >> 2;
   const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
   const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
@@ -317,7 +327,12 @@ __global__ __launch_bounds__(256) void dwconv3_nhwc_kernel(const float* __restri
   acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
   const long oo = (long)b * ystrideB + ((long)hh * W + ww) * ldy + c;
   if (y) *reinterpret_cast<float4*>(y + oo) = acc;
-  if (yp) store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);   // operand planes, either format
+  if (yp) {   // operand planes, either format (+ clamp watch: common.h)
+    float cw_ = 0.f;
+    clamp_see(cw_, acc);
+    clamp_report(clamp_max, cw_, mmsa_clamp_limit(yp_fmt));
+    store_planes4(yp + (long)b * pstrideB + ((long)hh * W + ww) * ldp, c, acc, yp_fmt);
+  }
 }
 
 // The same 3 x 3 conv on a 1 x 4 pixel strip per thread (W % 4 == 0; round 4, as conv_pair.hip's dwpair_gate4_kernel): a kernel row's six input
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float* __restr
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ y, long ldy, long ystrideB,
                                                             unsigned short* __restrict__ yp, long ldp, long pstrideB, int yp_fmt,
-                                                            int B, int H, int W, int C, int act) {
+                                                            int B, int H, int W, int C, int act, float* __restrict__ clamp_max) {
   const int c4n = C >> 2;
   const unsigned wg_ = mmsa_xcd_order(mmsa_block_lin(), mmsa_block_count());   // XCD-contiguous rows (common.h)
   const int bx_ = (int)(wg_ % gridDim.x), by_ = (int)(wg_ / gridDim.x);
@@ -370,13 +385,18 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float* __restr
     o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
     const long pix = (long)hh * W + w0 + p;
     if (y) *reinterpret_cast<float4*>(y + (long)b * ystrideB + pix * ldy + c) = o;
-    if (yp) store_planes4(yp + (long)b * pstrideB + pix * ldp, c, o, yp_fmt);   // operand planes, either format
+    if (yp) {   // operand planes, either format (+ clamp watch: common.h)
+      float cw_ = 0.f;
+      clamp_see(cw_, o);
+      clamp_report(clamp_max, cw_, mmsa_clamp_limit(yp_fmt));
+      store_planes4(yp + (long)b * pstrideB + pix * ldp, c, o, yp_fmt);
+    }
   }
 }
 
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
                                 float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB, int yp_fmt,
-                                int B, int H, int W, int C, int k, int act, int imgs_per_group, float* rowstats, hipStream_t stream) {
+                                int B, int H, int W, int C, int k, int act, int imgs_per_group, float* rowstats, float* clamp_max, hipStream_t stream) {
   MMSA_CHECK_ARG(yp_fmt == MMSA_FMT_B3 || yp_fmt == MMSA_FMT_H8, "dwconv_nhwc: bad output plane format %d", yp_fmt);
   MMSA_CHECK_ARG(x && w && (y || yp) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
   MMSA_CHECK_ARG(imgs_per_group >= 0 && (imgs_per_group == 0 || B % imgs_per_group == 0), "dwconv_nhwc: bad image grouping");
@@ -402,7 +422,7 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
     const int tx = cdiv(W, 8), ty = cdiv(H, 8);
     dim3 grid(tx * ty, cdiv(C, 64), B);
     hipLaunchKernelGGL(dwconv7_tiled_kernel, grid, dim3(256), 14 * 14 * 64 * sizeof(float), stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB,
-                       yp, ldp, pstrideB, yp_fmt, rowstats, C >> 6, H, W, C, tx, imgs_per_group, (long)k * k * C);
+                       yp, ldp, pstrideB, yp_fmt, rowstats, C >> 6, H, W, C, tx, imgs_per_group, (long)k * k * C, clamp_max);
     MMSA_CHECK_LAUNCH("dwconv_nhwc(7x7 tiled)");
     return MMSA_OK;
   }
@@ -411,11 +431,11 @@ extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const f
   MMSA_CHECK_ARG((long)B * H <= 65535, "dwconv_nhwc: B*H too large for the launch grid");
   const bool generic3 = MMSA_KNOB("MMSA_DWCONV3_GENERIC", 0) != 0;   // A/B aid
   if (k == 3 && !generic3 && (W & 3) == 0 && MMSA_KNOB("MMSA_DWCONV3_STRIP", 1) != 0 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
-    hipLaunchKernelGGL(dwconv3_strip_kernel, dim3(cdiv((long)(W >> 2) * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act);
+    hipLaunchKernelGGL(dwconv3_strip_kernel, dim3(cdiv((long)(W >> 2) * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act, clamp_max);
   else if (k == 3 && !generic3 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)bias) | ((uintptr_t)y)) & 15) == 0)
-    hipLaunchKernelGGL(dwconv3_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act);
+    hipLaunchKernelGGL(dwconv3_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, act, clamp_max);
   else
-    hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, k, act);
+    hipLaunchKernelGGL(dwconv_nhwc_kernel, dim3(cdiv((long)W * (C >> 2), 256), B * H), dim3(256), 0, stream, x, ldx, xstrideB, w, bias, y, ldy, ystrideB, yp, ldp, pstrideB, yp_fmt, B, H, W, C, k, act, clamp_max);
   MMSA_CHECK_LAUNCH("dwconv_nhwc");
   return MMSA_OK;
 }

@@ -33,6 +33,7 @@ struct GemmArgs {
   int act; float alpha;
   int out_mode; int ps_H, ps_W, ps_C;   // out_mode 1: 2x2 pixel-shuffle store (conv-transpose 2x2 s2)
   int cp_fmt;                           // format of the planes output (common.h: MMSA_FMT_B3 / MMSA_FMT_H8)
+  float* clamp_max;                     // optional clamp watch word (common.h)
 };
 
 #define BM 128
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
   // by register moves), one activation branch per 4 values: fully unrolled with the activation switch expanded per
   // element this epilogue was > 100 KiB of straight-line code -- beyond the 64 KiB instruction cache -- and ran at
   // instruction-fetch speed (same finding as gemm_v2.hip).
+  float cw_ = 0.f;   // clamp watch of the planes output (common.h)
 #pragma unroll 1
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + l15;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
           o.x += a.beta * rr.x; o.y += a.beta * rr.y; o.z += a.beta * rr.z; o.w += a.beta * rr.w;
         }
         if (C) *reinterpret_cast<float4*>(C + drow * a.ldc + dcol) = o;
-        if (Cp) store_planes4(Cp + drow * a.ldcp, dcol, o, MMSA_CP_AT(a.cp_fmt, dcol));
+        if (Cp) { clamp_see(cw_, o); store_planes4(Cp + drow * a.ldcp, dcol, o, MMSA_CP_AT(a.cp_fmt, dcol)); }
       } else {
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
@@ -267,12 +269,13 @@ __global__ __launch_bounds__(256) void gemm_split3_kernel(GemmArgs a) {
             float x = v[r];
             if (resid) x += a.beta * resid[rrow * a.ldr + dcol + r];
             if (C) C[drow * a.ldc + dcol + r] = x;
-            if (Cp) store_planes1(Cp + drow * a.ldcp, dcol + r, x, MMSA_CP_AT(a.cp_fmt, dcol + r));
+            if (Cp) { clamp_see1(cw_, x); store_planes1(Cp + drow * a.ldcp, dcol + r, x, MMSA_CP_AT(a.cp_fmt, dcol + r)); }
           }
         }
       }
     }
   }
+  if (Cp) clamp_report(a.clamp_max, cw_, MMSA_CP_SPLIT(a.cp_fmt) ? MMSA_H8_MAX : mmsa_clamp_limit(MMSA_CP_BASE(a.cp_fmt)));
 }
 
 int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
@@ -283,7 +286,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
-                        float* rs_out, const float* rn_mr, const float* rn_cs, int flavour);
+                        float* rs_out, const float* rn_mr, const float* rn_cs, int flavour, float* clamp_max);
 
 // ---- tiny problems (CoordinateAttention's 1x1 convs on pooled maps, AM:187-201: M = B*(h+w) <= ~1000 rows, N or K of 8..48): a
 // 128 x 128 MFMA tile would be one or two workgroups walking K alone (64 us for M = 128, N = 48, K = 1536).  Here one wave owns
@@ -341,7 +344,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
                                 int M, int N, int K, int batch, int act, float alpha,
                                 int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid,
                                 float* rowstats_out, const float* rownorm_mean_rstd, const float* rownorm_colsum, int flavour,
-                                hipStream_t stream) {
+                                float* clamp_max, hipStream_t stream) {
   const bool ap = Ap != nullptr;
   float* const rs_out = rowstats_out;
   const float* const rn_mr = rownorm_mean_rstd;
@@ -388,6 +391,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   a.Cp = Cp; a.ldcp = Cp ? ldcp : 0; a.strideCp = strideCp;
   a.M = M; a.N = N; a.K = K; a.act = act; a.alpha = alpha;
   a.out_mode = out_mode; a.ps_H = ps_H; a.ps_W = ps_W; a.ps_C = ps_C; a.cp_fmt = cp_fmt;
+  a.clamp_max = clamp_max;
   // main path: activation planes go to the LDS-DMA / 256x128 kernel (gemm_v2.hip); MMSA_GEMM_V1=1 (debug-knob builds) forces this one
   const bool force_v1 = MMSA_KNOB("MMSA_GEMM_V1", 0) != 0;
   // (round 1 routed one-strip shapes with many rows and a deep K -- ConvNeXt stage-0 pw2: N = 96, K = 384 -- to the 128-row tiles of
@@ -405,7 +409,7 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
   if (ap && (fmt != MMSA_FMT_B3 || (M >= 128 && !force_v1 && !narrow))) {   // h8 / h8c operands: only the LDS-DMA kernels read them
     return mmsa_gemm_v2_launch(Ap, lda, strideA, Wp, strideW, bias, strideBias, colscale, resid, ldr, strideR,
                                resid_mod, beta, C, ldc, strideC, Cp, ldcp, strideCp, M, N, K, batch, act, alpha,
-                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream, rs_out, rn_mr, rn_cs, flavour);
+                               out_mode, ps_H, ps_W, ps_C, fmt, cp_fmt, max_grid, stream, rs_out, rn_mr, rn_cs, flavour, clamp_max);
   }
   MMSA_CHECK_ARG(!extras, "gemm_split3: this shape is not routed to the LDS-DMA kernel, which alone writes row statistics / normalises rows");
   MMSA_CHECK_ARG(!cp_h8c, "gemm_split3: h8c output planes are written by the LDS-DMA kernel only (activation planes in, M >= 128)");
@@ -429,11 +433,13 @@ extern "C" int mmsa_gemm_split3(const float* A, const unsigned short* Ap, long l
 // kind 0: bf16 hi/lo planes; 1: h8 activation rows (chunk = lo bytes | q(hi) bytes); 2: h8 WEIGHT rows (chunk = q(hi) | lo); 3: h8c planes; 4: f3 (fp16 hi/lo)
 // (dense: row-pair stride 3 * cols_pad; rows odd: the pair partner of the last row is not written): common.h
 __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int rows, int cols, int cols_pad,
-                                    unsigned short* __restrict__ out, int kind) {
+                                    unsigned short* __restrict__ out, int kind, float* __restrict__ clamp_max) {
   const long total = (long)rows * cols_pad;
+  float cw_ = 0.f;   // clamp watch (common.h)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
     const float x = c < cols ? src[(long)r * ld + c] : 0.f;
+    clamp_see1(cw_, x);
     if (kind == 3) {   // h8c: row pairs [hi row 2j | hi row 2j+1 | lo lines] (common.h)
       h8c_store1(h8c_row(out, 3L * cols_pad, r, cols_pad), c, x);
       continue;
@@ -455,17 +461,18 @@ __global__ void split_planes_kernel(const float* __restrict__ src, long ld, int 
       rb[kind == 2 ? 0 : 8] = (unsigned char)(qh8 & 0xFFu);
     }
   }
+  clamp_report(clamp_max, cw_, kind == 0 ? 3.0e38f : kind == 4 ? MMSA_F3_MAX : MMSA_H8_MAX);
 }
 
 extern "C" int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pad,
-                                 unsigned short* out, int kind, hipStream_t stream) {
+                                 unsigned short* out, int kind, float* clamp_max, hipStream_t stream) {
   MMSA_CHECK_ARG(src && out && rows > 0 && cols > 0 && cols_pad >= cols && cols_pad % 32 == 0, "split_planes: bad args");
   MMSA_CHECK_ARG(kind >= 0 && kind <= 4, "split_planes: kind %d (0 bf16 hi/lo, 1 h8 activation, 2 h8 weight, 3 h8c, 4 f3)", kind);
   MMSA_CHECK_ARG(kind != 3 || cols_pad % 64 == 0, "split_planes: h8c planes need cols_pad %% 64 == 0");
   const long total = (long)rows * cols_pad;
   int blocks = cdiv(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, out, kind);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, cols_pad, out, kind, clamp_max);
   MMSA_CHECK_LAUNCH("split_planes");
   return MMSA_OK;
 }

@@ -549,8 +549,9 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         unsigned short* Cp, long ldcp, long strideCp,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
-                        float* rs_out, const float* rn_mr, const float* rn_cs, int flavour) {
+                        float* rs_out, const float* rn_mr, const float* rn_cs, int flavour, float* clamp_max) {
   GemmV2Args a;
+  a.clamp_max = clamp_max;
   // LayerNorm fold (mmsa_gemm_next_extras): both forms run on the unrolled fast epilogue of 128-column tiles with whole 64-column strips
   MMSA_CHECK_ARG(!rs_out || (C && out_mode == 0 && resid_mod <= 0 && act == ACT_NONE && (N & 63) == 0 && (ldc & 3) == 0 && (!resid || (ldr & 3) == 0) && (!Cp || (ldcp & 3) == 0)),
                  "gemm(v2): row statistics need a plain fp32 output, no activation, N %% 64 == 0 (N=%d)", N);

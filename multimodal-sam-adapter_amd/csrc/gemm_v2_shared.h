@@ -31,6 +31,7 @@ struct GemmV2Args {
   //           sum_k of the packed weight row n (what every x_k is actually multiplied with)
   float* rs_out; int rs_strips;
   const float* rn_mr; const float* rn_cs;
+  float* clamp_max;   // optional clamp watch word (common.h): the planes output's largest |value| beyond the format's range
   int stagger;   // > 0 (set by the launcher, see "slack stagger" there): estimated shader cycles of one tile period; workgroups that walk one tile fewer than the
                  // longest ones start late by a fraction of it (V2_SLACK_STAGGER below)
 #ifdef MMSA_DEBUG_KNOBS

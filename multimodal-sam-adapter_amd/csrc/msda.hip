@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void msda_kernel(
     const float* __restrict__ ref,   // FUSED: [Lq,2] reference points (x,y) in [0,1]
     float* __restrict__ out, long ldo,
     unsigned short* __restrict__ op, long ldop, int op_fmt,
-    int N, int S, int M, int D, int L, int Lq, int P) {
+    int N, int S, int M, int D, int L, int Lq, int P, float* __restrict__ clamp_max) {
   const int d4 = D >> 2;                        // lanes per (q, m) pair
   const int op_kpad = MMSA_PAD64(M * D);        // h8c output planes: fp16 values per row
   // 32-bit index arithmetic (N*Lq*M*d4 < 2^32, checked by the launcher): the four 64-bit div/mod of the first version
@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void msda_kernel(
   }
   if (out) *reinterpret_cast<float4*>(out + bq * ldo + (long)m * D + c) = acc;
   if (op) {   // operand planes for output_proj, either format
+    float cw_ = 0.f;   // clamp watch (common.h): a sample is a convex combination of value rows, which arrive as unbounded fp32
+    clamp_see(cw_, acc);
+    clamp_report(clamp_max, cw_, mmsa_clamp_limit(op_fmt));
     // D % 8 == 0: threads 2j / 2j+1 of a (query, head) group hold 8 consecutive channels: whole-line stores through the lane-pair exchange
     if ((D & 7) == 0) store_planes8_pair_any<1>(op, ldop, bq, op_kpad, m * D + (c & ~7), acc, op_fmt, (c >> 2) & 1, true);
     else store_planes4_any(op, ldop, bq, op_kpad, m * D + c, acc, op_fmt);
@@ -295,7 +298,7 @@ extern "C" int mmsa_ms_deform_attn_forward(const void* value, const int64_t* spa
   const int bs = msda_block(channels);
   hipLaunchKernelGGL(msda_kernel<false>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, (const float*)value, spatial_shapes,
                      level_start_index, (const float*)sampling_loc, (const float*)attn_weight, nullptr, 0L, nullptr, (float*)out,
-                     (long)num_heads * channels, nullptr, 0L, MMSA_FMT_B3, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point);
+                     (long)num_heads * channels, nullptr, 0L, MMSA_FMT_B3, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, nullptr);
   MMSA_CHECK_LAUNCH("ms_deform_attn_forward");
   return MMSA_OK;
 }
@@ -348,7 +351,7 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
                                const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
                                unsigned short* out_p, long ldop, int out_fmt,
                                int batch, int spatial_size, int num_heads, int channels, int num_levels,
-                               int num_query, int num_point, hipStream_t stream) {
+                               int num_query, int num_point, float* clamp_max, hipStream_t stream) {
   MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "msda_fused: bad output plane format %d", out_fmt);
   MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && ref_points && (out || out_p), "msda_fused: null pointer");
   MMSA_CHECK_ARG(!out_p || (ldop >= (out_fmt == MMSA_FMT_H8C ? 3L * MMSA_PAD64(num_heads * channels) : 2L * num_heads * channels) && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
@@ -364,7 +367,7 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
   const int bs = msda_block(channels);
   hipLaunchKernelGGL(msda_kernel<true>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, value, spatial_shapes,
                      level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, out_fmt, batch, spatial_size,
-                     num_heads, channels, num_levels, num_query, num_point);
+                     num_heads, channels, num_levels, num_query, num_point, clamp_max);
   MMSA_CHECK_LAUNCH("msda_fused");
   return MMSA_OK;
 }

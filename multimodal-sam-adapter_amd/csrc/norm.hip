@@ -16,8 +16,9 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b, float eps,
     float* __restrict__ y, long ldy, float* __restrict__ y2, long ldy2,
     unsigned short* __restrict__ yp, long ldp, int rows, int C,
-    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap, int plane_fmt) {
+    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap, int plane_fmt, float* __restrict__ clamp_max) {
   constexpr int LPR = 64 / RPW;                       // lanes per row
+  float cw_ = 0.f;                                    // clamp watch of the planes output (common.h)
   const int lane = threadIdx.x & (LPR - 1);
   // A wave (or half wave) walks rows slot, slot + nslots, ... with the NEXT row's loads in flight while the current row is
   // reduced and stored: one row per wave made every wave of the launch load, then reduce, then store in lockstep (read burst,
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
         o.z = (v[i].z - mean) * rstd * wv[i].z + bv[i].z;
         o.w = (v[i].w - mean) * rstd * wv[i].w + bv[i].w;
         if (yr) *reinterpret_cast<float4*>(yr + c) = o;
+        if (yp) clamp_see(cw_, o);
       }
       if (h8c) {
         if (pair16) h8c_store8_pair<1>(hr, c & ~7, o, lane & 1, in);
@@ -116,13 +118,14 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       }
     }
   }
+  if (yp) clamp_report(clamp_max, cw_, mmsa_clamp_limit(plane_fmt));
 }
 
 extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, const float* b, float eps,
                                    float* y, long ldy, float* y2, long ldy2,
                                    unsigned short* yp, long ldp, int rows, int C,
                                    int map_mode, int map_H, int map_W, int group_rows, long w_gstride, long y_gcol, int y_wrap,
-                                   int plane_fmt, hipStream_t stream) {
+                                   int plane_fmt, float* clamp_max, hipStream_t stream) {
   MMSA_CHECK_ARG(plane_fmt >= MMSA_FMT_B3 && plane_fmt <= MMSA_FMT_F3, "layernorm_rows: bad plane format %d", plane_fmt);
   MMSA_CHECK_ARG(!yp || plane_fmt != MMSA_FMT_H8C || (map_mode == 0 && group_rows == 0 && ldp >= 3L * MMSA_PAD64(C)),
                  "layernorm_rows: h8c planes are a plain [rows, C] output (no patchify / row groups), ldp = pair stride >= 3 * pad64(C)");
@@ -142,8 +145,8 @@ extern "C" int mmsa_layernorm_rows(const float* x, long ldx, const float* w, con
   const int ln_rows = MMSA_KNOB("MMSA_LN_ROWS", 0);
   const int per_slot = ln_rows > 0 ? ln_rows : (rows >= 8192 ? 4 : rows >= 4096 ? 2 : 1);
   dim3 grid(cdiv(rows, 4 * rpw * per_slot)), block(256);
-#define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt)
-  if (C <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<1, 2>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt);
+#define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_rows_kernel<NV, 1>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt, clamp_max)
+  if (C <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<1, 2>), grid, block, 0, stream, x, ldx, w, b, eps, y, ldy, y2, ldy2, yp, ldp, rows, C, map_mode, map_H, map_W, group_rows, w_gstride, y_gcol, y_wrap, plane_fmt, clamp_max);
   else if (C <= 256) LN_LAUNCH(1);
   else if (C <= 512) LN_LAUNCH(2);
   else if (C <= 1024) LN_LAUNCH(4);

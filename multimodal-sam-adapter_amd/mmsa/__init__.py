@@ -5,7 +5,7 @@ classes under the reference's names."""
 from . import lib  # noqa: F401  (raises if the HIP library is missing)
 from . import ops  # noqa: F401
 from . import inference  # noqa: F401  (encode_decode / slide_inference / argmax map of the reference's EncoderDecoder)
-from .backbone import SAMAdapterbimodalMixModNewInTwinConvNEW, SAMAdapterbimodalMixModNewInTwinConvNEWwithcp
+from .backbone import OperandRangeError, SAMAdapterbimodalMixModNewInTwinConvNEW, SAMAdapterbimodalMixModNewInTwinConvNEWwithcp
 from .head import SegformerHead
 from .chains import AttentionRangeError, Chains, Replay
 from .registry import BACKBONES, HEADS, build_backbone, build_head
@@ -29,4 +29,4 @@ if not _HAVE_MMSEG:     # local registry (no mmseg in the process): nothing to o
     register_head()
 
 __all__ = ["SegformerHead", "HEADS", "build_head", "register_head", "SAMAdapterbimodalMixModNewInTwinConvNEW", "SAMAdapterbimodalMixModNewInTwinConvNEWwithcp",
-           "BACKBONES", "build_backbone", "ops", "lib", "inference", "Chains", "Replay", "AttentionRangeError"]
+           "BACKBONES", "build_backbone", "ops", "lib", "inference", "Chains", "Replay", "AttentionRangeError", "OperandRangeError"]

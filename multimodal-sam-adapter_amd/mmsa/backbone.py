@@ -24,6 +24,10 @@ _VIT_DEFAULTS = dict(img_size=1024, patch_size=16, in_chans=3, embed_dim=1024, d
                      global_attn_indexes=[5, 11, 17, 23], pretrained_size=1024, fix=False)
 
 
+class OperandRangeError(RuntimeError):
+    """A forward converted a value beyond the range of an fp16-based operand format (the clamp watch word, include/mmsa.h): its outputs are invalid."""
+
+
 class Workspace:
     """Named, grow-only device buffers (stable addresses once warmed up -> HIP-graph capturable)."""
 
@@ -295,6 +299,15 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
 
     @torch.no_grad()
     def _pack(self, dev):
+        """Pre-pack the weights for `dev`.  The guard words of the model live here too: one logit word per ViT block (check_attention_guard) and, last, the
+        clamp watch word (include/mmsa.h "Clamp watch") -- weight planes that had to clamp a value report into it like every forward's activations do."""
+        guard = torch.zeros(self.cfg["depth"] + 1, device=dev)
+        with ops.clamp_watch(guard[self.cfg["depth"]:]):
+            pk = self._pack_impl(dev)
+        pk["attn_guard"] = guard
+        return pk
+
+    def _pack_impl(self, dev):
         cfg = self.cfg
         h8_sites = self._h8_sites()
         sd = self._pack_state_dict(dev)
@@ -573,7 +586,6 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             inv = sd[f"norm{i}.weight"] / torch.sqrt(sd[f"norm{i}.running_var"] + 1e-5)
             pk["bn"].append((inv.contiguous(), (sd[f"norm{i}.bias"] - sd[f"norm{i}.running_mean"] * inv).contiguous()))
         pk["pos_src"] = sd["pos_embed"]
-        pk["attn_guard"] = torch.zeros(cfg["depth"], device=dev)   # one logit guard word per ViT block (check_attention_guard)
         pk["geom"] = {}
         torch.cuda.synchronize(dev)
         return pk
@@ -654,11 +666,13 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         with torch.cuda.device(x.device):    # launches go to the current stream of the input's device
             x, B, H, W = self._prepare(x)
             guard = self.attention_guard == "sync" and not torch.cuda.is_current_stream_capturing()
-            for _ in range(self.cfg["depth"] + 1):
-                # ---- spatial prior module -> c1, c
-                c1, cbuf, Nc = self._cbufs(B, H, W)
-                c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
-                outs = self._vit(x, B, H, W, c1, cbuf, c1_ready)
+            depth = self.cfg["depth"]
+            for _ in range(depth + 1):
+                with ops.clamp_watch(self._packed["attn_guard"][depth:]):   # every plane-producing launch reports values beyond its format's range
+                    # ---- spatial prior module -> c1, c
+                    c1, cbuf, Nc = self._cbufs(B, H, W)
+                    c1_ready = self._spm(x, B, H, W, c1, cbuf, Nc)
+                    outs = self._vit(x, B, H, W, c1, cbuf, c1_ready)
                 # ---- attention logit guard: a block that ran fp16 attention beyond its range has been moved to bf16 hi/lo -> once more
                 if not guard or not self.check_attention_guard():
                     break
@@ -931,6 +945,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             return []
         if vals is None:
             vals = pk["attn_guard"].tolist()      # device -> host: waits for the work queued so far
+        depth = self.cfg["depth"]
+        if len(vals) > depth and vals[depth] > 0.0:
+            # clamp watch: some kernel converted a value beyond its operand format's range (h8 / h8c +-57344, f3 +-65504) -- the planes hold the clamped
+            # value, the result is not the reference's.  Nothing can be re-routed at run time (the formats are a pack-time choice): refuse.
+            pk["attn_guard"][depth:].zero_()
+            raise OperandRangeError(f"mmsa: a value of magnitude {vals[depth]:.6g} was clamped on its way into fp16-based operand planes (h8 / h8c hold |x| <= 57344, "
+                                    "f3 |x| <= 65504): the outputs since the last check are not the reference's.  (`h8_sites = ()` / `cnx_f16 = False` move the interaction, "
+                                    "up-conv and TwinConvNeXt GEMMs to bf16 hi/lo pairs with fp32's range; the ViT blocks' pair format is fp16-based either way.)")
         auto = self._attn_policy() == "auto"
         moved = []
         sd_dev = None     # the float parameters on the device, built once for all the blocks that move in this call

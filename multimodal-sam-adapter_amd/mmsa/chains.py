@@ -174,7 +174,16 @@ class Chains:
                     break
                 ev.synchronize()
             self._pending.pop(0)
-            moved = self.backbone.check_attention_guard(vals=host.tolist())
+            try:
+                moved = self.backbone.check_attention_guard(vals=host.tolist())
+            except RuntimeError:    # backbone.OperandRangeError: a value was clamped on its way into fp16-based planes -- nothing to re-route, the passes are invalid
+                self._bad.append((self._clean_upto + 1, self._seq))
+                self._clean_upto = self._seq
+                self._pool.append(host)
+                for _, _, h in self._pending:
+                    self._pool.append(h)
+                self._pending = []
+                raise
             self._pool.append(host)
             if moved:
                 self._bad.append((self._clean_upto + 1, self._seq))    # everything enqueued since the last clean inspection ran on the stale graphs
@@ -215,10 +224,15 @@ class Chains:
         passes since the last clean check were computed on fp16 attention beyond the threshold (their Replay.outputs() will raise), and the
         graphs are stale -- with `recapture` they are captured again here (same static input buffer), so the next replay() is valid."""
         torch.cuda.synchronize(self.x.device)
-        moved = self.backbone.check_attention_guard()
         for _, _, h in self._pending:
             self._pool.append(h)
         self._pending = []
+        try:
+            moved = self.backbone.check_attention_guard()
+        except RuntimeError:        # backbone.OperandRangeError (clamp watch): the passes since the last clean check are invalid
+            self._bad.append((self._clean_upto + 1, self._seq))
+            self._clean_upto = self._seq
+            raise
         if moved:
             self._bad.append((self._clean_upto + 1, self._seq))
         self._clean_upto = self._seq

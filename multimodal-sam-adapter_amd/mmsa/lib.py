@@ -40,21 +40,21 @@ SIGNATURES = {
     "mmsa_event_destroy": [P],
     "mmsa_ms_deform_attn_forward": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mmsa_ms_deform_attn_backward": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "mmsa_msda_fused": [P, P, P, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, P],
-    "mmsa_gemm_split3": [P, P, L, L, P, L, P, L, P, P, L, L, I, F, P, L, L, P, L, L, I, I, I, I, I, F, I, I, I, I, I, I, I, P, P, P, I, P],
+    "mmsa_msda_fused": [P, P, P, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, P, P],
+    "mmsa_gemm_split3": [P, P, L, L, P, L, P, L, P, P, L, L, I, F, P, L, L, P, L, L, I, I, I, I, I, F, I, I, I, I, I, I, I, P, P, P, I, P, P],
     "mmsa_convnext_mlp_fused": [P, L, L, P, L, P, L, P, P, P, P, L, L, I, I, I, I, I, P],
     "mmsa_rowstats_finalize": [P, I, I, I, F, P, P],
     "mmsa_zero_bytes": [P, ctypes.c_size_t, P],
-    "mmsa_split_planes": [P, L, I, I, I, P, I, P],
+    "mmsa_split_planes": [P, L, I, I, I, P, I, P, P],
     "mmsa_attention": [P, L, P, P, P, L, I, I, I, I, I, I, F, P],
     "mmsa_attention_planes": [P, L, P, P, P, L, I, I, I, I, I, I, F, I, I, P, P],
     "mmsa_relpos_bias": [P, L, P, P, P, I, I, I, I, I, I, P],
     "mmsa_relpos_bias_planes": [P, L, P, P, P, I, I, I, I, I, I, P],
-    "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, I, L, L, I, I, P],
+    "mmsa_layernorm_rows": [P, L, P, P, F, P, L, P, L, P, L, I, I, I, I, I, I, L, L, I, I, P, P],
     "mmsa_colstats": [P, L, L, P, I, I, I, P, I, P],
     "mmsa_ffrm_finalize": [P, I, I, I, F, F, P, P, P, P, P, P, P, P],
     "mmsa_lnhw_apply": [P, L, P, P, P, P, P, P, L, I, I, I, P],
-    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, I, P, P],
+    "mmsa_dwconv_nhwc": [P, L, L, P, P, P, L, L, P, L, L, I, I, I, I, I, I, I, I, P, P, P],
     "mmsa_dwpair_gate": [P, L, P, P, L, P, L, I, I, I, I, P],
     "mmsa_gconv_nhwc": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P],
     "mmsa_im2col_nchw": [P, I, I, I, I, I, I, I, P, I, P],

@@ -14,6 +14,8 @@ ACT = {"none": 0, "gelu": 1, "relu": 2, "relu6": 3, "hswish": 4, "sigmoid": 5}
 # When set to a list, every gemm() launch is bracketed by HIP events recorded on the launch stream and
 # (flops, start, stop) is appended; bench.py uses this for the roofline of the dominant kernel.
 GEMM_PROFILE = None
+CLAMP_WATCH = None   # a 1-element fp32 device tensor: the clamp watch word handed to every plane-producing launch (include/mmsa.h "Clamp watch"); the backbone
+                     # sets it around its forward (clamp_watch below) -- None = no watch
 GEMM_MAX_GRID = 0    # > 0: cap on the persistent workgroups of every gemm() launch (mmsa.chains gives each concurrent chain its share of the CUs)
 GEMM_FLAVOUR = int(os.environ.get("MMSA_GEMM_FLAVOUR", "0"))     # 0: workgroup shape chosen by the library; 4 / 8 force the 128- / 256-row form of the LDS-DMA GEMM (tests, A/B runs; bit-identical results)
 GEMM_SHAPES = None   # optional parallel list of (m, n, k, batch, act, has_resid, outputs) per profiled launch (tools/gemm_shapes.py)
@@ -44,6 +46,28 @@ def _stream():
     """The current stream of the current device.  Every entry point runs under `torch.cuda.device(tensor.device)` (the module
     forwards set it) and `_chk` refuses tensors of another device, so a launch never goes to device A's stream with device B's memory."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _clamp_ptr():
+    """Device address of the clamp watch word of the forward in progress (None outside one): include/mmsa.h "Clamp watch"."""
+    return CLAMP_WATCH.data_ptr() if CLAMP_WATCH is not None else None
+
+
+class clamp_watch:
+    """with ops.clamp_watch(word): every plane-producing launch inside reports values it had to clamp into `word` (a 1-element fp32 device tensor)."""
+
+    def __init__(self, word):
+        self.word = word
+
+    def __enter__(self):
+        global CLAMP_WATCH
+        self.keep, CLAMP_WATCH = CLAMP_WATCH, self.word
+        return self
+
+    def __exit__(self, *exc):
+        global CLAMP_WATCH
+        CLAMP_WATCH = self.keep
+        return False
 
 
 def _chk(t, dtype=torch.float32, name="tensor"):
@@ -210,7 +234,7 @@ def split_planes(w2d, kpad=None, out=None, fmt=FMT_B3, weight=False):
         kind = 3
     else:
         kind = 0 if out.fmt == FMT_B3 else 4 if out.fmt == FMT_F3 else (2 if out.weight else 1)
-    lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), kind, _stream())
+    lib.call("mmsa_split_planes", p, ld, n, k, kpad, out.p.data_ptr(), kind, _clamp_ptr(), _stream())
     return out
 
 
@@ -255,7 +279,7 @@ def gemm(a, w, out=None, bias=None, act="none", alpha=1.0, colscale=None, resid=
              _chk(bias, name="bias"), stride_bias, _chk(colscale, name="colscale"), pr, ldr, stride_r, resid_mod, beta,
              pc, ldc, stride_c, pcp, ldcp, stride_cp, m, w.n, w.kpad, batch, ACT[act], alpha,
              1 if pixel_shuffle else 0, ps[0], ps[1], ps[2], fmt, cp_format(out_planes), GEMM_MAX_GRID,
-             _chk(rowstats_out), _chk(row_norm[0]) if row_norm else None, _chk(row_norm[1]) if row_norm else None, GEMM_FLAVOUR, _stream())
+             _chk(rowstats_out), _chk(row_norm[0]) if row_norm else None, _chk(row_norm[1]) if row_norm else None, GEMM_FLAVOUR, _clamp_ptr(), _stream())
     if prof is not None:
         lib.call("mmsa_event_record", e1, _stream())
         ob = 3.0 if fmt == FMT_H8C else 4.0          # bytes per operand element (h8c planes: 3)
@@ -324,7 +348,7 @@ def layernorm(x, w, b, eps, out=None, out2=None, patchify=None, out_planes=None,
     mh, mw = patchify or (0, 0)
     lib.call("mmsa_layernorm_rows", px, ldx, _chk(w), _chk(b), eps, py, ldy, p2, ld2, pp, ldp, rows, c,
              1 if patchify else 0, mh, mw, group_rows, w_gstride, y_gcol, 1 if y_wrap else 0,
-             out_planes.fmt if out_planes is not None else FMT_B3, _stream())
+             out_planes.fmt if out_planes is not None else FMT_B3, _clamp_ptr(), _stream())
     return out if out is not None else out_planes
 
 
@@ -383,7 +407,7 @@ def msda_fused(value2d, spatial_shapes, level_start_index, raw, ref_points, out,
         pp, _, _, ldp = out_planes.mat("out planes")
     lib.call("mmsa_msda_fused", pv, _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64), pr, ldraw,
              _chk(ref_points), po, ldo, pp, ldp, out_planes.fmt if out_planes is not None else FMT_B3,
-             batch, spatial, heads, d, levels, lq, points, _stream())
+             batch, spatial, heads, d, levels, lq, points, _clamp_ptr(), _stream())
     return out if out is not None else out_planes
 
 
@@ -543,7 +567,7 @@ def dwconv(x, w, bias, out, b, h, wd, k, act="none", xstride_b=None, ystride_b=N
     ys = h * wd * ldo if ystride_b is None else ystride_b
     ps = h * wd * ldp if pstride_b is None else pstride_b
     lib.call("mmsa_dwconv_nhwc", px, ldx, xs, _chk(w), _chk(bias), po, ldo, ys, pp, ldp, ps, out_planes.fmt if out_planes is not None else FMT_B3,
-             b, h, wd, c, k, ACT[act], imgs_per_group, _chk(rowstats_out), _stream())
+             b, h, wd, c, k, ACT[act], imgs_per_group, _chk(rowstats_out), _clamp_ptr(), _stream())
     return out if out is not None else out_planes
 
 

@@ -91,7 +91,7 @@ def test_convffn_hidden_width_512_keeps_a_format_its_producer_writes():
     orc.load_state_dict(sd)
     m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **kw))
     m.load_state_dict(sd, strict=True)
-    x = make_input(dict(kwargs=kw, in_seed=42))
+    x = make_input(dict(kwargs=kw, in_seed=42), batch=1)
     fs, _ = m(x.to(DEV))
     ext = m._packed["inter"][0]["ext"][0]
     assert ext["fc2"].kpad == 512 and ext["fc2"].fmt == ops.FMT_H8, "fc2 (K = 512) stays on h8 line planes"
@@ -550,3 +550,69 @@ def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_di
     fs3, _ = m3(x.to(DEV))
     assert m3.check_attention_guard() == []
     assert all(torch.equal(a, b) for a, b in zip(fs3, fs))
+
+
+def test_clamp_flag_raises():
+    """the fp16-based operand formats clamp what they cannot hold (h8 / h8c: |x| > 57344, f3: |x| > 65504) -- silently until round 5.  Every
+    kernel that converts unbounded fp32 values to planes now folds the largest |value| it had to clamp into the clamp watch word (include/mmsa.h): at the
+    operator level (split_planes, GEMM epilogue, LayerNorm, MSDA gather, depthwise conv; bf16 hi/lo planes never report) and in the model, where a forward
+    that clamped raises instead of returning tensors that are not the reference's."""
+    import mmsa
+    from mmsa import ops
+    word = torch.zeros(1, device=DEV)
+    big = torch.zeros(64, 64, device=DEV)
+    big[3, 5] = -1.0e5
+    for fmt, hit in ((ops.FMT_B3, False), (ops.FMT_H8, True), (ops.FMT_H8C, True), (ops.FMT_F3, True)):
+        word.zero_()
+        with ops.clamp_watch(word):
+            ops.split_planes(big, fmt=fmt)
+            ops.split_planes(big * 0.5, fmt=fmt)            # 5e4: inside every range
+        assert word.item() == (1.0e5 if hit else 0.0), (fmt, word.item())
+    # GEMM epilogue (register-resident and staged paths), LayerNorm, depthwise conv, MSDA gather: a planes output beyond the range reports, fp32 outputs do not
+    a = ops.split_planes(torch.randn(512, 128, device=DEV), fmt=ops.FMT_H8C)
+    w = ops.split_planes(torch.randn(256, 128, device=DEV) / 11.0, fmt=ops.FMT_H8C)
+    bias = torch.zeros(256, device=DEV)
+    bias[7] = 9.0e4
+    for rows in (512, 200):        # interior tiles (register epilogue) / a ragged tile (staged epilogue)
+        word.zero_()
+        with ops.clamp_watch(word):
+            ops.gemm(a, w, torch.empty(rows, 256, device=DEV), bias=bias, m=rows)
+            assert word.item() == 0.0
+            ops.gemm(a, w, bias=bias, m=rows, out_planes=ops.alloc_planes(rows, 256, DEV, fmt=ops.FMT_B3))
+            assert word.item() == 0.0
+            ops.gemm(a, w, bias=bias, m=rows, out_planes=ops.alloc_planes(rows, 256, DEV, fmt=ops.FMT_H8C))
+        assert 8.9e4 < word.item() < 9.1e4, (rows, word.item())
+    x = torch.randn(96, 256, device=DEV)
+    lw = torch.ones(256, device=DEV)
+    lw[0] = 3.0e5
+    word.zero_()
+    with ops.clamp_watch(word):
+        ops.layernorm(x, lw, torch.zeros(256, device=DEV), 1e-6, out_planes=ops.alloc_planes(96, 256, DEV, fmt=ops.FMT_F3))
+    assert word.item() > 65504.0
+    # the model: a lin1 bias of 1e5 in one ViT block makes GELU hand 1e5 to the h8 / f3 planes of the MLP's hidden activation
+    cfg, orc, m0 = _build("tiny256")
+    m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    sd = {k: v.clone() for k, v in m0.state_dict().items()}
+    m.load_state_dict(sd)
+    xin = make_input(cfg).to(DEV)
+    fs, _ = m(xin)                                       # in range: runs
+    sd["blocks.2.mlp.lin1.bias"][5] = 1.0e5
+    m.load_state_dict(sd)
+    m.invalidate()
+    with pytest.raises(mmsa.OperandRangeError, match="clamped"):
+        m(xin)
+    sd["blocks.2.mlp.lin1.bias"][5] = 0.5                # back in range: the word was zeroed by the refusal, the model runs again
+    m.load_state_dict(sd)
+    fs2, _ = m(xin)
+    assert all(torch.isfinite(f).all() for f in fs2)
+    # a graph owner sees it through the same channel: the pass is refused by Replay.outputs()
+    sd["blocks.2.mlp.lin1.bias"][5] = 0.5
+    ch = mmsa.Chains(m, None, n=1).capture(xin)
+    assert ch.replay().outputs() is ch.feats
+    m.attention_guard_words()[cfg["kwargs"]["depth"]] = 7.0e4    # "a kernel of the next pass clamped a value of 7e4"
+    rp = ch.replay()
+    with pytest.raises(mmsa.OperandRangeError):
+        rp.outputs()
+    with pytest.raises(RuntimeError):
+        rp.outputs()
+    assert ch.replay().outputs() is ch.feats
