@@ -356,12 +356,21 @@ __device__ __forceinline__ void store_planes4_any(unsigned short* base, long ld,
 __device__ __forceinline__ float mmsa_clamp_limit(int fmt) {
   return (fmt == MMSA_FMT_H8 || fmt == MMSA_FMT_H8C) ? MMSA_H8_MAX : fmt == MMSA_FMT_F3 ? MMSA_F3_MAX : 3.0e38f;
 }
+#ifndef MMSA_CW_LEG
+#define MMSA_CW_LEG 1
+#endif
+#ifndef MMSA_CW_REGS
+#define MMSA_CW_REGS 1
+#endif
+#ifndef MMSA_CLAMP_WATCH
+#define MMSA_CLAMP_WATCH 1   // 0 (A/B timing builds): the watch compiled out
+#endif
 __device__ __forceinline__ void clamp_see(float& m, const float4 v) {
-  m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  if (MMSA_CLAMP_WATCH) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
-__device__ __forceinline__ void clamp_see1(float& m, float x) { m = fmaxf(m, fabsf(x)); }
+__device__ __forceinline__ void clamp_see1(float& m, float x) { if (MMSA_CLAMP_WATCH) m = fmaxf(m, fabsf(x)); }
 __device__ __forceinline__ void clamp_report(float* word, float m, float limit) {
-  if (word != nullptr && m > limit) atomicMax(reinterpret_cast<int*>(word), __float_as_int(m));
+  if (MMSA_CLAMP_WATCH && word != nullptr && m > limit) atomicMax(reinterpret_cast<int*>(word), __float_as_int(m));
 }
 
 // activation codes shared by the GEMM epilogue and the conv kernels

@@ -950,7 +950,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             # clamp watch: some kernel converted a value beyond its operand format's range (h8 / h8c +-57344, f3 +-65504) -- the planes hold the clamped
             # value, the result is not the reference's.  Nothing can be re-routed at run time (the formats are a pack-time choice): refuse.
             pk["attn_guard"][depth:].zero_()
-            raise OperandRangeError(f"mmsa: a value of magnitude {vals[depth]:.6g} was clamped on its way into fp16-based operand planes (h8 / h8c hold |x| <= 57344, "
+            raise OperandRangeError(f"mmsa: a value of magnitude >= {vals[depth]:.6g} was clamped on its way into fp16-based operand planes (h8 / h8c hold |x| <= 57344, "
                                     "f3 |x| <= 65504): the outputs since the last check are not the reference's.  (`h8_sites = ()` / `cnx_f16 = False` move the interaction, "
                                     "up-conv and TwinConvNeXt GEMMs to bf16 hi/lo pairs with fp32's range; the ViT blocks' pair format is fp16-based either way.)")
         auto = self._attn_policy() == "auto"

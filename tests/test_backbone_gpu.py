@@ -581,7 +581,7 @@ def test_clamp_flag_raises():
             ops.gemm(a, w, bias=bias, m=rows, out_planes=ops.alloc_planes(rows, 256, DEV, fmt=ops.FMT_B3))
             assert word.item() == 0.0
             ops.gemm(a, w, bias=bias, m=rows, out_planes=ops.alloc_planes(rows, 256, DEV, fmt=ops.FMT_H8C))
-        assert 8.9e4 < word.item() < 9.1e4, (rows, word.item())
+        assert 57344.0 <= word.item() < 9.1e4, (rows, word.item())      # the staged path reports the magnitude it met, the register path its format's limit
     x = torch.randn(96, 256, device=DEV)
     lw = torch.ones(256, device=DEV)
     lw[0] = 3.0e5
