@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="ATTR=VALUE",
+                    help="set an attribute of the backbone before its first forward (A/B runs: --set fold_adapter_ln=False --set 'h8_sites=(\"vit\",)'); the value is a Python literal")
     ap.add_argument("--no-extras", action="store_true", help="skip the eager_plugin_api / config4_frame / vith1024 lines of the default single-GPU run")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed graph-vs-eager / golden-probe checks")
     ap.add_argument("--default-init", action="store_true", help="A/B aid: default-init weights instead of the seeded live generator")
@@ -224,6 +226,11 @@ def main():
     model = None if STUB else mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
     if model is not None and not a.default_init:
         model.load_state_dict(seeded_state_dict(model, seed=cfg["seed"]))
+    if model is not None:
+        import ast
+        for kv in a.set:          # explicit switches of an A/B run (tools/ab_env.py): attributes, not environment variables
+            k_, _, v_ = kv.partition("=")
+            setattr(model, k_, ast.literal_eval(v_))
     x = make_input(cfg if not STUB else CONFIGS["tiny256"], batch=a.batch, seed=1234 + rank).to(dev)
 
     head = None

@@ -555,9 +555,12 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   // LayerNorm fold (mmsa_gemm_next_extras): both forms run on the unrolled fast epilogue of 128-column tiles with whole 64-column strips
   MMSA_CHECK_ARG(!rs_out || (C && out_mode == 0 && resid_mod <= 0 && act == ACT_NONE && (N & 63) == 0 && (ldc & 3) == 0 && (!resid || (ldr & 3) == 0) && (!Cp || (ldcp & 3) == 0)),
                  "gemm(v2): row statistics need a plain fp32 output, no activation, N %% 64 == 0 (N=%d)", N);
-  MMSA_CHECK_ARG(!rn_mr || (rn_cs && Cp && !C && !resid && out_mode == 0 && resid_mod <= 0 && (N & 127) == 0 && (act == ACT_NONE || act == ACT_GELU || act == ACT_RELU) &&
-                            ((((uintptr_t)bias) | ((uintptr_t)colscale) | ((uintptr_t)rn_cs)) & 15) == 0 && (strideBias & 3) == 0),
-                 "gemm(v2): the row-normalising epilogue needs a planes-only output, N %% 128 == 0 (N=%d), 16-byte aligned column vectors", N);
+  // row-normalising epilogue: a planes-only output (any M: ragged tiles run the staged form), or -- round 5, the adapter tokens' LayerNorm folded into value / offset
+  // projections and fc1 -- an fp32-only output of whole tiles (M %% 256 == 0: only the register-resident "rows" epilogue has that form)
+  MMSA_CHECK_ARG(!rn_mr || (rn_cs && !resid && out_mode == 0 && resid_mod <= 0 && (N & 127) == 0 && ((((uintptr_t)bias) | ((uintptr_t)colscale) | ((uintptr_t)rn_cs)) & 15) == 0 && (strideBias & 3) == 0 &&
+                            ((Cp && !C && (act == ACT_NONE || act == ACT_GELU || act == ACT_RELU)) ||
+                             (C && !Cp && act == ACT_NONE && (M & 255) == 0 && !colscale && alpha == 1.0f && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0))),
+                 "gemm(v2): the row-normalising epilogue needs N %% 128 == 0 (N=%d), 16-byte aligned column vectors and either a planes-only output or a plain fp32 output with M %% 256 == 0 (M=%d), no activation / scale", N, M);
   a.rs_out = rs_out; a.rs_strips = N >> 6; a.rn_mr = rn_mr; a.rn_cs = rn_cs;
   a.Ap = Ap; a.lda = lda; a.strideA = strideA;
   a.Wp = Wp; a.strideW = strideW;

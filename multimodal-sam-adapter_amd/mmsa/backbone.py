@@ -539,6 +539,23 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         def fold_ln(w2d, bias, lnw, lnb):      # -> weight and bias of the projection applied to the un-affine normalised tokens
             return (w2d * lnw[None, :]).contiguous(), (bias + w2d @ lnb).contiguous()
 
+        # Round 5: the adapter tokens' LayerNorms inside their consumer GEMMs (`fold_adapter_ln`; the ViT blocks' fold of round 3 applied to AM:490-511,525-542).
+        # Every LayerNorm over c -- the shared injector feat_norm / extractor query_norm, the extra extractors' query_norm, every ffn_norm -- follows a GEMM that
+        # has just written c (ConvFFN fc2, the extractor's output projection).  That producer also writes c's RAW operand planes and per-row strip sums;
+        # mmsa_rowstats_finalize turns them into (mean, rstd); the consumers (value / offsets projections, fc1) run on W o w with the row-normalising epilogue.
+        # Twelve passes over the largest token matrix of the path (21504 x 1024 per image: 88 MB read + 66 MB planes written each) go away.  Needs the affine
+        # parts folded into the weights (share_c_norm) and whole 128-column tiles at every consumer; tools/lnfold_adapter_study.py: no measurable error.
+        def colsum(pl):   # column sums of packed planes as the kernel reads them (what every x_k is actually multiplied with)
+            return ops.planes_to_float(pl, cols=pl.k)[: pl.n].double().sum(1).float().contiguous()
+        hid_c = int(D * cfg["cffn_ratio"]) if cfg["with_cffn"] else 128
+        # OPT-IN (`model.fold_adapter_ln = True`): built, pinned against the oracle (tests/test_backbone_gpu.py::test_adapter_layernorm_fold_against_the_oracle), and
+        # measured step-NEUTRAL at ViT-L 1024^2 (profiles/r05_adapter_ln_fold.txt: 31.12 / 31.39 ms without, 31.41 / 31.34 ms with; golden probes 0.94e-4 ->
+        # 1.15e-4): the eleven passes it deletes cost what the producers' extra plane + strip-sum stores and the consumers' row loads cost -- by bytes the fold
+        # saves only the read of c (176 MB per pass at batch 2), 0.3 ms at best.
+        fold_rn = (share_c and bool(getattr(self, "fold_adapter_ln", False)) and "inter" in h8_sites and D % 64 == 0
+                   and int(D * cfg["deform_ratio"]) % 128 == 0 and hid_c % 128 == 0)
+        pk["fold_adapter_ln"] = fold_rn
+
         def pack_msda(b, fold_val=None, fold_oa=None):
             w = torch.cat([sd[b + "sampling_offsets.weight"], sd[b + "attention_weights.weight"]], 0)
             bb = torch.cat([sd[b + "sampling_offsets.bias"], sd[b + "attention_weights.bias"]], 0)
@@ -547,21 +564,41 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 w, bb = fold_ln(w, bb, *fold_oa)
             if fold_val is not None:
                 wv, bv_ = fold_ln(wv, bv_, *fold_val)
-            return dict(oa=iplanes(w), oa_b=bb.contiguous(), val=iplanes(wv), val_b=bv_,
-                        out=iplanes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
+            # the offsets + attention-weights projection has 3 * heads * levels * points output columns (192 / 576 at ViT-L): padded with zero rows to whole
+            # 128-column GEMM tiles -- the same number of tiles, none of them ragged, so that every tile of the launch takes the register-resident epilogue
+            # (a launch that runs both epilogues no longer fits the instruction cache: profiles/r05_epilogue_regs.txt).  The deformable-attention kernel
+            # reads the first 3 * heads * levels * points columns of a row (ldraw = the padded width).
+            n_oa = w.shape[0]
+            if n_oa % 128:
+                npad = 128 - n_oa % 128
+                w = torch.cat([w, w.new_zeros(npad, w.shape[1])], 0)
+                bb = torch.cat([bb, bb.new_zeros(npad)], 0)
+            mp = dict(oa=iplanes(w), oa_b=bb.contiguous(), val=iplanes(wv), val_b=bv_,
+                      out=iplanes(sd[b + "output_proj.weight"]), out_b=sd[b + "output_proj.bias"])
+            if fold_rn:
+                if fold_oa is not None:
+                    mp["oa_cs"] = colsum(mp["oa"])
+                if fold_val is not None:
+                    mp["val_cs"] = colsum(mp["val"])
+            return mp
 
         def pack_extractor(b, fold_c=False):
             ep = dict(qnw=sd[b + "query_norm.weight"], qnb=sd[b + "query_norm.bias"], fnw=sd[b + "feat_norm.weight"],
-                      fnb=sd[b + "feat_norm.bias"], fold_c=fold_c, cffn=self.cfg["with_cffn"],
+                      fnb=sd[b + "feat_norm.bias"], fold_c=fold_c, first=False, cffn=self.cfg["with_cffn"],
                       attn=pack_msda(b + "attn.", fold_oa=(sd[b + "query_norm.weight"], sd[b + "query_norm.bias"]) if fold_c else None))
             if self.cfg["with_cffn"]:   # AM:485-488, 499-500
                 dw = sd[b + "ffn.dwconv.dwconv.weight"]
-                ep.update(fc1=iplanes(sd[b + "ffn.fc1.weight"]), fc1_b=sd[b + "ffn.fc1.bias"],
+                fc1_w, fc1_bias = sd[b + "ffn.fc1.weight"], sd[b + "ffn.fc1.bias"]
+                if fold_c:   # ffn_norm folded into fc1 (its input is then the un-affine normalised c, or raw c + the row-normalising epilogue)
+                    fc1_w, fc1_bias = fold_ln(fc1_w, fc1_bias, sd[b + "ffn_norm.weight"], sd[b + "ffn_norm.bias"])
+                ep.update(fc1=iplanes(fc1_w), fc1_b=fc1_bias,
                           dw=dw.reshape(dw.shape[0], 9).t().contiguous(), dw_b=sd[b + "ffn.dwconv.dwconv.bias"],
                           # fc2's A operand is written by the 3 x 3 depthwise conv (mmsa_dwconv_nhwc), which emits bf16 hi/lo and h8 LINE planes only:
                           # a hidden width >= 512 (cffn_ratio 0.5 at embed_dim 1024; the reference's configs stay <= 320) must not pick h8c here
                           fc2=iplanes(sd[b + "ffn.fc2.weight"], h8c_ok=False), fc2_b=sd[b + "ffn.fc2.bias"],
                           ffw=sd[b + "ffn_norm.weight"], ffb=sd[b + "ffn_norm.bias"])
+                if fold_rn and fold_c:
+                    ep["fc1_cs"] = colsum(ep["fc1"])
             return ep
 
         pk["inter"] = []
@@ -573,8 +610,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                                fnb=sd[b + "injector.feat_norm.bias"], fold_c=share_c,
                                attn=pack_msda(b + "injector.attn.", fold_val=(sd[b + "injector.feat_norm.weight"], sd[b + "injector.feat_norm.bias"]) if share_c else None)),
                       ext=[pack_extractor(b + "extractor.", fold_c=share_c)])
+            it["ext"][0]["first"] = True     # the extractor that shares the injector's un-affine normalised c (share_c_norm) when nothing is folded further
             if i == n_int - 1 and self.cfg["use_extra_extractor"]:   # BK:91-92
-                it["ext"] += [pack_extractor(b + "extra_extractors.0."), pack_extractor(b + "extra_extractors.1.")]
+                it["ext"] += [pack_extractor(b + "extra_extractors.0.", fold_c=share_c), pack_extractor(b + "extra_extractors.1.", fold_c=share_c)]
             it["inj"]["first_block"] = self.interaction_indexes[i][0]   # whose qkv GEMM reads the stream planes the injector writes (LayerNorm fold)
             pk["inter"].append(it)
         # --- tail: ConvTranspose2d(D,D,2,2) weight [Cin, Cout, 2, 2] -> rows (i,j,co), K = ci  (BK:55,324)
@@ -769,16 +807,19 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             taps["x_in"], taps["c_in"] = xs[0].clone(), cbuf[:B * Nc].clone()
 
         # ---- interactions (AM:567-581)
+        self._cfold = None     # adapter-token LayerNorm fold: no producer GEMM has written c yet (the first interaction normalises c with a LayerNorm pass)
+        n_inter = len(self.interaction_indexes)
         for i, idx in enumerate(self.interaction_indexes):
             it = pk["inter"][i]
             self._injector(it["inj"], xs[i], xs[i + 1], cbuf, geo, B, T, Nc)   # (with the LayerNorm fold: also the producer of block idx[0]'s stream planes)
             for bi in range(idx[0], idx[-1] + 1):
                 self._block(pk["blocks"][bi], geo["rel"][bi], xs[i + 1], B, Hp, Wp, geo["relg"][bi],
                             next_fmt=pk["blocks"][bi + 1]["qkv"].fmt if bi < idx[-1] else None)
-            for ex in it["ext"]:
-                self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W)
+            for j, ex in enumerate(it["ext"]):
+                self._extractor(ex, cbuf, xs[i + 1], geo, B, T, Nc, H, W, last=(i == n_inter - 1 and j == len(it["ext"]) - 1))
             if taps is not None:
                 taps[f"x{i}"], taps[f"c{i}"] = xs[i + 1].clone(), cbuf[:B * Nc].clone()
+        self._cfold = None
 
         # ---- tail (BK:316-337)
         if c1_ready is not None:
@@ -995,58 +1036,117 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         return [i for i, m in enumerate(after) if m == "b3" and (before is None or before[i] != "b3")]
 
     # ------------------------------------------------------------------ MSDeformAttn (ops/modules/ms_deform_attn.py:83-130)
-    def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None, stream_out=None):
+    def _msda(self, ap, qn, fn, resid, out, ss, lsi, ref, B, Lq, S, L, colscale=None, stream_out=None, q_rn=None, f_rn=None):
+        """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:83-130) on normalised query / feature planes `qn` / `fn` -- or, with `q_rn` / `f_rn` =
+        (mean_rstd, colsum), on the RAW tokens' planes with the LayerNorm applied by the projection's row-normalising epilogue.  `stream_out` =
+        (planes, strip sums): the output projection also writes its result as operand planes + per-row strip sums (the producer half of a LayerNorm fold)."""
         ws, cfg = self._ws, self.cfg
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
         dv = ap["val"].n
         val = ws.get("msda_val", B * S, dv)
-        ops.gemm(fn, ap["val"], val, bias=ap["val_b"])
+        ops.gemm(fn, ap["val"], val, bias=ap["val_b"], row_norm=f_rn)
         raw = ws.get("msda_raw", B * Lq, ap["oa"].n)
-        ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"])
+        ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"], row_norm=q_rn)
         samp = ws.planes("msda_s", B * Lq, dv, fmt=ap["out"].fmt)
         ops.msda_fused(val, ss, lsi, raw, ref, None, B, S, M, dv // M, L, Lq, Pn, out_planes=samp)
-        if stream_out is not None:   # the injector's output projection writes the ViT stream: also its planes and row sums (LayerNorm fold)
+        if stream_out is not None:
             ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale, out_planes=stream_out[0], rowstats_out=stream_out[1])
         else:
             ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale)
 
+    # Adapter-token LayerNorm fold (round 5, `_pack`: fold_adapter_ln).  `_cfold` = the state of one forward: "planes" hold the RAW operand planes of the
+    # current c and "mr" its per-row (mean, rstd) -- valid from the first GEMM that writes c (an extractor's output projection or fc2) until the next one.
+    def _c_fold_on(self, rows):
+        """The fold runs when it was packed and the token rows fill whole 256-row GEMM tiles (the row-normalising epilogue on an fp32 output has no ragged form:
+        other sizes run the same folded weights behind un-affine LayerNorm passes)."""
+        return bool(self._packed.get("fold_adapter_ln")) and rows % 256 == 0
+
+    def _c_buffers(self, rows, fmt):
+        D = self.cfg["embed_dim"]
+        return self._ws.planes("inj_fn", rows, D, fmt=fmt), self._ws.get("c_rs", rows, 2 * (D // 64)), self._ws.get("c_mr", rows, 2)
+
+    def _c_produced(self, rows, fmt):
+        """Called right after a GEMM wrote c together with its planes and strip sums: finalise the row statistics, mark the planes current."""
+        cp, crs, cmr = self._c_buffers(rows, fmt)
+        ops.rowstats_finalize(crs, rows, self.cfg["embed_dim"], 1e-6, cmr)
+        self._cfold = dict(planes=cp, mr=cmr)
+
     def _injector(self, ip, x_in, x_out, c, geo, B, T, Nc):  # AM:525-542
         ws, D = self._ws, self.cfg["embed_dim"]
         qn = ws.planes("inj_qn", B * T, D, fmt=ip["attn"]["oa"].fmt)
-        fn = ws.planes("inj_fn", B * Nc, D, fmt=ip["attn"]["val"].fmt)
         ops.layernorm(x_in, ip["qnw"], ip["qnb"], 1e-6, out_planes=qn)
-        if ip["fold_c"]:   # chat = (c - mean) * rstd: feat_norm's affine part lives in value_proj's packed weight; the extractor reuses `fn`
-            pk = self._packed
-            ops.layernorm(c, pk["ln_one"], pk["ln_zero"], 1e-6, out_planes=fn)
+        st = self._cfold
+        f_rn = None
+        if st is not None and "val_cs" in ip["attn"]:      # feat_norm inside value_proj: raw planes of c + its row statistics, from c's last producer
+            fn, f_rn = st["planes"], (st["mr"], ip["attn"]["val_cs"])
         else:
-            ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
+            fn = ws.planes("inj_fn", B * Nc, D, fmt=ip["attn"]["val"].fmt)
+            if ip["fold_c"]:   # chat = (c - mean) * rstd: feat_norm's affine part lives in value_proj's packed weight; the extractor reuses `fn`
+                pk = self._packed
+                ops.layernorm(c, pk["ln_one"], pk["ln_zero"], 1e-6, out_planes=fn)
+            else:
+                ops.layernorm(c, ip["fnw"], ip["fnb"], 1e-6, out_planes=fn)
         self._msda(ip["attn"], qn, fn, x_in, x_out, geo["ss1"], geo["lsi1"], geo["ref1"], B, T, Nc, 3, colscale=ip["gamma"],
                    stream_out=(self._stream_planes(B * T, self._packed["blocks"][ip["first_block"]]["qkv"].fmt)
-                               if self._packed["fold_ln"] and B * T >= 128 else None))
+                               if self._packed["fold_ln"] and B * T >= 128 else None), f_rn=f_rn)
 
-    def _extractor(self, ep, c, x, geo, B, T, Nc, H, W):  # AM:490-511, ConvFFN AM:446-471
+    def _extractor(self, ep, c, x, geo, B, T, Nc, H, W, last=False):  # AM:490-511, ConvFFN AM:446-471
+        """`last`: nothing reads c's operand planes after this extractor (the tail takes fp32): its fc2 writes none."""
         ws, D = self._ws, self.cfg["embed_dim"]
-        qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["attn"]["oa"].fmt)
+        pk = self._packed
+        rows = B * Nc
+        fold = self._c_fold_on(rows) and ep["fold_c"]
+        cfmt = ep["attn"]["oa"].fmt
+        st = self._cfold
+        q_rn = None
+        if fold and st is not None and "oa_cs" in ep["attn"]:   # query_norm inside the offsets / attention-weights projection
+            qn, q_rn = st["planes"], (st["mr"], ep["attn"]["oa_cs"])
+        else:
+            qn = ws.planes("inj_fn", rows, D, fmt=cfmt)
+            if not (ep["fold_c"] and ep["first"]):   # else: `inj_fn` still holds chat of this very c, written by the interaction's injector (nothing in between touches c or the buffer)
+                if ep["fold_c"]:
+                    ops.layernorm(c, pk["ln_one"], pk["ln_zero"], 1e-6, out_planes=qn)
+                else:
+                    ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
         fn = ws.planes("inj_qn", B * T, D, fmt=ep["attn"]["val"].fmt)
-        if not ep["fold_c"]:   # else: `inj_fn` still holds chat of this very c, written by the interaction's injector (nothing in between touches c or the buffer)
-            ops.layernorm(c, ep["qnw"], ep["qnb"], 1e-6, out_planes=qn)
         ops.layernorm(x, ep["fnw"], ep["fnb"], 1e-6, out_planes=fn)
-        self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1)
+        produce = fold and (ep["cffn"] or not last)       # this extractor's output projection is followed by a consumer of LN(c)
+        if produce:
+            cp, crs, _ = self._c_buffers(rows, cfmt)
+            self._cfold = None                             # (the planes are overwritten by the output projection below: q_rn's operand is read before, same stream)
+            self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1, stream_out=(cp, crs), q_rn=q_rn)
+            self._c_produced(rows, cfmt)
+        else:
+            self._cfold = None
+            self._msda(ep["attn"], qn, fn, c, c, geo["ss2"], geo["lsi2"], geo["ref2"], B, Nc, T, 1, q_rn=q_rn)
         if not ep["cffn"]:   # AM:499-500
             return
-        qn = ws.planes("inj_fn", B * Nc, D, fmt=ep["fc1"].fmt)
-        ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, out_planes=qn)
         hid = ep["fc1"].n
         hp = ep["fc2"].kpad  # K of fc2 padded to a multiple of 32; pad columns stay zero
-        h1 = ws.get("ffn_h1", B * Nc, hid)
-        h2f = ws.planes(f"ffn_h2_{hp}", B * Nc, hp, zero=True, fmt=ep["fc2"].fmt)
-        ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
+        h1 = ws.get("ffn_h1", rows, hid)
+        h2f = ws.planes(f"ffn_h2_{hp}", rows, hp, zero=True, fmt=ep["fc2"].fmt)
+        st = self._cfold
+        if st is not None and "fc1_cs" in ep:             # ffn_norm inside fc1
+            ops.gemm(st["planes"], ep["fc1"], h1, bias=ep["fc1_b"], row_norm=(st["mr"], ep["fc1_cs"]))
+        else:
+            qn = ws.planes("inj_fn", rows, D, fmt=ep["fc1"].fmt)
+            if ep["fold_c"]:
+                ops.layernorm(c, pk["ln_one"], pk["ln_zero"], 1e-6, out_planes=qn)
+            else:
+                ops.layernorm(c, ep["ffw"], ep["ffb"], 1e-6, out_planes=qn)
+            ops.gemm(qn, ep["fc1"], h1, bias=ep["fc1_b"])
         off = 0
         for (hh, wwd) in ((H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)):  # AM:462-470 token split 16n/4n/n
             ops.dwconv(h1[off:], ep["dw"], ep["dw_b"], None, B, hh, wwd, 3, act="gelu",
                        xstride_b=Nc * hid, out_planes=h2f.rows(off), pstride_b=Nc * 2 * hp)
             off += hh * wwd
-        ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
+        self._cfold = None
+        if fold and not last:
+            cp, crs, _ = self._c_buffers(rows, cfmt)
+            ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c, out_planes=cp, rowstats_out=crs)
+            self._c_produced(rows, cfmt)
+        else:
+            ops.gemm(h2f, ep["fc2"], c, bias=ep["fc2_b"], resid=c)
 
     # ------------------------------------------------------------------ spatial prior module (AM:929-964)
     def _spm(self, x, B, H, W, c1_out, cbuf, Nc, join=True):

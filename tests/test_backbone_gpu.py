@@ -616,3 +616,44 @@ def test_clamp_flag_raises():
     with pytest.raises(RuntimeError):
         rp.outputs()
     assert ch.replay().outputs() is ch.feats
+
+
+def test_adapter_layernorm_fold_against_the_oracle():
+    """Round 5: the LayerNorms over the adapter tokens c inside their consumer GEMMs.  A model wide enough for the fold (embed_dim 256:
+    value projection 128 wide, ConvFFN hidden 128; 512 x 512 image: 5376 token rows per image = 21 whole GEMM tiles) against the oracle, with the fold
+    (producers of c write raw planes + strip sums, value / offsets projections and fc1 normalise in their epilogue: no LayerNorm launch over c after the
+    first interaction's) and without it (`fold_adapter_ln = False`: un-affine LayerNorm passes in front of the SAME folded weights)."""
+    import mmsa
+    from mmsa import ops
+    kw = dict(CONFIGS["tiny256"]["kwargs"], img_size=512, pretrained_size=512, embed_dim=256, num_heads=4, deform_num_heads=4, cffn_ratio=0.5)
+    torch.manual_seed(0)
+    orc = R.OracleEncoder(**kw)
+    sd = seeded_state_dict(orc, seed=51)
+    orc.load_state_dict(sd)
+    x = make_input(dict(kwargs=kw, in_seed=52), batch=1)
+    ref, _ = orc(x)
+    outs = {}
+    for fold in (True, False):
+        m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **kw))
+        m.load_state_dict(sd, strict=True)
+        m.fold_adapter_ln = fold
+        calls = []
+        real_ln = ops.layernorm
+
+        def counting_ln(xin, *a_, **k_):
+            calls.append(tuple(xin.shape))
+            return real_ln(xin, *a_, **k_)
+        ops.layernorm = counting_ln
+        try:
+            fs, _ = m(x.to(DEV))
+        finally:
+            ops.layernorm = real_ln
+        assert m._packed["fold_adapter_ln"] == fold
+        n_c = sum(1 for s in calls if s[0] == 5376)          # LayerNorm launches over the adapter tokens (5376 rows)
+        assert n_c == (1 if fold else 12), (fold, n_c)        # 4 shared + 6 ffn_norm + 2 extra extractors' query_norm = 12 without the fold (the default)
+        for i, (f, r) in enumerate(zip(fs, ref)):
+            assert_close(f, r, what=f"adapter LayerNorm fold={fold} f{i+1} vs oracle")
+        outs[fold] = [f.clone() for f in fs]
+    assert not all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
+    for a, b in zip(outs[True], outs[False]):
+        assert_close(a, b, tol=2e-4, what="folded vs LayerNorm passes")

@@ -899,6 +899,12 @@ _REGS_CASES = [
     ("h8c", "C", None, "none", True, False, False),      # extractor output projection, ConvFFN fc2 (AM:447-451)
     ("f3", "C", None, "none", True, False, False),       # ConvNeXt pointwise_conv2 + gamma + residual (TC:110-132)
     ("h8", "C", None, "none", False, False, False),      # value / offset projections, fc1
+    # the "rows" form of fp32-only outputs (no per-column scale): whole 256-byte row segments through one LDS transpose per sub-tile
+    ("h8c", "C", None, "none", True, False, False, "plain"),     # extractor output projection (AM:494-497), ConvFFN fc2
+    ("h8", "C", None, "none", True, False, False, "plain"),
+    ("h8c", "C", None, "none", False, False, False, "plain"),    # value / offset projections, fc1
+    ("b3", "C", None, "none", False, False, False, "plain"),     # the neck's fc convs (AM:947-950); K <= 256: the 4-wave flavour
+    ("h8c", "C", None, "none", False, False, True, "plain"),     # the same with the adapter tokens' LayerNorm folded in (row-normalising form on an fp32 output)
 ]
 
 
@@ -908,7 +914,8 @@ def test_gemm_register_epilogue_variants(ops, case):
     workgroup, two batches with per-batch bias / colscale) against float64 -- and bit for bit against the LDS-staged epilogue, which the
     same rows take when they are launched as a ragged matrix (M = 200 < one tile): both epilogues apply the same operations in the same
     order to the same accumulators.  Strip sums: different summation order, so within fp32 rounding."""
-    fmt_name, outk, pfmt_name, act, use_res, use_rs, use_rn = case
+    fmt_name, outk, pfmt_name, act, use_res, use_rs, use_rn = case[:7]
+    plain = len(case) > 7            # no per-column scale, alpha = 1
     FM = {"b3": ops.FMT_B3, "h8": ops.FMT_H8, "h8c": ops.FMT_H8C, "f3": ops.FMT_F3}
     fmt = FM[fmt_name]
     B, M, N, K = 2, 768, 384, 256
@@ -931,13 +938,15 @@ def test_gemm_register_epilogue_variants(ops, case):
         pre = mr[:, 1:2].double() * (acc - mr[:, 0:1].double() * csum.double().view(B, 1, N).expand(B, M, N).reshape(B * M, N)) + bb
     else:
         pre = acc + bb
-    ref = fact(pre) * cc * 0.75
+    ref = fact(pre) * (1.0 if plain else cc * 0.75)
     if use_res:
         ref = ref + res.double()
     ref = ref.float()
 
     def run(rows, m_arg, batch):
-        kw = dict(bias=bias.to(DEV), colscale=cs.to(DEV), alpha=0.75, act=act, batch=batch, m=m_arg, stride_a=ap.batch_stride(M), stride_w=wp_all.batch_stride(N), stride_bias=N)
+        kw = dict(bias=bias.to(DEV), act=act, batch=batch, m=m_arg, stride_a=ap.batch_stride(M), stride_w=wp_all.batch_stride(N), stride_bias=N)
+        if not plain:
+            kw.update(colscale=cs.to(DEV), alpha=0.75)
         out = outp = rs = None
         if "C" in outk:
             out = torch.full((B * M, N), float("nan"), device=DEV)
@@ -969,7 +978,7 @@ def test_gemm_register_epilogue_variants(ops, case):
         want = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).view(B * M, -1).float()
         assert_close(rs, want, tol=2e-6, what=f"{case}: strip sums")
     # the staged epilogue on the same rows: batch 0 only, its first 200 rows as a ragged one-tile-row matrix (200 < 256: no interior tile)
-    if True:
+    if not (use_rn and outk == "C"):     # (the row-normalising form on an fp32 output exists for whole tiles only: the launcher refuses ragged M)
         out2, outp2, rs2 = run(200, 200, 1)
         if out is not None:
             assert torch.equal(out2[:200], out[:200]), f"{case}: register and staged epilogues differ (fp32)"
@@ -977,6 +986,9 @@ def test_gemm_register_epilogue_variants(ops, case):
             assert torch.equal(planes_to_float(outp2)[:200], planes_to_float(outp)[:200]), f"{case}: register and staged epilogues differ (planes)"
         if rs is not None:
             assert_close(rs2[:200], rs[:200], tol=2e-6, what=f"{case}: strip sums, staged vs register epilogue")
+    if use_rn and outk == "C":
+        with pytest.raises(RuntimeError, match="row-normalising"):
+            run(200, 200, 1)
     again = run(B * M, M, B)
     for t0, t1 in zip((out, outp.p if outp is not None else None, rs), (again[0], again[1].p if again[1] is not None else None, again[2])):
         if t0 is not None:

@@ -1,6 +1,7 @@
 """Same-box A/B of environment settings: each variant is bench.py in its own process, variants interleaved over several rounds.
-    python tools/ab_env.py [--rounds 2] [--steps 20] [--verify] name1:VAR=val+VAR2=val name2: ...
-(an empty setting list = the default build).  Prints ms/step per run and the per-variant minimum; with --verify also the golden probe
+    python tools/ab_env.py [--rounds 2] [--steps 20] [--verify] name1:VAR=val+VAR2=val name2: name3@fold_adapter_ln=False+h8c=False ...
+(`name:ENV=..` sets environment variables -- MMSA_LIB to time another library build --, `name@attr=value+..` passes `--set attr=value` to bench.py: a
+backbone attribute; an empty setting list = the default build).  Prints ms/step per run and the per-variant minimum; with --verify also the golden probe
 error of the timed path (`verified.golden_max_rel`)."""
 import json
 import os
@@ -21,13 +22,14 @@ while args and args[0].startswith("--"):
         raise SystemExit(f"unknown flag {args[0]}")
 variants = []
 for a in args:
+    a, _, attrs = a.partition("@")
     name, _, sets = a.partition(":")
     env = dict(kv.split("=", 1) for kv in sets.split("+") if kv)
-    variants.append((name, env))
+    variants.append((name, env, [x for kv in attrs.split("+") if kv for x in ("--set", kv)]))
 best = {}
 for rnd in range(rounds):
-    for name, env in variants:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-roofline"]
+    for name, env, extra in variants:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--no-extras"] + extra
         if not verify:
             cmd.append("--no-verify")
         r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env))
