@@ -27,6 +27,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 #define WA_WAVES 13
+#ifndef WP_FOLD
+#define WP_FOLD 1   // 0 (A/B builds): the scores are scaled in a pass of their own before the maxima (round 4)
+#endif
 #define WA_NKEY 208                      // key rows of the K image (13 tiles of 16)
 #define WA_NKV 224                       // key rows of the V image (7 MFMA k-groups of 32)
 #define WA_K_BYTES (2 * WA_NKEY * 128)   // [ks][key] rows of 128 B (4 hi chunks | 4 lo chunks of 32 channels)
@@ -243,6 +246,8 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
         const int qr = (int)(__umul24(jqc, a.magic) >> 16), qc = jqc - __umul24(qr, ws);
         *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G) = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(Bw + l15 * 32 + 8 * G + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (round 5: the same writes made UNCONDITIONAL -- an offset outside the window sent to one of the row's four spare floats, which meet zeros of the
+        // selector -- measured 45.5 -> 48.0 us per two-image launch, profiles/r05_wattn.txt: the exec-masked stores stay)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -322,10 +327,14 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       const int G = lane_o >> 4;
+      // (round 5) the scores stay UNSCALED here: sc2 > 0, so the row maximum of the scaled scores is sc2 x this one, and the exponential below takes
+      // fma(s, sc2, -sc2 * max) -- the 52 multiplies per lane of the scaling pass are gone; maxima and minima by threes (v_max3_f32 / v_min3_f32)
       float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
       for (int t = 0; t < 13; ++t) {
+#if !WP_FOLD
         s[t] *= sc2;
+#endif
         if (16 * t + 16 > Nk) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -334,15 +343,16 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
             s[t][r] = ok ? s[t][r] : -INFINITY;
           }
         } else {
-          mn = fminf(fminf(mn, fminf(s[t][0], s[t][1])), fminf(s[t][2], s[t][3]));
+          mn = fminf(fminf(mn, s[t][0]), s[t][1]);
+          mn = fminf(fminf(mn, s[t][2]), s[t][3]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = fmaxf(fmaxf(mx, s[t][0]), s[t][1]);
+        mx = fmaxf(fmaxf(mx, s[t][2]), s[t][3]);
       }
-      if (live) amax = fmaxf(amax, fmaxf(fabsf(mx), fabsf(mn)));   // logit guard: this lane's query column, existing keys only
+      if (live) amax = fmaxf(amax, (WP_FOLD ? sc2 : 1.0f) * fmaxf(fabsf(mx), fabsf(mn)));   // logit guard: this lane's query column, existing keys only
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      mxs = mx;
+      mxs = WP_FOLD ? mx * sc2 : mx;
     }
     // ---- barrier #3: V(i) landed (the 4 K DMA instructions of the next item, issued later, stay in flight)
     WP_STAMP(6);
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void wattn_persist_kernel(WAttnArgs 
           if (2 * g + hf < 13) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float p = __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
+              const float p = WP_FOLD ? __builtin_amdgcn_exp2f(fmaf(s[2 * g + hf][r], sc2, -mxs)) : __builtin_amdgcn_exp2f(s[2 * g + hf][r] - mxs);
               s[2 * g + hf][r] = p;
               psum += p;
             }
