@@ -40,7 +40,7 @@ Extra objects:
                   median / min / max (SURVEY 8d asks for the median of >= 20 iterations; `value` stays the contract's K-step total).
   attention_guard -- the per-block logit guard words read back after the timed region (backbone.check_attention_guard): the largest
                   |logit| any attention block scored and whether every block stayed inside its operand precision's range.
-  worst_case_precision -- the same step with EVERY GEMM and attention operand in the bf16 hi/lo format (MMSA_H8=none, attention 'b3'):
+  worst_case_precision -- the same step with EVERY GEMM and attention operand in the hi/lo pair formats (h8_sites = (), attention_precision = 'b3'):
                   what a checkpoint whose logits leave the fp16 range in every block would run.
   eager_plugin_api -- the call a reference user makes (segmentors/encoder_decoder.py:63-69): `backbone(x)` + head eagerly, no graph, the
                   attention guard in its default "sync" mode; its logits equal the replayed graph's bit for bit.
@@ -251,7 +251,7 @@ def main():
         head = mmsa.build_head(dict(type="SegformerHead", **hkw))
         if not a.default_init:
             head.load_state_dict(seeded_state_dict(head, seed=hcfg["seed"]))
-        model.emit_planes = os.environ.get("MMSA_EMIT_PLANES", "1") == "1"   # the tail also writes its four maps as planes: the head skips its NCHW -> planes pass
+        model.emit_planes = True   # (`--set emit_planes=False` for the A/B) the tail also writes its four maps as planes: the head skips its NCHW -> planes pass
 
     feats = [None]
 
@@ -561,7 +561,7 @@ def main():
                      "verified": {"logits_equal_the_replayed_graphs_bitwise": same_e}}
 
     worst = None
-    if model is not None and world == 1 and not a.no_roofline and os.environ.get("MMSA_H8") is None and os.environ.get("MMSA_ATTN") is None:
+    if model is not None and world == 1 and not a.no_roofline and not a.set:
         # every operand of every GEMM and attention kernel as a bf16 hi/lo pair: the operand formats a checkpoint with peaky attention in every
         # block falls back to.  Re-packs the weights (the graphs captured above are dead from here on: nothing replays them again).
         del replay, chains

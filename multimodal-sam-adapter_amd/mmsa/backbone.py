@@ -201,7 +201,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # of the bf16 hi/lo scheme; csrc/common.h has the error analysis, tools/precision_study.py the end-to-end measurement).
     # "vit" = qkv / proj / lin1 / lin2 of the SAM ViT blocks; "inter" = the Linear layers of the injectors / extractors (MSDA
     # projections, ConvFFN); "up" = the 2x2 transposed conv of the tail.  The TwinConvNeXt / neck GEMMs stay on bf16 hi/lo (the most
-    # error-sensitive part of the path: SURVEY appendix F).  `model.h8_sites = ()` or MMSA_H8=none keeps every site on bf16 hi/lo.
+    # error-sensitive part of the path: SURVEY appendix F).  `model.h8_sites = ()` keeps every site on 16-bit hi/lo pairs.
+    # Every switch of this class that changes numerics is an ATTRIBUTE (h8_sites, h8c, cnx_f16, fold_ln, fold_adapter_ln, fold_convnext_ln, share_c_norm,
+    # fuse_convnext_mlp, attention_precision, attention_guard): set it before the first forward, or call invalidate() after changing it; the A/B tools pass
+    # them through `bench.py --set attr=value`.  No environment variable changes what this module computes.
     # "attnv" = the attention kernels run P V on the fp16 MFMA: the v third of the qkv planes (GEMM output and bias rows) is h8-encoded
     # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study); the kernels with the rel-pos terms
     # fused run Q K^T and the rel-pos terms on fp16 hi parts too -- per block, and only while its logits are small (_attn_mode).
@@ -209,9 +212,6 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     attention_precision = "auto"   # 'auto' | 'f16' | 'b3': operand precision INSIDE the attention kernels where the "attnv" site allows fp16 (_attn_mode)
 
     def _h8_sites(self):
-        env = os.environ.get("MMSA_H8")
-        if env is not None:
-            return tuple(t for t in env.split(",") if t and t != "none")
         return tuple(getattr(self, "h8_sites", self.H8_DEFAULT))
 
     @contextlib.contextmanager
@@ -280,21 +280,21 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         return sd
 
     def _h8c_wanted(self):
-        """h8 sites with deep contractions travel as h8c planes (default); `model.h8c = False` / MMSA_H8C=0 keeps them on h8 line planes (A/B)."""
-        return os.environ.get("MMSA_H8C", "1") != "0" and bool(getattr(self, "h8c", True))
+        """h8 sites with deep contractions travel as h8c planes (default); `model.h8c = False` keeps them on h8 line planes (A/B)."""
+        return bool(getattr(self, "h8c", True))
 
     def _cnx_f16_wanted(self):
-        """TwinConvNeXt GEMMs on fp16 hi/lo pairs (default) instead of bf16 hi/lo; `model.cnx_f16 = False` / MMSA_CNX_F16=0 for the A/B.  Not with
+        """TwinConvNeXt GEMMs on fp16 hi/lo pairs (default) instead of bf16 hi/lo; `model.cnx_f16 = False` for the A/B.  Not with
         the opt-in ConvNeXt LayerNorm fold (its depthwise kernel writes bf16 hi/lo planes)."""
-        fold = bool(getattr(self, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
-        return os.environ.get("MMSA_CNX_F16", "1") != "0" and bool(getattr(self, "cnx_f16", True)) and not fold
+        fold = bool(getattr(self, "fold_convnext_ln", False))
+        return bool(getattr(self, "cnx_f16", True)) and not fold
 
     def _fold_ln_wanted(self, hidden=None):
         """Whether _pack folds the ViT blocks' LayerNorms into their consumer GEMMs (a pack-time setting: checkpoint.load_packed compares it)."""
         D, heads = self.cfg["embed_dim"], self.cfg["num_heads"]
         Da = heads * ops.pad32(D // heads)
         hidden = int(D * self.cfg["mlp_ratio"]) if hidden is None else hidden
-        return (os.environ.get("MMSA_FOLD_LN", "1") != "0" and bool(getattr(self, "fold_ln", True)) and D % 64 == 0
+        return (bool(getattr(self, "fold_ln", True)) and D % 64 == 0
                 and (3 * Da) % 128 == 0 and hidden % 128 == 0)
 
     @torch.no_grad()
@@ -370,7 +370,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             pk["blocks"].append(dict(
                 n1w=sd[b + "norm1.weight"], n1b=sd[b + "norm1.bias"], n2w=sd[b + "norm2.weight"], n2b=sd[b + "norm2.bias"],
                 qkv_b=qkv_bias,
-                # k = v of pad tokens; with the fp16 P V of the attention kernels (the "attnv" site, a default; MMSA_H8 without it: bf16 hi/lo pairs) the v third
+                # k = v of pad tokens; with the fp16 P V of the attention kernels (the "attnv" site, a default; `h8_sites` without it: fp16 hi/lo pairs) the v third
                 # of the qkv planes -- these bias rows and the qkv GEMM's output -- is h8-encoded (ops.Planes.split)
                 qkv_bp=(ops.split_planes_qkv(qkv_bias.reshape(1, -1).contiguous(), Da) if ("attnv" in h8_sites and Da % 32 == 0)
                         else ops.split_planes(qkv_bias.reshape(1, -1).contiguous(), kpad=3 * Da, fmt=ops.FMT_F3)),
@@ -404,10 +404,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             # default (round 4): fp16 hi/lo pairs ("f3": 22 significant bits, the same three MFMAs per product as bf16 hi/lo) for the whole
             # chain (stem, downsample and pointwise convs) -- its operand rounding is what GFFM amplifies (tools/f3_study.py)
             return ops.FMT_F3 if cnx_f16 else ops.FMT_B3
-        # ConvNeXt LayerNorm fold (round 3): OPT-IN (`model.fold_convnext_ln = True` or MMSA_FOLD_CNX_LN=1).  Built, tested, and measured at
+        # ConvNeXt LayerNorm fold (round 3): OPT-IN (`model.fold_convnext_ln = True`).  Built, tested, and measured at
         # ViT-L 1024^2: step -0.17 ms, golden probes 2.9e-4 -> 4.6e-4 (the chain's error is amplified ~15 x by GFFM, DESIGN.md sections 2 and 4.2):
         # not worth the margin.  Applies to the stages that run pointwise_conv1 as a GEMM (not the fused stage-0 pair), 64-channel chunks.
-        want_cnx = bool(getattr(self, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
+        want_cnx = bool(getattr(self, "fold_convnext_ln", False))
         pk["cnx_f16"] = cnx_f16
 
         def fold_cnx(c_):
@@ -531,8 +531,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # Injector i normalises the adapter tokens c with its feat_norm, extractor i normalises the SAME c (the injector only
         # updates x) with its query_norm: two LayerNorm passes over the largest token matrix of the path (Nc = 21504 rows per
         # image).  LN(c; w, b) W^T + bias = chat (W * w)^T + (W b + bias) with chat = (c - mean) * rstd, so the affine parts are folded
-        # into the two projections' weights here and ONE pass computes chat for both (`share_c_norm`; MMSA_SHARE_CNORM=0 keeps two).
-        share_c = os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(self, "share_c_norm", True))
+        # into the two projections' weights here and ONE pass computes chat for both (`share_c_norm = False` keeps two).
+        share_c = bool(getattr(self, "share_c_norm", True))
         pk["share_c_norm"] = share_c
         pk["ln_one"], pk["ln_zero"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
 
@@ -958,10 +958,10 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     attention_guard = "sync"
 
     def _attn_policy(self):
-        return os.environ.get("MMSA_ATTN") or getattr(self, "attention_precision", "auto")
+        return getattr(self, "attention_precision", "auto")
 
     def _attn_mode(self, bp):
-        """'f16' or 'b3' for this block's attention kernels.  `attention_precision` (or MMSA_ATTN): 'f16' / 'b3' force one; 'auto'
+        """'f16' or 'b3' for this block's attention kernels.  `attention_precision`: 'f16' / 'b3' force one; 'auto'
         (default): the block's recorded mode -- 'f16' until its guard word has exceeded ATTN_F16_MAX_LOGIT once (check_attention_guard)."""
         pol = self._attn_policy()
         if pol in ("f16", "b3"):
@@ -1241,7 +1241,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             n = ws.planes(t + "n", 2 * P, c, fmt=wf)
             hbuf = ws.planes(t + "h", 2 * P, 4 * c, fmt=wf)
             # narrow stages (C = 96 / 192): the pointwise pair as ONE kernel that keeps the 4C hidden tensor in LDS (csrc/mlp_fused.hip)
-            fuse_mlp = ops.convnext_mlp_fused_supported(c) and bool(getattr(self, "fuse_convnext_mlp", True)) and os.environ.get("MMSA_FUSE_MLP", "1") != "0"
+            fuse_mlp = ops.convnext_mlp_fused_supported(c) and bool(getattr(self, "fuse_convnext_mlp", True))
             fold = "pw1f" in st["stages"][i][0] and not fuse_mlp and hh % 8 == 0 and wwd % 8 == 0 and P >= 128
             if fold:
                 rs = ws.get(t + "rs", 2 * P, 2 * (c // 64))

@@ -194,9 +194,9 @@ def load_packed(model, path, device="cuda"):
     if blob["cfg"] != model.cfg:
         raise RuntimeError(f"{path}: packed for a different architecture")
     want = {"h8_sites": list(model._h8_sites()), "h8c": bool(model._h8c_wanted()),
-            "share_c_norm": os.environ.get("MMSA_SHARE_CNORM", "1") != "0" and bool(getattr(model, "share_c_norm", True))}
+            "share_c_norm": bool(getattr(model, "share_c_norm", True))}
     want["fold_ln"] = bool(model._fold_ln_wanted())
-    want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False)) or os.environ.get("MMSA_FOLD_CNX_LN", "0") == "1"
+    want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False))
     want["cnx_f16"] = bool(model._cnx_f16_wanted())
     if blob.get("settings") != want:
         raise RuntimeError(f"{path}: packed with settings {blob.get('settings')}, the model runs {want}: repack")

@@ -17,7 +17,7 @@ GEMM_PROFILE = None
 CLAMP_WATCH = None   # a 1-element fp32 device tensor: the clamp watch word handed to every plane-producing launch (include/mmsa.h "Clamp watch"); the backbone
                      # sets it around its forward (clamp_watch below) -- None = no watch
 GEMM_MAX_GRID = 0    # > 0: cap on the persistent workgroups of every gemm() launch (mmsa.chains gives each concurrent chain its share of the CUs)
-GEMM_FLAVOUR = int(os.environ.get("MMSA_GEMM_FLAVOUR", "0"))     # 0: workgroup shape chosen by the library; 4 / 8 force the 128- / 256-row form of the LDS-DMA GEMM (tests, A/B runs; bit-identical results)
+GEMM_FLAVOUR = 0     # 0: workgroup shape chosen by the library; 4 / 8 force the 128- / 256-row form of the LDS-DMA GEMM (tests, A/B runs; bit-identical results)
 GEMM_SHAPES = None   # optional parallel list of (m, n, k, batch, act, has_resid, outputs) per profiled launch (tools/gemm_shapes.py)
 
 

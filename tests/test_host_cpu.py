@@ -460,3 +460,31 @@ def test_f3_and_h8c_planes_host_logic():
     got = ops.planes_to_float(ops.Planes(raw, 2, 64, 64, ops.FMT_H8C))
     assert torch.equal(got, hi.float() + lo.view(torch.float8_e5m2).float() / (2048.0 * 1.09375))
     assert (got - x).abs().max() <= 2.0 ** -13 * x.abs().max()
+
+
+def test_the_product_package_reads_no_numerics_switch_from_the_environment():
+    """every switch that changes what the package computes is a module attribute (bench.py --set passes them in A/B runs).  The only
+    environment variables the package reads name FILES (the library to load, a ConvNeXt checkpoint) or arm a test aid that changes no result."""
+    pkg = os.path.join(ROOT, "multimodal-sam-adapter_amd", "mmsa")
+    allowed = {"MMSA_LIB", "MMSA_CONVNEXT_CKPT", "MMSA_DEBUG_POISON_LDS"}
+    found = set()
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            found |= set(re.findall(r"os\.environ(?:\.get)?[\(\[]\s*[\"']([A-Z0-9_]+)[\"']", src))
+            assert "getenv" not in src, fn
+    assert found <= allowed, f"environment reads in the product package: {sorted(found - allowed)}"
+
+
+def test_gemm_kernels_do_not_spill_into_their_k_loops():
+    """a scratch reload in front of an LDS-DMA instruction is an s_waitcnt vmcnt(0) -- a drain of the whole prefetch stream.  Every
+    instantiation of the LDS-DMA GEMM kernels is compiled to ISA here (hipcc cross-compiles without a GPU) and must stay at <= 10 scratch instructions
+    (gemm_v2: 0 since the epilogue sees the lane id through an opaque copy; gemm_h8c: the handful around its tile loop, none between its barriers)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_scratch", os.path.join(ROOT, "tools", "isa_scratch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.census(os.path.join(ROOT, "multimodal-sam-adapter_amd", "csrc", "gemm_h8c.hip"))
+    assert len(res) >= 6
+    for k, v in res.items():
+        assert v["scratch"] <= 10, f"{k}: {v['scratch']} scratch instructions"
