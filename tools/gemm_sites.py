@@ -34,6 +34,10 @@ SITES = [
     ("injoa", 8192, 576, 1024, 1, "h8c", "none", "C", None, 0, 0, 0, 0),
     ("extval", 8192, 512, 1024, 1, "h8c", "none", "C", None, 0, 0, 0, 0),
     ("injout", 8192, 1024, 512, 1, "h8c", "none", "CP", "h8c", 1, 1, 0, 1),
+    # diagnostic variants of lin1 (not model sites; run with --only): what GELU and the row-normalising form cost its epilogue
+    ("lin1none", 8192, 4096, 1024, 1, "h8c", "none", "P", "h8c", 0, 0, 1, 0),
+    ("lin1norn", 8192, 4096, 1024, 1, "h8c", "gelu", "P", "h8c", 0, 0, 0, 0),
+    ("lin1bare", 8192, 4096, 1024, 1, "h8c", "none", "P", "h8c", 0, 0, 0, 0),
 ]
 
 
@@ -45,7 +49,7 @@ def worker(only):
     FM = {"b3": ops.FMT_B3, "h8": ops.FMT_H8, "h8c": ops.FMT_H8C, "f3": ops.FMT_F3}
     res = []
     for (label, M, N, K, b, fmt_n, act, outk, pf, resid, rs, rn, cs) in SITES:
-        if only and label not in only:
+        if (only and label not in only) or (not only and label in ("lin1none", "lin1norn", "lin1bare")):
             res.append(float("nan"))
             continue
         fmt = FM[fmt_n]
