@@ -376,45 +376,51 @@ __device__ __forceinline__ void clamp_report(float* word, float m, float limit) 
 // activation codes shared by the GEMM epilogue and the conv kernels
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_HSWISH = 4, ACT_SIGMOID = 5 };
 
-// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26: 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1/(1 + p|x|)): one v_rcp,
-// one v_exp and 7 FMAs instead of libm's ~40-instruction piecewise erff -- the GELU epilogue of the MLP GEMMs evaluates
-// it 32768 times per output tile.  The error is two orders below the bf16x3 product error (2^-17 relative).
-__device__ __forceinline__ float fast_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  const float r = fmaf(-p, e, 1.0f);
-  return copysignf(r, x);
+// GELU(x) = x Phi(x) (erf form, nn.GELU's default) as  h + |h| (1 - e),  h = x / 2,  e = erfc(|x| / sqrt 2) = exp2(P(min(|x|, 6)))  with P a degree-6 polynomial without
+// constant term, fitted (weighted least squares, Lawson iterations: tools/gelu_fit.py) to log2 erfc so that |x| / 2 * |exp2(P) - erfc| is minimal over [0, 6]:
+// 8.2e-8 with exact arithmetic, 3.6e-7 absolute in fp32 (the previous Abramowitz & Stegun 7.1.26 form: 4.6e-7 in fp32) -- two orders below the operand formats' rounding.
+// Beyond |x| = 6, erfc < 2e-9 and 1 - e rounds to 1: the result is x or 0.  ONE transcendental per value instead of two (v_rcp_f32 + v_exp_f32) and 6 instead of 7
+// polynomial steps: a transcendental costs 2.5 issue slots of a plain instruction on this chip and the GELU of the MLP GEMMs is issue time of the epilogue, 26 of lin1's
+// 163 us (profiles/r05_gelu_forms.txt).  gelu1 (single values: element-wise epilogues, the gated MLPs of the neck) and gelu2 (packed pairs: v_pk_fma_f32, two values
+// per instruction) perform the same operations in the same order on every value: bit-identical results.
+#define MMSA_GELU_C1 -1.151147127e+00f
+#define MMSA_GELU_C2 -4.589156806e-01f
+#define MMSA_GELU_C3 -5.323817953e-02f
+#define MMSA_GELU_C4 7.977456786e-03f
+#define MMSA_GELU_C5 -7.398718735e-04f
+#define MMSA_GELU_C6 2.992386726e-05f
+__device__ __forceinline__ float gelu1(float x) {
+  const float a = fminf(fabsf(x), 6.0f);
+  float p = fmaf(MMSA_GELU_C6, a, MMSA_GELU_C5);
+  p = fmaf(p, a, MMSA_GELU_C4);
+  p = fmaf(p, a, MMSA_GELU_C3);
+  p = fmaf(p, a, MMSA_GELU_C2);
+  p = fmaf(p, a, MMSA_GELU_C1);
+  p *= a;
+  const float r = 1.0f - __builtin_amdgcn_exp2f(p);   // erf(|x| / sqrt 2)
+  const float h = x * 0.5f;
+  return fmaf(fabsf(h), r, h);
 }
-
-// GELU on 4 values with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per instruction); the two
-// transcendentals per value (v_rcp_f32, v_exp_f32) stay scalar.  Same formula as fast_erf.
 typedef __attribute__((ext_vector_type(2))) float mmsa_f2;
 __device__ __forceinline__ mmsa_f2 gelu2(mmsa_f2 x) {
-  const mmsa_f2 z = x * 0.70710678118654752440f;
-  const mmsa_f2 az = __builtin_elementwise_abs(z);
-  const mmsa_f2 d = az * 0.3275911f + 1.0f;
-  mmsa_f2 t;
-  t.x = __builtin_amdgcn_rcpf(d.x);
-  t.y = __builtin_amdgcn_rcpf(d.y);
-  mmsa_f2 p = t * 1.061405429f + (-1.453152027f);
-  p = p * t + 1.421413741f;
-  p = p * t + (-0.284496736f);
-  p = p * t + 0.254829592f;
-  p = p * t;
-  const mmsa_f2 a2 = az * az * (-1.4426950408889634f);
+  mmsa_f2 a;
+  a.x = fminf(fabsf(x.x), 6.0f);
+  a.y = fminf(fabsf(x.y), 6.0f);
+  mmsa_f2 p = a * MMSA_GELU_C6 + MMSA_GELU_C5;
+  p = p * a + MMSA_GELU_C4;
+  p = p * a + MMSA_GELU_C3;
+  p = p * a + MMSA_GELU_C2;
+  p = p * a + MMSA_GELU_C1;
+  p = p * a;
   mmsa_f2 e;
-  e.x = __builtin_amdgcn_exp2f(a2.x);
-  e.y = __builtin_amdgcn_exp2f(a2.y);
-  mmsa_f2 r = 1.0f - p * e;            // erf(|z|)
-  r.x = copysignf(r.x, z.x);
-  r.y = copysignf(r.y, z.y);
-  return x * 0.5f * (r + 1.0f);
+  e.x = __builtin_amdgcn_exp2f(p.x);
+  e.y = __builtin_amdgcn_exp2f(p.y);
+  const mmsa_f2 r = 1.0f - e;
+  const mmsa_f2 h = x * 0.5f;
+  mmsa_f2 o;
+  o.x = fmaf(fabsf(h.x), r.x, h.x);
+  o.y = fmaf(fabsf(h.y), r.y, h.y);
+  return o;
 }
 __device__ __forceinline__ float4 gelu4(float4 v) {
   const mmsa_f2 a = gelu2((mmsa_f2){v.x, v.y}), b = gelu2((mmsa_f2){v.z, v.w});
@@ -423,7 +429,7 @@ __device__ __forceinline__ float4 gelu4(float4 v) {
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
-    case ACT_GELU: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));  // erf-form GELU (nn.GELU default)
+    case ACT_GELU: return gelu1(x);  // erf-form GELU (nn.GELU default)
     case ACT_RELU: return fmaxf(x, 0.0f);
     case ACT_RELU6: return fminf(fmaxf(x, 0.0f), 6.0f);
     case ACT_HSWISH: return x * (fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) / 6.0f);
