@@ -35,6 +35,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned hc_u4;
                     // here: 64 more live registers in the steady state push ~20 loop invariants into scratch, reloaded around the loop in every output
                     // tile (lin1 loop-only 160 us with, 122 us without: profiles/r04_h8c_gemm.txt).  Off.
 #endif
+#ifndef HC_LATE_DRAIN
+#define HC_LATE_DRAIN 0   // 1 (A/B builds): the last pair of an output tile does NOT drain the operand stream -- the next tile's first pieces (requested during that pair) stay in
+                          // flight into the epilogue, which waits for them together with its own bias / column / row vectors (gemm_v2_epilogue.inc EPI_DRAIN): one exposed round
+                          // trip per tile boundary instead of two.  Measured a wash (lin1 / qkv -1 %, lin2 / proj +1 ... +2 %, step +0.1 ms: profiles/r05_epilogue_regs.txt, job r05_x)
+#endif
 #ifndef HC_EPI_UNROLL
 #define HC_EPI_UNROLL 1   // 0 (A/B builds): the rolled epilogue for every instantiation
 #endif
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
     /* output tile runs the tile-index arithmetic, whose temporaries on top of a read phase's 192 live registers spilled loop invariants */ \
     if (FAST_) { ++lp_j; ++lp_p; ++hp_j; ++hp_p; } else { if (do_l) HC_L_ADVANCE() if (do_h) HC_H_ADVANCE() }          \
     HC_SB();                                                                                                          \
-    if (FAST_) HC_WAIT(9); else if (last || tail) HC_WAIT(0); else if (!skipw) HC_WAIT(9);                            \
+    if (FAST_) HC_WAIT(9); else if (tail || (last && !HC_LATE_DRAIN)) HC_WAIT(0); else if (!skipw) HC_WAIT(9);        \
     HC_BAR()                                                                                                          \
     if (!(FAST_)) nowait = 0;                                                                                         \
     ++j;                                                                                                              \
@@ -258,13 +263,15 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
 #pragma unroll 1
     for (; p < np; ++p) HC_PAIR(0, 0)
     if (!grp) HC_BAR()
-    // ---- tile boundary: every DMA issued so far has landed (the last pair drained); the LO unit of the last pair is free until phase X of
+    // ---- tile boundary: (HC_LATE_DRAIN = 0: every DMA issued so far has landed, the last pair drained; 1: the next tile's HI(j+1) / LO(j) pieces may still be in
+    // flight -- into the OTHER LO unit and the HI units, never into the staging area -- and the epilogue drains them).  The LO unit of the last pair is free until phase X of
     // the next pair requests LO(j+1) into it -- with the gap behind / before it: 40 KiB of staging for the epilogue
     if (V2_DBG(a) == 2) {   // timing ablation (debug-knob builds): no epilogue
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j_ = 0; j_ < 4; ++j_) { asm volatile("" :: "v"(acc[i][j_])); acc[i][j_] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      if (HC_LATE_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       nowait = 1;
     } else {
       // the epilogue sees the lane id through an opaque copy: everything it derives from it (row / column indices, 64-bit addresses) is
@@ -275,7 +282,9 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
       asm volatile("" : "+v"(lane_o_));
       const int lane = lane_o_, l15 = lane_o_ & 15, g = lane_o_ >> 4;
 #define EPI_STAGING_BASE (smem + (((j - 1) & 1) ? 2 * HC_H_UNIT + HC_L_UNIT : 2 * HC_H_UNIT))
+#define EPI_LATE_DRAIN HC_LATE_DRAIN
 #include "gemm_v2_epilogue.inc"
+#undef EPI_LATE_DRAIN
 #undef EPI_STAGING_BASE
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
