@@ -376,26 +376,29 @@ __device__ __forceinline__ void clamp_report(float* word, float m, float limit) 
 // activation codes shared by the GEMM epilogue and the conv kernels
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_HSWISH = 4, ACT_SIGMOID = 5 };
 
-// GELU(x) = x Phi(x) (erf form, nn.GELU's default) as  h + |h| (1 - e),  h = x / 2,  e = erfc(|x| / sqrt 2) = exp2(P(min(|x|, 6)))  with P a degree-6 polynomial without
+// GELU(x) = x Phi(x) (erf form, nn.GELU's default) as  h + |h| (1 - e),  h = x / 2,  e = erfc(|x| / sqrt 2) = exp2(P(min(|x|, 6)))  with P a degree-7 polynomial without
 // constant term, fitted (weighted least squares, Lawson iterations: tools/gelu_fit.py) to log2 erfc so that |x| / 2 * |exp2(P) - erfc| is minimal over [0, 6]:
-// 8.2e-8 with exact arithmetic, 3.6e-7 absolute in fp32 (the previous Abramowitz & Stegun 7.1.26 form: 4.6e-7 in fp32) -- two orders below the operand formats' rounding.
-// Beyond |x| = 6, erfc < 2e-9 and 1 - e rounds to 1: the result is x or 0.  ONE transcendental per value instead of two (v_rcp_f32 + v_exp_f32) and 6 instead of 7
-// polynomial steps: a transcendental costs 2.5 issue slots of a plain instruction on this chip and the GELU of the MLP GEMMs is issue time of the epilogue, 26 of lin1's
+// 3.7e-8 with exact arithmetic, 3.3e-7 absolute in fp32 (the previous Abramowitz & Stegun 7.1.26 form: 4.6e-7 in fp32) -- two orders below the operand formats' rounding.
+// Beyond |x| = 6, erfc < 2e-9 and 1 - e rounds to 1: the result is x or 0.  ONE transcendental per value instead of two (v_rcp_f32 + v_exp_f32), the same
+// number of polynomial steps: a transcendental costs 2.5 issue slots of a plain instruction on this chip and the GELU of the MLP GEMMs is issue time of the epilogue, 26 of lin1's
 // 163 us (profiles/r05_gelu_forms.txt).  gelu1 (single values: element-wise epilogues, the gated MLPs of the neck) and gelu2 (packed pairs: v_pk_fma_f32, two values
 // per instruction) perform the same operations in the same order on every value: bit-identical results.
-#define MMSA_GELU_C1 -1.151147127e+00f
-#define MMSA_GELU_C2 -4.589156806e-01f
-#define MMSA_GELU_C3 -5.323817953e-02f
-#define MMSA_GELU_C4 7.977456786e-03f
-#define MMSA_GELU_C5 -7.398718735e-04f
-#define MMSA_GELU_C6 2.992386726e-05f
+#ifndef MMSA_GELU_DEG
+#define MMSA_GELU_DEG 7   // 6, 8 (A/B builds).  Fit error with exact arithmetic 8.2e-8 / 3.7e-8 / 9.0e-9, in fp32 3.6e-7 / 3.3e-7 / 3.1e-7: from degree 7 on the fp32 evaluation is the floor
+#endif
+#if MMSA_GELU_DEG == 6
+#define MMSA_GELU_COEFFS {-1.151147127e+00f, -4.589156806e-01f, -5.323817953e-02f, 7.977456786e-03f, -7.398718735e-04f, 2.992386726e-05f}
+#elif MMSA_GELU_DEG == 7
+#define MMSA_GELU_COEFFS {-1.151126981e+00f, -4.590439200e-01f, -5.294858292e-02f, 7.670805324e-03f, -5.757985055e-04f, -1.279479329e-05f, 4.278379038e-06f}
+#else
+#define MMSA_GELU_COEFFS {-1.151111007e+00f, -4.591621459e-01f, -5.262760073e-02f, 7.245406508e-03f, -2.720646735e-04f, -1.314778056e-04f, 2.805791701e-05f, -1.902148711e-06f}
+#endif
 __device__ __forceinline__ float gelu1(float x) {
+  constexpr float c[MMSA_GELU_DEG] = MMSA_GELU_COEFFS;
   const float a = fminf(fabsf(x), 6.0f);
-  float p = fmaf(MMSA_GELU_C6, a, MMSA_GELU_C5);
-  p = fmaf(p, a, MMSA_GELU_C4);
-  p = fmaf(p, a, MMSA_GELU_C3);
-  p = fmaf(p, a, MMSA_GELU_C2);
-  p = fmaf(p, a, MMSA_GELU_C1);
+  float p = fmaf(c[MMSA_GELU_DEG - 1], a, c[MMSA_GELU_DEG - 2]);
+#pragma unroll
+  for (int k = MMSA_GELU_DEG - 3; k >= 0; --k) p = fmaf(p, a, c[k]);
   p *= a;
   const float r = 1.0f - __builtin_amdgcn_exp2f(p);   // erf(|x| / sqrt 2)
   const float h = x * 0.5f;
@@ -406,11 +409,10 @@ __device__ __forceinline__ mmsa_f2 gelu2(mmsa_f2 x) {
   mmsa_f2 a;
   a.x = fminf(fabsf(x.x), 6.0f);
   a.y = fminf(fabsf(x.y), 6.0f);
-  mmsa_f2 p = a * MMSA_GELU_C6 + MMSA_GELU_C5;
-  p = p * a + MMSA_GELU_C4;
-  p = p * a + MMSA_GELU_C3;
-  p = p * a + MMSA_GELU_C2;
-  p = p * a + MMSA_GELU_C1;
+  constexpr float c[MMSA_GELU_DEG] = MMSA_GELU_COEFFS;
+  mmsa_f2 p = a * c[MMSA_GELU_DEG - 1] + c[MMSA_GELU_DEG - 2];
+#pragma unroll
+  for (int k = MMSA_GELU_DEG - 3; k >= 0; --k) p = p * a + c[k];
   p = p * a;
   mmsa_f2 e;
   e.x = __builtin_amdgcn_exp2f(p.x);

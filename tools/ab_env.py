@@ -40,7 +40,7 @@ for rnd in range(rounds):
             continue
         extra = ""
         if verify and isinstance(d.get("verified"), dict):
-            extra = "  " + " ".join(f"{k}={v}" for k, v in d["verified"].items() if "max_rel" in k)
+            extra = "  " + " ".join(f"{k}={v}" for k, v in d["verified"].items() if "max_rel" in k or "golden_probes" in k)
         print(f"round {rnd} {name:14s} {d['ms_per_step']:.3f} ms/step {d['value']:.2f} img/s  encoder-only {d.get('encoder_only')}{extra}", flush=True)
         best[name] = min(best.get(name, 1e9), d["ms_per_step"])
 print("best: " + "  ".join(f"{k} {v:.3f}" for k, v in best.items()))

@@ -1,5 +1,5 @@
 """Coefficients of the GELU the kernels evaluate (csrc/common.h gelu1 / gelu2):  GELU(x) = h + |h| (1 - exp2(P(min(|x|, 6)))),  h = x / 2,
-P(u) = c1 u + ... + c6 u^6 fitted to log2 erfc(u / sqrt 2) on [0, 6] so that the absolute error of GELU, |u| / 2 * |exp2(P(u)) - erfc(u / sqrt 2)|, is minimal
+P(u) = c1 u + ... + c7 u^7 fitted to log2 erfc(u / sqrt 2) on [0, 6] so that the absolute error of GELU, |u| / 2 * |exp2(P(u)) - erfc(u / sqrt 2)|, is minimal
 (weighted least squares + Lawson re-weighting).  Prints the coefficients and the errors of the fp32 evaluation (same operation order as the kernels) next to the
 Abramowitz & Stegun 7.1.26 form it replaced.      python tools/gelu_fit.py [degree]"""
 import sys
@@ -58,7 +58,7 @@ def gelu_as(x):
 
 
 if __name__ == "__main__":
-    deg = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    deg = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     e64, c = fit(deg)
     c32 = c.astype(f32)
     x = np.concatenate([-np.linspace(0, 12, 400001)[::-1], np.linspace(0, 12, 400001)]).astype(f32)
