@@ -203,9 +203,9 @@ __device__ __forceinline__ void h8_split2(float a, float b, unsigned& hi, unsign
   const mmsa_h2 h = __builtin_convertvector(v, mmsa_h2);            // round to nearest even
   const mmsa_f32x2 hf = __builtin_convertvector(h, mmsa_f32x2);
   constexpr float ls_ = COMP ? MMSA_H8_LO_SCALE * MMSA_H8C_LO_COMP : MMSA_H8_LO_SCALE;
-  const float la = (a - hf.x) * ls_, lb = (b - hf.y) * ls_;   // (exact without COMP)
+  const mmsa_f32x2 l = (v - hf) * ls_;   // (exact without COMP); packed: v_pk_add_f32 + v_pk_mul_f32 for the pair -- the GEMM epilogues are issue-bound (profiles/r05_gelu_forms.txt)
   hi = __builtin_bit_cast(unsigned, h);
-  lo8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(la, lb, (int)lo8, UPPER);
+  lo8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(l.x, l.y, (int)lo8, UPPER);
   qh8 = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(hf.x, hf.y, (int)qh8, UPPER);
 }
 // four floats -> 4 fp16 (8 bytes), 4 lo bytes, 4 q(hi) bytes

@@ -35,6 +35,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned hc_u4;
                     // here: 64 more live registers in the steady state push ~20 loop invariants into scratch, reloaded around the loop in every output
                     // tile (lin1 loop-only 160 us with, 122 us without: profiles/r04_h8c_gemm.txt).  Off.
 #endif
+#ifdef HC_EPI_STAMP   // timing experiment build only (tools/build_variant.sh ... -DHC_EPI_STAMP; tools/epi_stamps.py): shader-clock stamps of workgroup 0's SECOND tile boundary,
+                      // lane 0 of every wave: 0 = the k loop's last barrier passed, 1 = epilogue vectors requested, 2 = they (and everything older) arrived, 3..6 = sub-tile
+                      // 0..3 done (its stores issued), 7 = epilogue left, 8 = the barrier behind it passed
+__device__ unsigned long long g_hc_estamps[8 * 16];
+extern "C" int mmsa_debug_epi_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_hc_estamps), sizeof(g_hc_estamps)); }
+#define EPI_STAMP(i_) { if (estamp_on_) { __builtin_amdgcn_sched_barrier(0); et_[i_] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } }
+#define EPI_STAMP_WAIT() { if (estamp_on_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+#define EPI_STAMP(i_)
+#define EPI_STAMP_WAIT()
+#endif
 #ifndef HC_LATE_DRAIN
 #define HC_LATE_DRAIN 0   // 1 (A/B builds): the last pair of an output tile does NOT drain the operand stream -- the next tile's first pieces (requested during that pair) stay in
                           // flight into the epilogue, which waits for them together with its own bias / column / row vectors (gemm_v2_epilogue.inc EPI_DRAIN): one exposed round
@@ -278,6 +289,11 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
       // computed HERE, per tile.  Hoisted above the tile loop -- what LICM does with them otherwise -- those values are live across the k
       // loops, whose steady state needs 192 registers for accumulators, hi fragments and fp8 tuples alone: ~200 spilled registers, reloaded
       // (scratch loads, one exposed round trip per group) in every epilogue.
+#ifdef HC_EPI_STAMP
+      unsigned long long et_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const bool estamp_on_ = blockIdx.x == 0 && tdone == 1;
+#endif
+      EPI_STAMP(0)
       int lane_o_ = lane;
       asm volatile("" : "+v"(lane_o_));
       const int lane = lane_o_, l15 = lane_o_ & 15, g = lane_o_ >> 4;
@@ -286,6 +302,16 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
 #include "gemm_v2_epilogue.inc"
 #undef EPI_LATE_DRAIN
 #undef EPI_STAGING_BASE
+      EPI_STAMP(7)
+#ifdef HC_EPI_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      HC_BAR()
+      EPI_STAMP(8)
+      if (estamp_on_ && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q_ = 0; q_ < 9; ++q_) g_hc_estamps[wave * 16 + q_] = et_[q_];
+      }
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     HC_BAR()   // the staging area is free again
