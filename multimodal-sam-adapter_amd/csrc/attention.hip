@@ -297,17 +297,17 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
       }                                                                                      \
     }                                                                                        \
   } while (0)
-#define STORE_KV()                                                                           \
+#define STORE_KV(Kh_, Kl_, Vh_, Vl_)                                                                           \
   do {                                                                                       \
     if constexpr (PL) {                                                                      \
       _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                       \
         const int c = squart * (HD / 4) + 8 * i;                                             \
         const int ko = (c >> 3) * (64 * 16) + skey * 16;                                     \
-        *reinterpret_cast<uint4*>(Khi + ko) = and4(rkh[i], kv_keep);                         \
-        if constexpr (VF != 2) *reinterpret_cast<uint4*>(Klo + ko) = and4(rkl[i], kv_keep);  \
+        *reinterpret_cast<uint4*>((Kh_) + ko) = and4(rkh[i], kv_keep);                         \
+        if constexpr (VF != 2) *reinterpret_cast<uint4*>((Kl_) + ko) = and4(rkl[i], kv_keep);  \
         const int vo = skey * VSTR + c * 2;                                                  \
-        *reinterpret_cast<uint4*>(Vhi + vo) = and4(rvh[i], kv_keep);                         \
-        if constexpr (VF == 0) *reinterpret_cast<uint4*>(Vlo + vo) = and4(rvl[i], kv_keep);  \
+        *reinterpret_cast<uint4*>((Vh_) + vo) = and4(rvh[i], kv_keep);                         \
+        if constexpr (VF == 0) *reinterpret_cast<uint4*>((Vl_) + vo) = and4(rvl[i], kv_keep);  \
       }                                                                                      \
     } else {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < NF4; ++i) {                                      \
@@ -315,12 +315,12 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         uint2 h, l;                                                                          \
         f3_split4(rk[i], h, l);                                                              \
         const int ko = (c >> 3) * (64 * 16) + skey * 16 + (c & 7) * 2;                       \
-        *reinterpret_cast<uint2*>(Khi + ko) = h;                                             \
-        *reinterpret_cast<uint2*>(Klo + ko) = l;                                             \
+        *reinterpret_cast<uint2*>((Kh_) + ko) = h;                                             \
+        *reinterpret_cast<uint2*>((Kl_) + ko) = l;                                             \
         f3_split4(rv[i], h, l);                                                              \
         const int vo = skey * VSTR + c * 2;                                                  \
-        *reinterpret_cast<uint2*>(Vhi + vo) = h;                                             \
-        *reinterpret_cast<uint2*>(Vlo + vo) = l;                                             \
+        *reinterpret_cast<uint2*>((Vh_) + vo) = h;                                             \
+        *reinterpret_cast<uint2*>((Vl_) + vo) = l;                                             \
       }                                                                                      \
     }                                                                                        \
   } while (0)
@@ -335,12 +335,30 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
   float amax = 0.f;   // logit guard: largest |score| (log2 units) this lane's LIVE queries have seen
 
   const int nkb = (a.Nk + 63) / 64;
+  // VF = 2, MMSA_ATTN_DB = 1 (A/B builds; round 5): the lo planes' LDS regions are unused by the all-fp16 form and can serve as a SECOND K / V buffer, so that a key
+  // block costs one barrier instead of two: block kb + 1 is written (from the registers its loads filled during block kb's arithmetic) into the buffer block kb - 1 was
+  // read from, which every wave left before the barrier that ended block kb - 1.  Measured no faster (257.5 -> 261 us per two-image launch, profiles/r05_attention.txt):
+  // with two workgroups per CU the barriers were not what a key block waits for -- its softmax is issue time (profiles/r05_gelu_forms.txt has the issue costs).  Off.
+#ifndef MMSA_ATTN_DB
+#define MMSA_ATTN_DB 0
+#endif
+  constexpr bool DB = (VF == 2) && MMSA_ATTN_DB;
   LOAD_KV(0);
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();  // previous block fully consumed (also orders the bias-table fill on kb == 0)
-    STORE_KV();
+  if constexpr (DB) {
+    __syncthreads();   // (orders the bias-table fill; the staging region is free)
+    STORE_KV(Khi, Klo, Vhi, Vlo);
     __syncthreads();
-    if (kb + 1 < nkb) LOAD_KV(kb + 1);
+    if (nkb > 1) LOAD_KV(1);
+  }
+  for (int kb = 0; kb < nkb; ++kb) {
+    if constexpr (!DB) {
+      __syncthreads();  // previous block fully consumed (also orders the bias-table fill on kb == 0)
+      STORE_KV(Khi, Klo, Vhi, Vlo);
+      __syncthreads();
+      if (kb + 1 < nkb) LOAD_KV(kb + 1);
+    }
+    const unsigned char* Krd = (DB && (kb & 1)) ? Klo : Khi;   // the buffer this block is read from
+    const unsigned char* Vrd = (DB && (kb & 1)) ? Vlo : Vhi;
 
     // ---- S^T tiles: [t = key tile][sub]; lane holds keys 16t + 4G + r (r = reg), query column l15
     f32x4 s[2][4];
@@ -353,7 +371,7 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (ks * 4 + G) * (64 * 16) + (16 * t + l15) * 16;
-        const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(Khi + off);
+        const bf16x8 kh_ = *reinterpret_cast<const bf16x8*>(Krd + off);
         if constexpr (VF == 2) {
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub)
@@ -463,8 +481,8 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
         // lane i = 4q'+p of a 16-lane group addresses row q' (key), columns 4p..4p+3 of the 4x16 block
         const int row0 = 32 * s2 + 4 * G + (l15 >> 2);
         const int voff = row0 * VSTR + (16 * d + 4 * (l15 & 3)) * 2;
-        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff));
-        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vhi + voff + 16 * VSTR));
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vrd + voff));
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(Vrd + voff + 16 * VSTR));
         const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
         if constexpr (VF) {
 #pragma unroll
@@ -481,6 +499,13 @@ __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(Att
             o[sub][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, ph[sub][s2]), o[sub][d], 0, 0, 0);
           }
         }
+      }
+    }
+    if constexpr (DB) {
+      if (kb + 1 < nkb) {   // (uniform) block kb + 1 into the other buffer, then ONE barrier: it is visible, and this block's buffer is free for block kb + 2
+        if (kb & 1) STORE_KV(Khi, Klo, Vhi, Vlo); else STORE_KV(Klo, Klo, Vlo, Vlo);
+        __syncthreads();
+        if (kb + 2 < nkb) LOAD_KV(kb + 2);
       }
     }
   }
