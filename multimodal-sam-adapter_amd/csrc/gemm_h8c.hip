@@ -46,6 +46,10 @@ extern "C" int mmsa_debug_epi_stamps(unsigned long long* host_out) { return (int
 #define EPI_STAMP(i_)
 #define EPI_STAMP_WAIT()
 #endif
+#ifndef HC_SETPRIO
+#define HC_SETPRIO 0   // 1 (A/B builds): s_setprio 1 around the matrix parts of a pair, 0 around its read / request parts
+#endif
+#define HC_PRIO(p_) { if (HC_SETPRIO) __builtin_amdgcn_s_setprio(p_); }
 #ifndef HC_LATE_DRAIN
 #define HC_LATE_DRAIN 0   // 1 (A/B builds): the last pair of an output tile does NOT drain the operand stream -- the next tile's first pieces (requested during that pair) stay in
                           // flight into the epilogue, which waits for them together with its own bias / column / row vectors (gemm_v2_epilogue.inc EPI_DRAIN): one exposed round
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
     if (FAST_) HC_WAIT(9); else if (tail) HC_WAIT(0); else if (!skipw) HC_WAIT(9);                                    \
     HC_BAR()                                                                                                          \
     /* ======== phase X, matrix part: 32 fp16 MFMAs (two independent passes: no accumulator is touched twice in a row) */ \
+    HC_PRIO(1)                                                                                                        \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                  \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                \
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wh0[ni]), __builtin_bit_cast(mx_h8, ah0[mi]), acc[ni][mi], 0, 0, 0); \
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                \
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_h8, wh1[ni]), __builtin_bit_cast(mx_h8, ah1[mi]), acc[ni][mi], 0, 0, 0); \
     HC_SB();                                                                                                          \
+    HC_PRIO(0)                                                                                                        \
     if (FAST_) HC_WAIT(9); else if (tail) HC_WAIT(0); else if (!skipw) HC_WAIT(9);                                    \
     HC_BAR()                                                                                                          \
     /* ======== phase Y, read part: lo pairs -> fp8 tuples.  A operand: [q(hi) k-tile 0 | q(hi) k-tile 1 | lo 0 | lo 1], W operand: */ \
@@ -243,10 +249,12 @@ __global__ __launch_bounds__(512, 1) void gemm_h8c_kernel(GemmV2Args a) {
     if (FAST_) HC_WAIT(9); else if (tail) HC_WAIT(0); else if (!skipw) HC_WAIT(9);                                    \
     HC_BAR()                                                                                                          \
     /* ======== phase Y, matrix part: 16 block-scaled fp8 MFMAs (K = 128) */                                          \
+    HC_PRIO(1)                                                                                                        \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                  \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                \
         acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(opW[ni], opA[mi], acc[ni][mi], 1, 1, 0, MMSA_H8_MFMA_SCALE, 0, 0x7f7f7f7f); \
     HC_SB();                                                                                                          \
+    HC_PRIO(0)                                                                                                        \
     /* both cursors move HERE, where few registers are live (the fragments are dead, the MFMAs queued): a cursor that wraps to the next */ \
     /* output tile runs the tile-index arithmetic, whose temporaries on top of a read phase's 192 live registers spilled loop invariants */ \
     if (FAST_) { ++lp_j; ++lp_p; ++hp_j; ++hp_p; } else { if (do_l) HC_L_ADVANCE() if (do_h) HC_H_ADVANCE() }          \
