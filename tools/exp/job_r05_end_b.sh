@@ -6,7 +6,7 @@ timeout 600 python bench.py --chains 1 --no-cpu-baseline 2> /dev/null | tail -1 
 python -c "import json; d=json.load(open('gpurun_out/$TAG/bench_chains1.json')); print('chains=1:', d['value'], d['ms_per_step'], d['encoder_only'])"
 MMSA_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline 2> gpurun_out/$TAG/dist.err | tail -1 > gpurun_out/$TAG/bench_dist1.json
 python -c "import json; d=json.load(open('gpurun_out/$TAG/bench_dist1.json')); print('RCCL 1 rank:', d['value'], d['ms_per_step'], d['config']['collective'])" || tail -5 gpurun_out/$TAG/dist.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --chains 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --chains 1 > /dev/null 2>&1
 cp $(ls gpurun_out/$TAG/prof/*/*kernel_stats.csv | head -1) gpurun_out/$TAG/kernel_stats.csv
 rm -rf gpurun_out/$TAG/prof
 python tools/kstats.py gpurun_out/$TAG/kernel_stats.csv auto 60 > gpurun_out/$TAG/kstats.txt; head -14 gpurun_out/$TAG/kstats.txt
