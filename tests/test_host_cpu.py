@@ -488,3 +488,25 @@ def test_gemm_kernels_do_not_spill_into_their_k_loops():
     assert len(res) >= 6
     for k, v in res.items():
         assert v["scratch"] <= 10, f"{k}: {v['scratch']} scratch instructions"
+
+
+def test_kernel_gelu_coefficients_hold_their_error_bound():
+    """csrc/common.h evaluates GELU as x/2 + |x/2| (1 - exp2(P(min(|x|, 6)))) with a fitted P (tools/gelu_fit.py).  The coefficients compiled into the kernels,
+    evaluated in fp32 in the kernels' operation order, stay within 4e-7 of the erf-form GELU (nn.GELU's default, the reference's activation: IE:154-167, TC:107-111)
+    over [-12, 12], and a fresh fit reproduces them."""
+    import sys
+    from scipy.special import erf
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gelu_fit
+    src = open(os.path.join(ROOT, "multimodal-sam-adapter_amd", "csrc", "common.h")).read()
+    deg = int(re.search(r"#define MMSA_GELU_DEG (\d+)", src).group(1))
+    block = re.search(r"#%s MMSA_GELU_DEG == %d\s*\n#define MMSA_GELU_COEFFS \{([^}]*)\}" % ("if" if deg == 6 else "elif", deg), src)
+    assert block, "coefficient table of the compiled degree not found"
+    c32 = np.array([float(v.strip().rstrip("f")) for v in block.group(1).split(",")], dtype=np.float32)
+    assert len(c32) == deg
+    x = np.concatenate([-np.linspace(0, 12, 200001)[::-1], np.linspace(0, 12, 200001)]).astype(np.float32)
+    exact = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    err = np.abs(gelu_fit.gelu_new(x, c32).astype(np.float64) - exact).max()
+    assert err < 4e-7, err
+    _, c = gelu_fit.fit(deg, n=20001, iters=200)
+    assert np.allclose(c.astype(np.float32), c32, rtol=2e-3, atol=2e-7), (c, c32)
