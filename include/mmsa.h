@@ -44,18 +44,27 @@
  *  - Clamp watch (round 5).  The fp16-based formats clamp what they cannot hold (h8 / h8c: |x| > 57344, f3: |x| > 65504; bf16 hi/lo planes have fp32's
  *    range).  The entries that convert UNBOUNDED fp32 values to planes -- mmsa_gemm_split3, mmsa_layernorm_rows, mmsa_split_planes, mmsa_msda_fused,
  *    mmsa_dwconv_nhwc -- take `clamp_max`, an optional DEVICE float (NULL = no watch): a launch that had to clamp folds the largest |value| it met beyond
- *    the format's range into it with an atomic max (never lowered; the caller zeroes it).  0 after a forward = every operand plane holds its value.  The
+ *    the format's range (the GEMM's register epilogue: at least the format's limit -- it reports THAT it clamped, not by how much) into it with an atomic max (never lowered; the caller zeroes it).  0 after a forward = every operand plane holds its value.  The
  *    attention entries need none (their outputs are convex combinations of v, which the qkv GEMM's watch has seen).  The reference computes in fp32
  *    and has no such range; mmsa/backbone.py reads the word with the attention guard words and refuses a forward that clamped.
  */
 #ifndef MMSA_H
 #define MMSA_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
 
+/* A binding sees an opaque pointer.  The library's own sources include this header too (csrc/common.h defines MMSA_BUILDING_LIBRARY behind
+ * <hip/hip_runtime.h>), with the stream spelled as the HIP type they use, so that every definition is compiled against its declaration here:
+ * a definition whose argument list differs from the prototype is a "conflicting types" error of the library build, not silent stack garbage
+ * in a caller.  Both spellings are one pointer in the ABI. */
+#ifdef MMSA_BUILDING_LIBRARY
+typedef hipStream_t mmsa_stream_t;
+#else
 typedef void* mmsa_stream_t; /* hipStream_t */
+#endif
 
 /* mmsa_version() returns the MMSA_ABI_VERSION (mmsa_version.h) the library was built with; a binding must refuse a library whose number differs from
  * the header it was written against (mmsa/lib.py does) -- argument lists are not self-describing through a C ABI. */
@@ -159,7 +168,8 @@ int mmsa_gemm_split3(const float* A, const uint16_t* Ap, long lda, long strideA,
  * MMSA_FMT_F3: the format of A, W1, W2 (and of the hidden image the kernel keeps in LDS). */
 int mmsa_convnext_mlp_fused(const uint16_t* Ap, long lda, long strideA, const uint16_t* W1p, long strideW1, const uint16_t* W2p,
                             long strideW2, const float* b1, const float* b2, const float* gamma, float* x, long ldx, long strideX,
-                            int M, int C, int batch, int max_grid, int fmt, mmsa_stream_t stream);
+                            int M, int C, int batch, int max_grid, int fmt,
+                            float* clamp_max /* optional clamp watch word of the hidden tensor's planes (fmt = MMSA_FMT_F3), see Conventions */, mmsa_stream_t stream);
 
 /* fp32 [rows, cols] (row stride ld) -> planes [rows, 2*cols_pad], zero padded (cols_pad % 32 == 0).
  * kind 0: bf16 hi/lo; 1: h8 activation rows; 2: h8 weight rows; 3: h8c planes [ceil(rows / 2), 3*cols_pad] (cols_pad % 64 == 0; activations and weights);
@@ -172,7 +182,7 @@ int mmsa_split_planes(const float* src, long ld, int rows, int cols, int cols_pa
  * |logit| it scores -- scale * q.k + the rel-pos terms, natural units, over existing keys (pad tokens of a window included, they are
  * attended to) and live queries -- into it with an atomic max (never lowered; the caller zeroes it).  The reference computes attention
  * in fp32 (IE:488-499) and needs no such word; this library chooses the operand precision of a block's attention (v_fmt) from it:
- * the host reads it after the step and moves a block whose logits outgrow single fp16 operands to fp16 hi/lo PAIRS (f3 planes; mmsa/backbone.py). */
+ * the host reads it after the step and moves a block whose logits outgrow single fp16 operands to fp16 hi/lo PAIRS (f3 planes; mmsa/backbone.py).
  * qkv [B*H*W, ldq] = q|k|v, channel = head*head_dim + c; qkv_bias [3*D]; rp from mmsa_relpos_bias;
  * window_size 0 = global.  out [B*H*W, ldo]. head_dim in {32, 64}. */
 int mmsa_attention(const float* qkv, long ldq, const float* qkv_bias, const float* rp, float* out, long ldo, int B,

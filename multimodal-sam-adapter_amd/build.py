@@ -6,6 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")   # the C ABI's header: csrc/common.h includes it, every definition is compiled against its prototype
 OUT = os.path.join(HERE, "mmsa", "libmmsa_hip.so")
 
 
@@ -24,7 +25,7 @@ def source_digest():
     sources they were measured on; bench.py attaches a profile to its JSON line only when it equals the digest of the sources in the tree."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))):
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))) + sorted(glob.glob(os.path.join(INCLUDE, "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()
@@ -34,7 +35,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))
+    srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     return any(os.path.getmtime(s) > t for s in srcs)
 
 

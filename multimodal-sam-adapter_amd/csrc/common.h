@@ -9,10 +9,10 @@
 #define MMSA_ERR_ARG (-1)
 #define MMSA_ERR_LAUNCH (-2)
 
-// scalar type codes of the dtype-dispatched entry points (include/mmsa.h)
-enum { MMSA_DT_F32 = 0, MMSA_DT_F16 = 1, MMSA_DT_F64 = 2 };
-
-extern "C" const char* mmsa_last_error(void);
+// The C ABI's own header: every `extern "C"` definition of the library is compiled against its prototype there (a mismatch in the argument list is a
+// "conflicting types" error of this build), and the enums (MMSA_DT_*, MMSA_FMT_*, MMSA_ACT_*) have one definition.
+#define MMSA_BUILDING_LIBRARY 1
+#include "../../include/mmsa.h"
 void mmsa_set_error(const char* fmt, ...);
 
 // A/B and timing knobs.  The RELEASE library reads no environment variable and holds no writable global besides the thread-local error
@@ -143,7 +143,7 @@ __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k
 // for ACTIVATIONS (A operand); WEIGHTS store the chunk as 8 q(hi) bytes + 8 lo bytes, so that for both operands the lane's 32
 // operand bytes of the fp8 MFMA are just the chunks of two consecutive k-blocks, and byte p of A always meets byte p of W with
 // the roles (lo, q(hi)) crossed.  Values are clamped to +-57344 (the largest e5m2 / a finite fp16) before the split.
-enum { MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2, MMSA_FMT_F3 = 3 };
+// (enum MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2, MMSA_FMT_F3 = 3: include/mmsa.h, included above)
 // Output-plane format argument of the GEMM (`cp_fmt`): bits 0..7 = format of the columns below the split, bits 8.. = split / 32;
 // columns >= split (a multiple of 32, 0 = no split) are written as MMSA_FMT_H8.  The qkv projection writes q and k as bf16 hi/lo
 // planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: DESIGN.md 4.1).

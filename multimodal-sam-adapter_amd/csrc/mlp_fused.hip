@@ -30,6 +30,7 @@ struct MlpFusedArgs {
   float* x; long ldx; long strideX;                      // residual in / result out, fp32
   int M, batch;                                          // rows per batch
   int ntiles, tiles_per_batch;
+  float* clamp;                                          // optional clamp watch word (common.h): the hidden tensor GELU(A W1^T + b1) is converted to planes in the kernel
 };
 
 #define MF_C 96
@@ -44,6 +45,7 @@ struct MlpFusedArgs {
 // F16: A, W1, W2 and the hidden image are fp16 hi/lo pairs ("f3" planes, common.h) and the products run on the fp16 MFMA; else bf16 hi/lo
 template <bool F16>
 __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
+  float cw_ = 0.f;   // clamp watch: the largest |hidden value| this lane converted to f3 planes (reported once, at the end)
   constexpr int C = MF_C, HID = MF_HID;
   constexpr int NSTEP = 2 * (HID / 64);   // 12 steps per tile: (A, B) per 64-column hidden chunk
   constexpr int NT = C / 32;              // 16-column output tiles per wave (C / 2 columns per wave)
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
             float4 o = make_float4(acc_h[mi][ni][0] + bb.x, acc_h[mi][ni][1] + bb.y, acc_h[mi][ni][2] + bb.z, acc_h[mi][ni][3] + bb.w);
             o = gelu4(o);
             uint2 hh, ll;
-            if constexpr (F16) f3_split4(o, hh, ll); else split4(o, hh, ll);
+            if constexpr (F16) { clamp_see(cw_, o); f3_split4(o, hh, ll); } else split4(o, hh, ll);
             const int row = wm * 32 + mi * 16 + l15;
             const int chunk = ni * 2 + (g >> 1);                      // 16-byte chunk (8 values) of the 32-wide k-block
             const int sw = (row >> 1) & 7;
@@ -221,12 +223,13 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpFusedArgs a) {
       }
     }
   }
+  if constexpr (F16) clamp_report(a.clamp, cw_, MMSA_F3_MAX);
 }
 
 // x[b] <- x[b] + gamma[b] * (GELU(A[b] W1[b]^T + b1[b]) W2[b]^T + b2[b]) for b < batch; C = 96; rows M per batch.
 extern "C" int mmsa_convnext_mlp_fused(const unsigned short* Ap, long lda, long strideA, const unsigned short* W1p, long strideW1,
                                        const unsigned short* W2p, long strideW2, const float* b1, const float* b2, const float* gamma,
-                                       float* x, long ldx, long strideX, int M, int C, int batch, int max_grid, int fmt, hipStream_t stream) {
+                                       float* x, long ldx, long strideX, int M, int C, int batch, int max_grid, int fmt, float* clamp_max, hipStream_t stream) {
   MMSA_CHECK_ARG(Ap && W1p && W2p && b1 && b2 && gamma && x && M > 0 && batch > 0, "convnext_mlp_fused: bad args");
   MMSA_CHECK_ARG(C == MF_C, "convnext_mlp_fused: C = %d not supported (%d)", C, MF_C);
   MMSA_CHECK_ARG(fmt == MMSA_FMT_B3 || fmt == MMSA_FMT_F3, "convnext_mlp_fused: planes format %d (bf16 hi/lo or f3)", fmt);
@@ -238,7 +241,7 @@ extern "C" int mmsa_convnext_mlp_fused(const unsigned short* Ap, long lda, long 
                  "convnext_mlp_fused: fp32 pointers must be 16-byte aligned, ldx %% 4 == 0");
   MlpFusedArgs a;
   a.Ap = Ap; a.lda = lda; a.strideA = strideA; a.W1p = W1p; a.strideW1 = strideW1; a.W2p = W2p; a.strideW2 = strideW2;
-  a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.x = x; a.ldx = ldx; a.strideX = strideX; a.M = M; a.batch = batch;
+  a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.x = x; a.ldx = ldx; a.strideX = strideX; a.M = M; a.batch = batch; a.clamp = clamp_max;
   a.tiles_per_batch = cdiv(M, 128);
   a.ntiles = a.tiles_per_batch * batch;
   static MmsaPerDevice per_dev_ = {};

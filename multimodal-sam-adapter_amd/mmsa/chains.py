@@ -15,11 +15,13 @@ stream and joins them into it."""
 import torch
 
 from . import ops
+from .backbone import OperandRangeError
 
 
 class AttentionRangeError(RuntimeError):
-    """A replayed pass ran fp16 attention on logits beyond its range (backbone.ATTN_F16_MAX_LOGIT): the outputs of the passes named in the message are
-    invalid.  The blocks concerned have been moved to fp16 hi/lo pairs and the graphs captured again: replay those passes."""
+    """A replayed pass ran outside its operand formats' range: fp16 attention on logits beyond backbone.ATTN_F16_MAX_LOGIT (the blocks concerned have been moved
+    to fp16 hi/lo pairs), or a value beyond the fp16-based planes' range (backbone.range_fallback: the model is in its wide-range state now, every block is
+    named).  The outputs of the passes named in the message are invalid; the graphs have been captured again: replay those passes."""
 
 
 class Replay:
@@ -176,9 +178,10 @@ class Chains:
             self._pending.pop(0)
             try:
                 moved = self.backbone.check_attention_guard(vals=host.tolist())
-            except RuntimeError:    # backbone.OperandRangeError: a value was clamped on its way into fp16-based planes -- nothing to re-route, the passes are invalid
+            except OperandRangeError:    # a value was clamped on its way into fp16-based planes and nothing is left to re-route (backbone.range_fallback): the passes are invalid
                 self._bad.append((self._clean_upto + 1, self._seq))
                 self._clean_upto = self._seq
+                torch.cuda.synchronize(self.x.device)   # the copies into the pending host buffers have landed before the buffers go back to the pool
                 self._pool.append(host)
                 for _, _, h in self._pending:
                     self._pool.append(h)
@@ -198,8 +201,9 @@ class Chains:
             first, last = self._bad[-1]
             torch.cuda.synchronize(self.x.device)
             self.capture(self.x)
-            raise AttentionRangeError(f"mmsa.Chains: ViT block(s) {moved_at[1]} scored attention logits beyond the fp16 range (seen after pass {moved_at[0]}): "
-                                      f"the outputs of passes {first}..{last} are invalid.  The blocks now run on fp16 hi/lo pairs and the graphs have been "
+            raise AttentionRangeError(f"mmsa.Chains: ViT block(s) {moved_at[1]} ran outside their operand formats' range -- attention logits beyond the fp16 threshold, or (all blocks) "
+                                      f"a value beyond the fp16-based planes' range (seen after pass {moved_at[0]}): "
+                                      f"the outputs of passes {first}..{last} are invalid.  The blocks now run on hi/lo pairs and the graphs have been "
                                       "captured again -- replay those passes.")
 
     def _verify(self, seq):
@@ -229,7 +233,7 @@ class Chains:
         self._pending = []
         try:
             moved = self.backbone.check_attention_guard()
-        except RuntimeError:        # backbone.OperandRangeError (clamp watch): the passes since the last clean check are invalid
+        except OperandRangeError:   # clamp watch, nothing left to re-route: the passes since the last clean check are invalid
             self._bad.append((self._clean_upto + 1, self._seq))
             self._clean_upto = self._seq
             raise

@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 
-PACK_FORMAT = 10   # 10: the attention path's hi/lo planes (bias rows, rel-pos tables, fallback block weights) are fp16 pairs; 9: the ConvNeXt planes' format (fp16 hi/lo pairs) among the settings; 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
+PACK_FORMAT = 11   # 11 (round 6): extractor dicts carry `first`, fc1 of every shared-norm extractor the folded ffn_norm, attn_guard has depth + 1 words (the clamp watch), the offsets / attention-weights projection is padded to 128 columns, settings carry fold_adapter_ln and the wide-range state, the pack its `weights_clamped` flag; 10: the attention path's hi/lo planes (bias rows, rel-pos tables, fallback block weights) are fp16 pairs; 9: the ConvNeXt planes' format (fp16 hi/lo pairs) among the settings; 8: byte-exact digests (sha1) instead of floating-point sums; the blocks' attention modes / largest logits travel with the planes; 7: ConvNeXt LayerNorm fold (pw1f / pw1_cs / pw1_bf, setting fold_cnx_ln); 6: plane checksum + pack-time settings in the header, both attention table formats (relp / relp16, qkv_bp_b3); 3: planes carry their operand format (bf16 hi/lo or h8); 4: LayerNorm affine parts folded into the adapter projections (share_c_norm); 5: planes carry `split` (qkv bias rows: v columns as h8 planes)
 
 
 def unwrap_state_dict(ck):
@@ -172,15 +172,16 @@ def save_packed(model, path, device="cuda"):
                 for k in ("amode", "max_logit"):
                     if k in bo:
                         bp[k] = bo[k]
-                if bo.get("amode") == "b3" and bp["qkv"].fmt != ops.FMT_F3:
-                    bp.update(model._block_gemm_planes(sd_dev, bp["index"], ops.FMT_F3, pk["fold_ln"], dev))
+                if bo.get("amode") == "b3" and bp["qkv"].fmt != model._pair_fmt():
+                    bp.update(model._block_gemm_planes(sd_dev, bp["index"], model._pair_fmt(), pk["fold_ln"], dev))
         torch.cuda.synchronize(dev)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     enc = _enc(pk)
     torch.save({"format": PACK_FORMAT, "cfg": model.cfg, "state_dict": sd, "packed": enc, "fingerprint": _fingerprint(sd),
                 "packed_checksum": _packed_checksum(enc),
                 "settings": {"h8_sites": list(model._h8_sites()), "h8c": bool(pk.get("h8c", False)), "share_c_norm": bool(pk.get("share_c_norm", True)), "fold_ln": bool(pk.get("fold_ln", False)),
-                             "fold_cnx_ln": bool(pk.get("fold_cnx_ln", False)), "cnx_f16": bool(pk.get("cnx_f16", False))}}, path)
+                             "fold_cnx_ln": bool(pk.get("fold_cnx_ln", False)), "cnx_f16": bool(pk.get("cnx_f16", False)),
+                             "fold_adapter_ln": bool(pk.get("fold_adapter_ln", False)), "wide": bool(pk.get("wide", False))}}, path)
 
 
 def load_packed(model, path, device="cuda"):
@@ -193,11 +194,17 @@ def load_packed(model, path, device="cuda"):
         raise RuntimeError(f"{path}: not an mmsa packed checkpoint (format {PACK_FORMAT})")
     if blob["cfg"] != model.cfg:
         raise RuntimeError(f"{path}: packed for a different architecture")
+    # the wide-range state (backbone.range_fallback) is a property of the WEIGHTS the file carries: it travels with them.  (After load_state_dict below --
+    # its post hook resets the state -- it is set from the file again.)
+    wide = bool((blob.get("settings") or {}).get("wide", False))
+    model._wide_range = wide
     want = {"h8_sites": list(model._h8_sites()), "h8c": bool(model._h8c_wanted()),
             "share_c_norm": bool(getattr(model, "share_c_norm", True))}
     want["fold_ln"] = bool(model._fold_ln_wanted())
     want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False))
     want["cnx_f16"] = bool(model._cnx_f16_wanted())
+    want["wide"] = wide
+    want["fold_adapter_ln"] = bool(model._fold_adapter_ln_wanted())   # (a pack-time setting that drives the run-time path: ADVICE r05)
     if blob.get("settings") != want:
         raise RuntimeError(f"{path}: packed with settings {blob.get('settings')}, the model runs {want}: repack")
     if blob["fingerprint"] != _fingerprint(blob["state_dict"]):
@@ -205,8 +212,11 @@ def load_packed(model, path, device="cuda"):
     if blob.get("packed_checksum") != _packed_checksum(blob["packed"]):
         raise RuntimeError(f"{path}: state dict and packed planes do not belong together (the plane buffers fail their checksum)")
     model.load_state_dict(blob["state_dict"], strict=True)       # invalidates any earlier pack (post hook)
+    model._wide_range = wide
     dev = torch.device(device)
     pk = _dec(blob["packed"], dev)
+    if tuple(pk["attn_guard"].shape) != (model.cfg["depth"] + 1,):   # (a guard tensor without the clamp word would switch the watch off silently)
+        raise RuntimeError(f"{path}: the packed guard words have shape {tuple(pk['attn_guard'].shape)}, expected ({model.cfg['depth'] + 1},): repack")
     # spot check on the device: planes -> float must give back the weights they claim to be the split of
     sd = blob["state_dict"]
     for planes, w in ((pk["pe_w"], sd["patch_embed.proj.weight"].reshape(model.cfg["embed_dim"], -1)),

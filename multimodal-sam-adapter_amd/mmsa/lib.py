@@ -42,7 +42,7 @@ SIGNATURES = {
     "mmsa_ms_deform_attn_backward": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mmsa_msda_fused": [P, P, P, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, P, P],
     "mmsa_gemm_split3": [P, P, L, L, P, L, P, L, P, P, L, L, I, F, P, L, L, P, L, L, I, I, I, I, I, F, I, I, I, I, I, I, I, P, P, P, I, P, P],
-    "mmsa_convnext_mlp_fused": [P, L, L, P, L, P, L, P, P, P, P, L, L, I, I, I, I, I, P],
+    "mmsa_convnext_mlp_fused": [P, L, L, P, L, P, L, P, P, P, P, L, L, I, I, I, I, I, P, P],
     "mmsa_rowstats_finalize": [P, I, I, I, F, P, P],
     "mmsa_zero_bytes": [P, ctypes.c_size_t, P],
     "mmsa_split_planes": [P, L, I, I, I, P, I, P, P],
@@ -87,7 +87,7 @@ for _name, _args in SIGNATURES.items():
 
 # The C ABI is not self-describing: a library built from another tree (MMSA_LIB variants, a stale in-tree .so) may export every symbol and still take
 # different argument lists.  include/mmsa.h MMSA_ABI_VERSION is bumped with every such change; this binding was written for:
-ABI_VERSION = 101
+ABI_VERSION = 102
 if _lib.mmsa_version() != ABI_VERSION:
     raise RuntimeError(f"{LIB_PATH}: ABI version {_lib.mmsa_version()} but mmsa/lib.py binds version {ABI_VERSION} (include/mmsa.h MMSA_ABI_VERSION): "
                        "rebuild with python multimodal-sam-adapter_amd/build.py")

@@ -32,11 +32,13 @@ def collect_gemm_profile(prof):
     collect_gemm_profile.bytes = compulsory bytes of the same launches (operands read once, outputs written once)."""
     flops, ms = 0.0, 0.0
     collect_gemm_profile.bytes = sum(p[3] for p in prof)
-    for f, e0, e1, _ in prof:
+    collect_gemm_profile.launches = []     # (FLOPs, compulsory bytes, milliseconds) per launch, in launch order
+    for f, e0, e1, by in prof:
         t = ctypes.c_float()
         lib.call("mmsa_event_elapsed_ms", e0, e1, ctypes.byref(t))
         flops += f
         ms += t.value
+        collect_gemm_profile.launches.append((f, by, t.value))
         lib.call("mmsa_event_destroy", e0)
         lib.call("mmsa_event_destroy", e1)
     return flops, ms
@@ -304,7 +306,7 @@ def convnext_mlp_fused(a, w1, w2, b1, b2, gamma, x, m, batch=1, stride_a=0, stri
         e0, e1 = _event(), _event()
         lib.call("mmsa_event_record", e0, _stream())
     lib.call("mmsa_convnext_mlp_fused", pa, lda, stride_a, w1.p.data_ptr(), stride_w1, w2.p.data_ptr(), stride_w2, _chk(b1), _chk(b2),
-             _chk(gamma), px, ldx, stride_x, m, c, batch, GEMM_MAX_GRID, a.fmt, _stream())
+             _chk(gamma), px, ldx, stride_x, m, c, batch, GEMM_MAX_GRID, a.fmt, _clamp_ptr(), _stream())
     if prof is not None:      # both contractions of the pair count towards the GEMM family (bench.py roofline)
         lib.call("mmsa_event_record", e1, _stream())
         prof.append((2.0 * 2.0 * m * c * 4 * c * batch, e0, e1, 4.0 * batch * (m * c * 3 + 2 * 4 * c * c)))

@@ -52,6 +52,10 @@ CONFIGS = {
     # a MIXED precision state at ViT-L: q / k x 3 in 6 of the 24 blocks only (two of them global blocks) -- the guard moves those six to
     # fp16 hi/lo pairs, the other eighteen stay on single fp16 operands, in one forward
     "vitl1024_mixed": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9, qk_scale=3.0, qk_blocks=[2, 5, 9, 14, 19, 23]),
+    # values beyond the fp16-based operand formats' range inside the ViT blocks (tests/weights.py large_magnitude): a post-LayerNorm channel of
+    # ~1e5 in front of qkv and of lin1, a GELU hidden unit of 6e4 -- the reference is fp32 and computes them; the model must go to its wide-range state and agree
+    "tiny256_wide": dict(kwargs=dict(_TINY, img_size=256), batch=1, seed=2, in_seed=6, large_mag=dict(ln2=(1, 5), ln1=(2, 9), gelu=(3, 17))),
+    "vitl1024_wide": dict(kwargs=_VITL, batch=1, seed=5, in_seed=9, large_mag=dict(ln2=(7, 100), ln1=(12, 333), gelu=(20, 1234))),
     "vith1024": dict(kwargs=_VITH, batch=1, seed=17, in_seed=18),
     "vitl800": dict(kwargs=_VITL800, batch=1, seed=19, in_seed=20, type="SAMAdapterbimodalMixModNewInTwinConvNEWwithcp"),
 }

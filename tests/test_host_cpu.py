@@ -22,6 +22,78 @@ def test_library_exports_every_declared_symbol():
     assert mmsa.lib.version() == mmsa.lib.ABI_VERSION == int(re.search(r"#define MMSA_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "mmsa_version.h")).read()).group(1))
 
 
+def _header_prototypes():
+    """(name -> (return kind, [argument kinds])) parsed from include/mmsa.h.  Kinds: P pointer, I int / unsigned, L long / int64, F float, D double, Z size_t."""
+    hdr = open(os.path.join(ROOT, "include", "mmsa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)                      # comments (also the ones between arguments)
+    hdr = "\n".join(l for l in hdr.split("\n") if not l.lstrip().startswith("#"))
+
+    def kind(t):
+        t = t.strip()
+        if "*" in t or t.startswith("mmsa_stream_t"):
+            return "P"
+        t = re.sub(r"\b(const|unsigned)\b", " ", t).split()
+        base = t[0] if t else "int"                                       # `unsigned pattern` -> base "pattern" is the NAME: unsigned int
+        return {"int": "I", "long": "L", "int64_t": "L", "float": "F", "double": "D", "size_t": "Z", "char": "I"}.get(base, "I")
+
+    protos = {}
+    for ret, name, args in re.findall(r"\b((?:const\s+)?[a-z_0-9]+\s*\*?)\s*(mmsa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = " ".join(args.split())
+        protos[name] = (kind(ret), [] if args in ("", "void") else [kind(a) for a in args.split(",")])
+    return protos
+
+
+def test_header_prototypes_match_ctypes_table():
+    """the header, the definitions and the ctypes table were three hand-kept copies compared by NAME only.  The definitions are
+    now compiled against the header (csrc/common.h includes it; next test); this one compares every prototype's argument COUNT and KIND with
+    mmsa/lib.py SIGNATURES, so that a trailing argument dropped from one of the two fails here and not as stack garbage in a launch."""
+    import ctypes
+    import mmsa
+    protos = _header_prototypes()
+    assert set(protos) == set(mmsa.lib.SIGNATURES) and len(protos) >= 45
+    ckind = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_uint: "I", ctypes.c_long: "L", ctypes.c_float: "F", ctypes.c_double: "D",
+             ctypes.c_size_t: "Z", ctypes.c_char_p: "P"}
+
+    def ck(t):
+        return ckind.get(t, "P")        # POINTER(...) types
+
+    for name, (ret, args) in protos.items():
+        got = [ck(t) for t in mmsa.lib.SIGNATURES[name]]
+        want = ["L" if a == "Z" else a for a in args]
+        got = ["L" if a == "Z" else a for a in got]                     # size_t and long: one 64-bit integer register either way
+        assert got == want, f"{name}: include/mmsa.h declares {''.join(want)} ({len(want)} arguments), mmsa/lib.py binds {''.join(got)} ({len(got)})"
+        rt = ck(mmsa.lib._RESTYPES.get(name, ctypes.c_int))
+        assert rt == ret, f"{name}: return kind {ret} in the header, {rt} in mmsa/lib.py"
+    # the check itself: dropping a trailing argument from either side is seen
+    broken = dict(mmsa.lib.SIGNATURES, mmsa_gemm_split3=mmsa.lib.SIGNATURES["mmsa_gemm_split3"][:-1])
+    assert [ck(t) for t in broken["mmsa_gemm_split3"]] != protos["mmsa_gemm_split3"][1]
+
+
+def test_the_library_sources_are_compiled_against_the_header(tmp_path):
+    """Every source that defines an entry point includes include/mmsa.h (through csrc/common.h, with the stream spelled hipStream_t), so a
+    definition that disagrees with its prototype is a compile error of the library build; shown here on a stand-in definition with g++
+    (the rule is the language's: two `extern "C"` declarations of one name with different parameter lists conflict)."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "multimodal-sam-adapter_amd", "csrc")
+    common = open(os.path.join(csrc, "common.h")).read()
+    assert '#include "../../include/mmsa.h"' in common and "#define MMSA_BUILDING_LIBRARY" in common
+    for f in glob.glob(os.path.join(csrc, "*.hip")):
+        src = open(f).read()
+        if re.search(r'extern "C" (?:int|long|const char\*) mmsa_', src):
+            assert re.search(r'#include "(common|gemm_v2_shared)\.h"', src), f"{f} defines entry points without the header"
+    inc = os.path.join(ROOT, "include")
+    good = tmp_path / "good.cpp"
+    good.write_text('#include "mmsa.h"\nextern "C" int mmsa_zero_bytes(void* p, size_t bytes, mmsa_stream_t stream) { (void)p; (void)bytes; (void)stream; return 0; }\n')
+    bad = tmp_path / "bad.cpp"
+    bad.write_text('#include "mmsa.h"\nextern "C" int mmsa_zero_bytes(void* p, size_t bytes) { (void)p; (void)bytes; return 0; }\n')
+    assert subprocess.run(["g++", "-fsyntax-only", "-I", inc, str(good)], capture_output=True).returncode == 0
+    r = subprocess.run(["g++", "-fsyntax-only", "-I", inc, str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "conflict" in r.stderr
+    # and the header is plain C (a cgo / JNI binding compiles it as such)
+    assert subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-pedantic", "-Werror", os.path.join(inc, "mmsa.h")], capture_output=True).returncode == 0
+
+
 def test_state_dict_contract_with_the_constructor_switches_off(golden_dir):
     """with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34): the parameter tree of the reference built that way."""
     import mmsa
@@ -176,6 +248,49 @@ def test_data_parallel_harness_gloo_world2():
     assert s0 == s1 == 1.5
 
 
+def _logits_gather_worker(rk, ws, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rk, world_size=ws)
+    from mmsa.dist import LogitsGather, allgather_logits
+    g = LogitsGather()
+    local = torch.zeros(2 if rk == 0 else 1, 3)           # ragged: a global batch of 3 over 2 ranks
+    hs, log = [], []
+    for k in range(4):
+        local.fill_(10.0 * k + rk)                        # "replay k" overwrites the SAME logits buffer
+        hs.append(g.submit(local, global_batch=3))
+        log.append(("submit", k))
+        if k >= 1:                                        # step k is under way: only now is step k - 1 collected
+            r_ = hs[k - 1].result()
+            log.append(("collect", k - 1))
+            assert r_.shape == (3, 3) and r_[:, 0].tolist() == [10.0 * (k - 1), 10.0 * (k - 1), 10.0 * (k - 1) + 1], r_
+    last = hs[-1].result()
+    same = torch.equal(last, allgather_logits(local, 3))  # the synchronous form gives the same tensor
+    q.put((rk, log, g.issued, same))
+    dist.destroy_process_group()
+
+
+def test_logits_gather_is_pipelined_behind_the_next_step_gloo_world2():
+    """mmsa.dist.LogitsGather (round 6): step k's gather is issued with async_op, reads a staging COPY of the logits (so the next step may overwrite the
+    buffer at once), and is collected after step k + 1 has been submitted; double-buffered staging / outputs; ragged shards; same tensor as the
+    synchronous allgather_logits."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_logits_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rk, log, issued, same in res:
+        assert same
+        assert issued == [(0, True), (1, True), (2, True), (3, True)]
+        assert log == [("submit", 0), ("submit", 1), ("collect", 0), ("submit", 2), ("collect", 1), ("submit", 3), ("collect", 2)]
+
+
 def _run_bench_stub(extra_env, args=("--gpus", "2", "--steps", "3", "--warmup", "1"), timeout=240):
     import subprocess
     import sys
@@ -200,6 +315,7 @@ def test_bench_rank_body_gloo_world2():
     assert 20.0 <= line["ms_per_step"] < 200.0
     assert abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
     assert line["roofline"] is None and line["cpu_baseline"] is None and line["verified"] is None
+    assert line["config"]["collective_overlap"] == {"next_step_enqueued_before_previous_gather_was_collected": 2, "collected": 4}
 
 
 def test_bench_rank_body_gloo_world8_with_ragged_shards():
@@ -214,6 +330,11 @@ def test_bench_rank_body_gloo_world8_with_ragged_shards():
     assert line["chains_probe_ms"] == {"chains_ms": 12.0, "one_chain_ms": 50.0}
     assert 80.0 <= line["ms_per_step"] < 400.0
     assert abs(line["value"] - 13 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-2 * line["value"]
+    # round 6: the gather of step k is collected only after step k + 1 has been enqueued -- (warm-up 1 + 2 timed steps) of which the
+    # first of each loop has no predecessor -> 1 overlapped hand-over, every gather collected (the drains included) -- and each rank takes its share of the
+    # host threads before it generates the seeded parameters
+    assert line["config"]["collective_overlap"] == {"next_step_enqueued_before_previous_gather_was_collected": 1, "collected": 3}
+    assert line["config"]["host_threads_per_rank"] == max(1, (os.cpu_count() or 1) // 8)
 
 
 def test_bench_parent_stops_the_job_when_a_rank_dies():

@@ -64,6 +64,9 @@ def _check_model(golden_dir, name, full):
     torch.manual_seed(0)
     m = R.OracleEncoder(**cfg["kwargs"])
     sd = seeded_state_dict(m, seed=cfg["seed"])
+    if cfg.get("large_mag"):   # values beyond the fp16-based operand formats' range inside the ViT blocks (tests/weights.py large_magnitude)
+        from tests.weights import large_magnitude
+        sd = large_magnitude(sd, cfg["large_mag"])
     assert abs(weights_checksum(sd) - float(g["weights_checksum"])) <= 1e-6 * float(g["weights_checksum"])
     m.load_state_dict(sd)
     x = make_input(cfg)
@@ -86,10 +89,11 @@ def _check_model(golden_dir, name, full):
             assert (got_full - ref_full).abs().max().item() <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel"])
+@pytest.mark.parametrize("name", ["tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel", "tiny256_wide"])
 def test_oracle_tiny_models(golden_dir, name):
     """224: window padding 14->14 none, rel-pos interpolation (pretrained 256); 256: pad 16->28; 320: pad 20->28; 256_plain: the
-    constructor switches off -- with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34, AM:485-500, BK:91-92, BK:326); 256_norel: use_rel_pos = qkv_bias = False (IE:317,320-327)."""
+    constructor switches off -- with_cffn / use_extra_extractor / add_vit_feature = False (BK:32-34, AM:485-500, BK:91-92, BK:326); 256_norel: use_rel_pos = qkv_bias = False (IE:317,320-327);
+    256_wide: post-LayerNorm channels of ~1e5 and a GELU hidden unit of 6e4 inside the ViT blocks (beyond the fp16-based operand formats' range)."""
     _check_model(golden_dir, name, full=True)
 
 

@@ -73,3 +73,30 @@ def peaky_attention(sd, embed_dim, factor, blocks=None):
             v[:2 * embed_dim] *= factor
             out[k] = v
     return out
+
+
+def large_magnitude(sd, spec):
+    """`sd` re-parametrised so that intermediate tensors of the ViT blocks leave the range of the fp16-based operand formats (+-57344 / +-65504) while the
+    function the model computes stays an ordinary one -- the reference computes in fp32 and is indifferent.  `spec` = dict with
+      ln2: (block, channel)  norm2.weight[channel] x 3e4 and column `channel` of mlp.lin1.weight / 3e4: the post-LayerNorm plane that feeds lin1 holds ~1e5 there;
+      ln1: (block, channel)  the same for norm1 and attn.qkv;
+      gelu: (block, unit)    mlp.lin1.bias[unit] = 6e4 and column `unit` of mlp.lin2.weight x 1e-4: the GELU hidden activation of that unit is ~6e4 in every token.
+    The fixtures `*_wide` are captured from the imported reference with these weights (tools/oracle/make_golden.py)."""
+    out = dict(sd)
+
+    def mod(key):
+        out[key] = out[key].clone()
+        return out[key]
+    if "ln2" in spec:
+        b, c = spec["ln2"]
+        mod(f"blocks.{b}.norm2.weight")[c] *= 3.0e4
+        mod(f"blocks.{b}.mlp.lin1.weight")[:, c] /= 3.0e4
+    if "ln1" in spec:
+        b, c = spec["ln1"]
+        mod(f"blocks.{b}.norm1.weight")[c] *= 3.0e4
+        mod(f"blocks.{b}.attn.qkv.weight")[:, c] /= 3.0e4
+    if "gelu" in spec:
+        b, j = spec["gelu"]
+        mod(f"blocks.{b}.mlp.lin1.bias")[j] = 6.0e4
+        mod(f"blocks.{b}.mlp.lin2.weight")[:, j] *= 1.0e-4
+    return out

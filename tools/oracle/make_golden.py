@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
 
 import ref_import  # noqa: E402
-from tests.weights import peaky_attention, seeded_state_dict  # noqa: E402
+from tests.weights import large_magnitude, peaky_attention, seeded_state_dict  # noqa: E402
 from tests.configs import CONFIGS, HEAD_CONFIGS, make_head_inputs, make_input, weights_checksum, probe_index  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -117,6 +117,8 @@ def gen_model(name, full):
     sd = seeded_state_dict(ref, seed=cfg["seed"])
     if cfg.get("qk_scale"):
         sd = peaky_attention(sd, cfg["kwargs"]["embed_dim"], cfg["qk_scale"], cfg.get("qk_blocks"))
+    if cfg.get("large_mag"):
+        sd = large_magnitude(sd, cfg["large_mag"])
     ref.load_state_dict(sd)
     x = make_input(cfg)
     with torch.no_grad():
@@ -310,7 +312,7 @@ def main():
     gen_msda_bwd()
     gen_msda()
     gen_bookkeeping()
-    for n in ("tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel"):
+    for n in ("tiny224", "tiny256", "tiny320", "tiny256_plain", "tiny256_norel", "tiny256_wide"):
         gen_model(n, full=True)
     gen_slide()
     gen_whole_dim()
@@ -324,6 +326,7 @@ def main():
         gen_model("vitl1024_b", full=False)
         gen_model("vitl1024_peaky", full=False)
         gen_model("vitl1024_mixed", full=False)
+        gen_model("vitl1024_wide", full=False)
 
 
 if __name__ == "__main__":
