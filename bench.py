@@ -341,7 +341,7 @@ def main():
             chains, nch = None, 1
     chain_probe = None
     if chains is not None and not a.force_chains:
-        # The overlap of the chains depends on how the runtime maps their streams onto hardware queues (another queue
+        # The overlap of the chains depends on how the runtime maps their streams onto hardware queues (LAB_NOTES.md 4.1: another queue
         # count costs 25-30 %).  Untimed probe: a few replays of both forms; the timed region runs the faster one.
         one_replay, one_out, one_graphed = capture(local_step)
         one_feats = feats[0]

@@ -54,7 +54,7 @@ struct AttnArgs {
 // VF = 1 (with PL): the v columns of the qkv planes carry an fp16 hi part (h8 planes: the qkv GEMM writes them that way, common.h
 // MMSA_CP_SPLIT) and P V runs as ONE fp16 MFMA per product with P rounded to fp16 -- instead of three bf16 MFMAs on hi/lo pairs of
 // both.  P <= 1 has 11 significant bits in fp16 and its rounding errors average out over the keys; measured on the CPU oracle
-// (ViT-B 512^2, every attention block): 2.9e-5 relative on f1..f4 against 1.2e-4 for a bf16 P.  Q K^T stays on
+// (ViT-B 512^2, every attention block): 2.9e-5 relative on f1..f4 against 1.2e-4 for a bf16 P (LAB_NOTES.md 4.1).  Q K^T stays on
 // bf16 hi/lo pairs: the scores are exponentiated.
 template <int HD, bool PL, bool FB, bool REL = false, int VF = 0>
 __global__ __launch_bounds__(256, (FB && HD <= 64) ? 2 : 1) void attn_kernel(AttnArgs a) {

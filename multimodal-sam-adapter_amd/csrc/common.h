@@ -17,7 +17,7 @@ void mmsa_set_error(const char* fmt, ...);
 
 // A/B and timing knobs.  The RELEASE library reads no environment variable and holds no writable global besides the thread-local error
 // string: MMSA_KNOB(name, default) is the default, as a constant.  A debug-knob build of one source (tools/build_variant.sh <so> <file>
-// -DMMSA_DEBUG_KNOBS) reads the integer environment variable `name` instead -- the experiments recorded in DESIGN.md were run that way.
+// -DMMSA_DEBUG_KNOBS) reads the integer environment variable `name` instead -- the experiments recorded in LAB_NOTES.md were run that way.
 #ifdef MMSA_DEBUG_KNOBS
 #include <stdlib.h>
 static inline int mmsa_knob_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -146,7 +146,7 @@ __host__ __device__ __forceinline__ int ilv(int k) { return ((k >> 5) << 6) | (k
 // (enum MMSA_FMT_B3 = 0, MMSA_FMT_H8 = 1, MMSA_FMT_H8C = 2, MMSA_FMT_F3 = 3: include/mmsa.h, included above)
 // Output-plane format argument of the GEMM (`cp_fmt`): bits 0..7 = format of the columns below the split, bits 8.. = split / 32;
 // columns >= split (a multiple of 32, 0 = no split) are written as MMSA_FMT_H8.  The qkv projection writes q and k as bf16 hi/lo
-// planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: DESIGN.md 4.1).
+// planes and v with an fp16 hi part this way (the attention kernels run P V on the fp16 MFMA: LAB_NOTES.md 4.1).
 #define MMSA_CP_BASE(f_) ((f_) & 0xff)
 #define MMSA_CP_SPLIT(f_) (((f_) >> 8) * 32)
 #define MMSA_CP_AT(f_, col_) ((MMSA_CP_SPLIT(f_) > 0 && (col_) >= MMSA_CP_SPLIT(f_)) ? MMSA_FMT_H8 : MMSA_CP_BASE(f_))
@@ -175,7 +175,7 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 
 // ---- "f3" planes (round 4): the bf16 hi/lo layout (32 hi values, then 32 lo values per k-block) with fp16 halves -- x = hi + lo, hi = fp16(x),
 // lo = fp16(x - hi): 22 significant bits where bf16 hi/lo has 16, the same three MFMAs per product (v_mfma_f32_16x16x32_f16: hh + hl + lh) at the
-// same rate.  Used where operand rounding is what the outputs see: the TwinConvNeXt chain, whose error GFFM multiplies by ~15 (DESIGN.md section 2;
+// same rate.  Used where operand rounding is what the outputs see: the TwinConvNeXt chain, whose error GFFM multiplies by ~15 (LAB_NOTES.md section 2;
 // tools/f3_study.py).  fp16's range is the price: values are clamped to +-65504 (LayerNorm outputs, GELU hidden activations and weights are far
 // inside it); below 6.1e-5 hi and lo become subnormal -- the MFMA does not flush them -- and the pair degrades gracefully to an absolute 6e-8.
 #define MMSA_F3_MAX 65504.0f

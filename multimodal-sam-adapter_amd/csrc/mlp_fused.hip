@@ -4,7 +4,7 @@
 //
 // Why.  At C = 96 the two GEMMs have 3 k-tiles per output tile against an epilogue that writes (pw1) and an operand stream that
 // re-reads (pw2) the 4C-wide hidden tensor -- 403 MB per block at stage 0, batch 2: both launches are bound by their epilogues /
-// operand staging, not by the matrix pipe.  Here a workgroup keeps the A image of a 128-row tile in LDS (48 KiB)
+// operand staging, not by the matrix pipe (LAB_NOTES.md 4.1).  Here a workgroup keeps the A image of a 128-row tile in LDS (48 KiB)
 // and walks the hidden dimension in chunks of 64 columns, two steps per chunk: step A computes the chunk's hidden values (K = C: the
 // whole W1 slice of the chunk is ONE 24 KiB ring slot), applies bias + GELU, splits them and writes them as an A-operand image into
 // LDS; step B consumes that image as the K = 64 slice of the second contraction (the W2 slice of the chunk is again one 24 KiB slot)

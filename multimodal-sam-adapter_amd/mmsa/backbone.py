@@ -211,7 +211,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # fuse_convnext_mlp, attention_precision, attention_guard): set it before the first forward, or call invalidate() after changing it; the A/B tools pass
     # them through `bench.py --set attr=value`.  No environment variable changes what this module computes.
     # "attnv" = the attention kernels run P V on the fp16 MFMA: the v third of the qkv planes (GEMM output and bias rows) is h8-encoded
-    # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study); the kernels with the rel-pos terms
+    # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study, LAB_NOTES.md 4.1); the kernels with the rel-pos terms
     # fused run Q K^T and the rel-pos terms on fp16 hi parts too -- per block, and only while its logits are small (_attn_mode).
     H8_DEFAULT = ("vit", "inter", "up", "attnv")
     attention_precision = "auto"   # 'auto' | 'f16' | 'b3': operand precision INSIDE the attention kernels where the "attnv" site allows fp16 (_attn_mode)
@@ -220,7 +220,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # (h8 / h8c) / +-65504 (f3); the reference is fp32 and has no such limit.  A forward -- or the pack itself -- that had to clamp (the clamp watch word)
     # switches the MODEL to its wide-range state: every GEMM site that travels on fp16-based planes (ViT blocks, interactions, up-conv, TwinConvNeXt) is
     # repacked on bf16 hi/lo pairs, which have fp32's exponent range (2^-17 per product instead of 2^-15.6 / 2^-22: the formats of rounds 1-3, error
-    # budget in DESIGN.md section 2), and the forward runs again -- exactly the contract of the attention logit guard: eager forwards re-route themselves,
+    # budget in LAB_NOTES.md section 2), and the forward runs again -- exactly the contract of the attention logit guard: eager forwards re-route themselves,
     # graph owners see `check_attention_guard()` report every block as moved and capture again.  The state is sticky (it travels with the packed file) and
     # one-way.  What stays fp16-based in every mode: the planes the attention kernels read (q, k, v, bias rows, rel-pos tables; |x| <= 65504 / 57344) --
     # a q . k with such entries is a logit beyond 1e9, where fp32 softmax itself is a one-hot of rounding noise; that case still raises OperandRangeError.
@@ -407,7 +407,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         if "vit" in h8_sites and D % 64 == 0 and Da % 64 == 0 and hidden_ % 64 == 0:
             vfmt = ops.FMT_H8C if (min(D, Da, hidden_) >= 512 and self._h8c_wanted()) else ops.FMT_H8
         pk["vit_fmt"] = vfmt
-        # LayerNorm fold (IE:396-421): norm1 / norm2 of the ViT blocks live in their consumer GEMMs.  The producer of the
+        # LayerNorm fold (IE:396-421; LAB_NOTES.md 4.2): norm1 / norm2 of the ViT blocks live in their consumer GEMMs.  The producer of the
         # residual stream (proj, lin2, the injector's output projection) also writes the stream as planes and per-row strip sums; qkv / lin1
         # run on W o w and compute rstd * (x W'^T - mean * colsum(W')) + (W b + bias) in their epilogue.  tools/lnfold_study.py: same error as
         # LayerNorm + GEMM on the seeded weights, + 1.5e-5 at |mean| = 4.5 std.  Needs whole 128-column tiles and 64-column strips.
@@ -444,18 +444,23 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # --- TwinConvNeXt
         cnx_f16 = self._cnx_f16_wanted()
 
-        def cfmt(w2d):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path):
+        def cfmt(w2d, pw=0):   # "cnx" in h8_sites (NOT a default: the 36-block chain is the error-sensitive part of the path, LAB_NOTES.md section 2):
             # h8 operands for the pointwise convs whose two contraction lengths (C and 4C) are multiples of 64 and that do not run on the fused stage-0 kernel
-            # ("cnx2": stage 2 alone -- the selective variant of tools/cnx_h8_study.py, measured and left off: DESIGN.md section 4.2)
+            # ("cnx2": stage 2 alone -- the selective variant of tools/cnx_h8_study.py, measured and left off: LAB_NOTES.md section 4.2)
             c_ = min(w2d.shape)
             on = "cnx" in h8_sites or ("cnx2" in h8_sites and c_ == self.channels[2])
             if on and c_ % 64 == 0 and not ops.convnext_mlp_fused_supported(c_):
                 return ops.FMT_H8
+            # "cnx2p2" (round 6; NOT a default): pointwise_conv2 of stage 2 alone (K = 4C = 1536: 12 k-tile pairs, the h8c kernel's regime) on
+            # h8c planes -- two matrix units per product instead of three; pointwise_conv1 stays on f3 and writes its GELU output as h8c planes.
+            # tools/cnx_precision_trade.py + profiles/r06_cnx_precision_trade.txt: f3 / f4 error x 2 / x 3.5 at ViT-B on the oracle for the step time measured there
+            if "cnx2p2" in h8_sites and pw == 2 and c_ == self.channels[2] and (4 * c_) % 64 == 0 and 4 * c_ >= 512 and self._h8c_wanted():
+                return ops.FMT_H8C
             # default (round 4): fp16 hi/lo pairs ("f3": 22 significant bits, the same three MFMAs per product as bf16 hi/lo) for the whole
-            # chain (stem, downsample and pointwise convs) -- its operand rounding is what GFFM amplifies (tools/f3_study.py)
+            # chain (stem, downsample and pointwise convs) -- its operand rounding is what GFFM amplifies (LAB_NOTES.md section 2, tools/f3_study.py)
             return ops.FMT_F3 if cnx_f16 else ops.FMT_B3
         # ConvNeXt LayerNorm fold (round 3): OPT-IN (`model.fold_convnext_ln = True`).  Built, tested, and measured at
-        # ViT-L 1024^2: step -0.17 ms, golden probes 2.9e-4 -> 4.6e-4 (the chain's error is amplified ~15 x by GFFM, DESIGN.md sections 2 and 4.2):
+        # ViT-L 1024^2: step -0.17 ms, golden probes 2.9e-4 -> 4.6e-4 (the chain's error is amplified ~15 x by GFFM, LAB_NOTES.md sections 2 and 4.2):
         # not worth the margin.  Applies to the stages that run pointwise_conv1 as a GEMM (not the fused stage-0 pair), 64-channel chunks.
         want_cnx = bool(getattr(self, "fold_convnext_ln", False))
         pk["cnx_f16"] = cnx_f16
@@ -482,7 +487,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                     blk = dict(dw=dw.reshape(dw.shape[0], 49).t().contiguous(), dw_b=sd[b + "depthwise_conv.bias"],
                                nw=sd[b + "norm.weight"], nb=sd[b + "norm.bias"],
                                pw1=planes(sd[b + "pointwise_conv1.weight"], fmt=cfmt(sd[b + "pointwise_conv1.weight"])), pw1_b=sd[b + "pointwise_conv1.bias"],
-                               pw2=planes(sd[b + "pointwise_conv2.weight"], fmt=cfmt(sd[b + "pointwise_conv2.weight"])), pw2_b=sd[b + "pointwise_conv2.bias"],
+                               pw2=planes(sd[b + "pointwise_conv2.weight"], fmt=cfmt(sd[b + "pointwise_conv2.weight"], 2)), pw2_b=sd[b + "pointwise_conv2.bias"],
                                gamma=sd[b + "gamma"])
                     if fold_cnx(self.channels[i]):
                         # the block's LayerNorm (TC:103-106) folded into pointwise_conv1: W o w as planes, their column sums as the kernel
@@ -501,8 +506,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         def stack2(fx, fy):
             if isinstance(fx, ops.Planes):
                 buf = torch.cat([fx.p, fy.p], 0).contiguous()
-                pl = ops.Planes(buf[:fx.n], fx.n, fx.k, fx.kpad, fx.fmt, fx.weight)
-                pl.full = buf           # keeps the second batch alive; batch stride = n * 2 * kpad elements
+                pl = ops.Planes(buf[:fx.p.shape[0]], fx.n, fx.k, fx.kpad, fx.fmt, fx.weight)    # (h8c planes hold row PAIRS: n / 2 tensor rows)
+                pl.full = buf           # keeps the second batch alive; batch stride = Planes.batch_stride(n)
                 return pl
             return torch.stack([fx, fy], 0).contiguous()
 
@@ -1301,7 +1306,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
             d = ws.get(t + "tmp", 2 * P, c)
             wf = st["stages"][i][0]["pw1"].fmt          # operand format of this stage's pointwise convs (bf16 hi/lo unless "cnx" is an h8 site)
             n = ws.planes(t + "n", 2 * P, c, fmt=wf)
-            hbuf = ws.planes(t + "h", 2 * P, 4 * c, fmt=wf)
+            hbuf = ws.planes(t + "h", 2 * P, 4 * c, fmt=st["stages"][i][0]["pw2"].fmt)   # (pointwise_conv2's operand format: f3 like pw1, or h8c with the "cnx2p2" site)
             # narrow stages (C = 96 / 192): the pointwise pair as ONE kernel that keeps the 4C hidden tensor in LDS (csrc/mlp_fused.hip)
             fuse_mlp = ops.convnext_mlp_fused_supported(c) and bool(getattr(self, "fuse_convnext_mlp", True))
             fold = "pw1f" in st["stages"][i][0] and not fuse_mlp and hh % 8 == 0 and wwd % 8 == 0 and P >= 128
@@ -1310,7 +1315,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 mr = ws.get(t + "mr", 2 * P, 2)
             for blk in st["stages"][i]:  # ConvNeXtBlock TC:98-132
                 if fold:
-                    # LayerNorm folded (like the ViT blocks'): the depthwise conv writes its RAW output as planes + per pixel and
+                    # LayerNorm folded (like the ViT blocks', LAB_NOTES.md 4.2): the depthwise conv writes its RAW output as planes + per pixel and
                     # 64-channel chunk (sum, sum of squares); pointwise_conv1 runs on W o w and normalises in its epilogue
                     ops.dwconv(cur, blk["dw"], blk["dw_b"], None, 2 * B, hh, wwd, 7, imgs_per_group=B, out_planes=n, rowstats_out=rs)
                     ops.rowstats_finalize(rs, 2 * P, c, 1e-6, mr)
@@ -1328,9 +1333,9 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                                            stride_w2=blk["pw2"].n * 2 * blk["pw2"].kpad, stride_x=P * c)
                     continue
                 ops.gemm(n, blk["pw1"], bias=blk["pw1_b"], act="gelu", out_planes=hbuf, batch=2, m=P, stride_a=P * 2 * n.kpad,
-                         stride_w=blk["pw1"].n * 2 * blk["pw1"].kpad, stride_bias=4 * c, stride_cp=P * 2 * hbuf.kpad)
+                         stride_w=blk["pw1"].n * 2 * blk["pw1"].kpad, stride_bias=4 * c, stride_cp=hbuf.batch_stride(P))
                 ops.gemm(hbuf, blk["pw2"], cur, bias=blk["pw2_b"], colscale=blk["gamma"], resid=cur, batch=2, m=P,
-                         stride_a=P * 2 * hbuf.kpad, stride_w=blk["pw2"].n * 2 * blk["pw2"].kpad, stride_bias=c,
+                         stride_a=hbuf.batch_stride(P), stride_w=blk["pw2"].batch_stride(blk["pw2"].n), stride_bias=c,
                          stride_r=P * c, stride_c=P * c)
             nw, nb = st["out_norm"][i]
             ops.layernorm(cur, nw, nb, 1e-6, tcat[i], group_rows=P, w_gstride=c, y_gcol=c, y_wrap=True,

@@ -2,7 +2,7 @@
 
 Why.  Images are independent in the eval-mode forward, and every GEMM of the path is ONE persistent grid whose
 workgroups all reach their epilogue at the same moment: the chip alternates between k loops (matrix pipe busy, memory idle) and
-epilogues (a store burst at HBM speed, matrix pipe idle) -- DESIGN.md section 4.1.  Two chains that each own half of the CUs
+epilogues (a store burst at HBM speed, matrix pipe idle) -- LAB_NOTES.md section 4.1.  Two chains that each own half of the CUs
 (`ops.GEMM_MAX_GRID`) run those phases against each other.  Measured on one MI355X, ViT-L 1024^2, batch 2 (tools/chains_bench.py,
 bench.py --chains 1 / 2 on the same box): one chain of 2 images 37.3-37.5 ms, two chains of 1 image 35.7-36.4 ms (encoder only), 38.8
 against 37.3 ms with the head; the results are bit-identical (the kernels' arithmetic does not depend on the batch size or on the

@@ -106,7 +106,8 @@ def _dec(o, dev):
     if isinstance(o, dict) and o.get("__planes__"):
         buf = o["p"].to(dev)
         if o["stacked"]:
-            pl = ops.Planes(buf[:o["n"]], o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False), o.get("split", 0))
+            rows_ = ops.planes_shape(o["n"], o["k"], o.get("fmt", ops.FMT_B3))[0]      # (h8c planes hold row pairs)
+            pl = ops.Planes(buf[:rows_], o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False), o.get("split", 0))
             pl.full = buf
             return pl
         return ops.Planes(buf, o["n"], o["k"], o["kpad"], o.get("fmt", ops.FMT_B3), o.get("weight", False), o.get("split", 0))

@@ -123,7 +123,7 @@ def test_fewer_than_128_token_rows_with_the_layernorm_fold():
 
 
 def test_convnext_layernorm_fold_opt_in(golden_dir):
-    """`fold_convnext_ln` (opt-in: at ViT-L it costs more error than its 0.17 ms are worth): the ConvNeXt blocks' LayerNorm
+    """`fold_convnext_ln` (opt-in: at ViT-L it costs more error than its 0.17 ms are worth, LAB_NOTES.md 4.2): the ConvNeXt blocks' LayerNorm
     folded into pointwise_conv1 at the stages where the shapes allow it; within the gate against the golden, and not bit-equal to the default."""
     import mmsa
     cfg, orc, m = _build("tiny320")
@@ -489,7 +489,7 @@ def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_di
     every qkv projection scaled so that the logits are 9 x larger (max ~ 36), 'auto' falls back to bf16 hi/lo operands (the whole block:
     qkv / proj / MLP weights too) and stays within the gate against the oracle on the SAME scaled weights, where the forced fp16 kernels
     do not.  (At 16 x -- max |logit| ~ 64 -- the fallback measured 1.06e-3, forced fp16 far more: the logit error of a 2^-17 product
-    grows with the logit, so ~60 is where bf16 hi/lo itself leaves the 1e-3 gate)"""
+    grows with the logit, so ~60 is where bf16 hi/lo itself leaves the 1e-3 gate; LAB_NOTES.md section 2.)"""
     import mmsa
     cfg, orc, m = _build("vitb512")
     x = make_input(cfg)

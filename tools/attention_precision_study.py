@@ -1,6 +1,6 @@
 """Operand-precision study of the SAM attention blocks on the CPU oracle (test infrastructure, never on the product path):
 which operands of Attention.forward (IE:465-501) tolerate rounding to fp16 / bf16, measured end to end on f1..f4 against the plain
-fp32 oracle.  The numbers behind DESIGN.md section 2 "Attention on single fp16 MFMAs".
+fp32 oracle.  The numbers behind LAB_NOTES.md section 2 "Attention on single fp16 MFMAs".
     python tools/attention_precision_study.py [tiny256|vitb512 ...] [--logit-scale 1,4,16]
 --logit-scale S: the q and k rows of every qkv projection (weights and biases) are multiplied by sqrt(S), i.e. every attention logit by
 S -- the seeded test weights give logits of a few units, released SAM checkpoints have much peakier attention; the

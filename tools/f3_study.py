@@ -1,5 +1,5 @@
 """Would fp16 hi + fp16 lo operands (22 significant bits, the same three MFMAs per product as bf16 hi/lo: hh + hl + lh on the fp16 MFMA) buy parity
-margin where bf16 hi/lo (16 bits) is used today -- the TwinConvNeXt chain and the neck's 1 x 1 convs, whose error GFFM amplifies?
+margin where bf16 hi/lo (16 bits) is used today -- the TwinConvNeXt chain and the neck's 1 x 1 convs, whose error GFFM amplifies (LAB_NOTES.md section 2)?
 CPU oracle emulation (test infrastructure, never on the product path): f1..f4 against the plain fp32 oracle.   python tools/f3_study.py [vitb512]"""
 import os
 import sys

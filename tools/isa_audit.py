@@ -1,7 +1,7 @@
 """ISA audit of the built library: disassembles every gfx950 code object of libmmsa_hip.so and reports, per kernel, the
 packed-fp32 instructions (v_pk_fma/mul/add_f32) whose LOW result lane selects the HIGH half of a source register pair
 (an `op_sel:[..1..]` operand).  hipcc's SLP vectoriser produces that form from neighbouring scalar FMAs, and it is the form
-that returned wrong upper halves in dwpair_gate_kernel under concurrent streams in round 1; the library is
+that returned wrong upper halves in dwpair_gate_kernel under concurrent streams in round 1 (LAB_NOTES.md section 4); the library is
 built with -fno-slp-vectorize and must contain none.  python tools/isa_audit.py [path/to/lib.so] -> exit code 1 if any is found."""
 import os
 import re

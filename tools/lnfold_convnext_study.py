@@ -2,7 +2,7 @@
 the ViT blocks), on the CPU oracle with the kernels' bf16 hi/lo arithmetic (test infrastructure, never on the product path).
 'today' = LN, then the bf16 hi/lo product; 'folded' = bf16 hi/lo product on the RAW depthwise-conv output against W o w,
 epilogue rstd * (acc - mean * colsum) + b'.  TwinConvNeXt is the error-sensitive chain (its error is amplified ~15 x by GFFM:
-DESIGN.md section 2), so what matters is the twin stage outputs and f1..f4.
+LAB_NOTES.md section 2), so what matters is the twin stage outputs and f1..f4.
     python tools/lnfold_convnext_study.py [vitb512]"""
 import os
 import sys
