@@ -122,6 +122,17 @@ int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes, const int
                     int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
                     float* clamp_max /* optional clamp watch word of out_planes, see Conventions */, mmsa_stream_t stream);
 
+/* mmsa_msda_fused on fp16 values (round 6; the model's opt-in `msda_value` attribute).  The gather is bound by the bytes it pulls through the CU's vector-memory
+ * pipe; `value_planes` = the value projection's output (ops/modules/ms_deform_attn.py:103-104) as MMSA_FMT_H8 ACTIVATION planes [batch * spatial_size, row stride
+ * ldvp >= 2 * num_heads * channels], written by that GEMM's own epilogue.  lo_bytes = 0: a corner reads the 8 fp16 hi values of a lane's 8 channels (half the
+ * bytes of fp32 values; the value is rounded to 11 significant bits); lo_bytes != 0: + their e5m2 lo bytes (3/4 of the bytes, ~14 bits).  Everything else as
+ * mmsa_msda_fused; channels % 8 == 0, num_heads * channels % 32 == 0. */
+int mmsa_msda_fused_planes(const uint16_t* value_planes, long ldvp, int lo_bytes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
+                           uint16_t* out_planes, long ldop, int out_fmt, int batch,
+                           int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
+                           float* clamp_max, mmsa_stream_t stream);
+
 /* --- GEMM (replaces F.linear / 1x1 conv / patchify conv / ConvTranspose2d 2x2 s2) ---------------------------
  * C = beta*resid + colscale[n] * alpha * act(A[M,K] W[N,K]^T + bias[n]); batch > 1 = strided batched (strides in
  * elements; strideW / strideBias may be 0 to share; colscale, when given, uses strideBias too).  K % 32 == 0.  resid_mod > 0: residual row = row % resid_mod

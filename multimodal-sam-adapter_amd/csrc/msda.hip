@@ -105,6 +105,116 @@ __global__ __launch_bounds__(256) void msda_kernel(
 }
 
 
+// ---- the gather on fp16 values (round 6; opt-in through the model's `msda_value` attribute).  The gather is bound by the bytes it pulls through the CU's
+// vector-memory pipe (64 B/clk: 128 B per corner, head and sample with fp32 values; LAB_NOTES 4.3 "(7)").  Here `value` arrives as H8 ACTIVATION PLANES
+// (common.h: per row and 32-channel block one 128-byte line = 32 fp16 hi values + four 16-byte chunks {8 e5m2(lo * 2^11) bytes | 8 q(hi) bytes}), written
+// by the value projection's own epilogue (cp_fmt = MMSA_FMT_H8, no fp32 output).  A lane owns 8 channels of a (query, head) pair and reads per corner
+//   LO = false: the 8 fp16 hi values (16 B): half the bytes, the value rounded to 11 significant bits (the oracle study: tools/msda_value_f16_study.py);
+//   LO = true : + the 8 lo bytes (8 B): 3/4 of the bytes, value = hi + lo / 2^11 to ~14 bits.
+// Same sampling arithmetic, same fused prologue (softmax over L*P, loc = ref + off / (W, H)) as msda_kernel<true>.
+__device__ __forceinline__ void msda_decode_hi8(const uint4 u, float* f) {
+  const __half2* h = reinterpret_cast<const __half2*>(&u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const float2 t = __half22float2(h[i]); f[2 * i] = t.x; f[2 * i + 1] = t.y; }
+}
+__device__ __forceinline__ void msda_decode_lo8(const uint2 b, float* f) {   // e5m2 = the top byte of an fp16 value
+  const unsigned w[4] = {__builtin_amdgcn_perm(0u, b.x, 0x010c000cu), __builtin_amdgcn_perm(0u, b.x, 0x030c020cu),
+                         __builtin_amdgcn_perm(0u, b.y, 0x010c000cu), __builtin_amdgcn_perm(0u, b.y, 0x030c020cu)};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const float2 t = __half22float2(*reinterpret_cast<const __half2*>(&w[i])); f[2 * i] = t.x; f[2 * i + 1] = t.y; }
+}
+template <bool LO>
+__global__ __launch_bounds__(256) void msda_planes_kernel(
+    const unsigned short* __restrict__ vp, long ldv, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ raw, long ldraw, const float* __restrict__ ref, float* __restrict__ out, long ldo,
+    unsigned short* __restrict__ op, long ldop, int op_fmt, int N, int S, int M, int D, int L, int Lq, int P, float* __restrict__ clamp_max) {
+  const int d8 = D >> 3;                        // lanes per (q, m) pair
+  const int op_kpad = MMSA_PAD64(M * D);
+  const unsigned pair = (mmsa_xcd_order(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) / (unsigned)d8;
+  const int c = ((threadIdx.x) % d8) * 8;       // blockDim.x is a multiple of d8
+  const unsigned npairs = (unsigned)N * (unsigned)Lq * (unsigned)M;
+  if (pair >= npairs) return;
+  const unsigned bq = pair / (unsigned)M;
+  const int m = (int)(pair - bq * (unsigned)M);
+  const int b = (int)(bq / (unsigned)Lq);
+  const int q = (int)(bq - (unsigned)b * (unsigned)Lq);
+  const int LP = L * P;
+  const float* offp = raw + bq * ldraw + (long)m * LP * 2;
+  const float* logp = raw + bq * ldraw + (long)M * LP * 2 + (long)m * LP;
+  float mx = -INFINITY;
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, logp[i]);
+  float ssum = 0.f;
+  for (int i = 0; i < LP; ++i) ssum += expf(logp[i] - mx);
+  const float inv = 1.0f / ssum;
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const int ch = m * D + c;                     // first of this lane's 8 channels: line ch / 32 of the row, halves (ch & 31) .. + 7 of its hi part
+  const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp) + (long)b * S * ldv * 2 + (long)(ch >> 5) * 128;
+  const int hi_off = (ch & 31) * 2, lo_off = 64 + ((ch & 31) >> 3) * 16;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const unsigned char* vl = vb + (long)lsi[l] * ldv * 2;
+    for (int p = 0; p < P; ++p) {
+      const float lx = rx + offp[(l * P + p) * 2] / (float)W;
+      const float ly = ry + offp[(l * P + p) * 2 + 1] / (float)H;
+      const float wgt = expf(logp[l * P + p] - mx) * inv;
+      const float h_im = ly * H - 0.5f;
+      const float w_im = lx * W - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lwf = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lwf;
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const bool ok[4] = {h_low >= 0 && w_low >= 0, h_low >= 0 && w_high <= W - 1, h_high <= H - 1 && w_low >= 0, h_high <= H - 1 && w_high <= W - 1};
+        const long pos[4] = {(long)h_low * W + w_low, (long)h_low * W + w_high, (long)h_high * W + w_low, (long)h_high * W + w_high};
+        const float cw[4] = {hh * hw * wgt, hh * lwf * wgt, lh * hw * wgt, lh * lwf * wgt};
+        uint4 uh[4];
+        uint2 ul[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {           // all corner loads of the sample in flight together
+          uh[k] = make_uint4(0u, 0u, 0u, 0u);
+          ul[k] = make_uint2(0u, 0u);
+          if (ok[k]) {
+            const unsigned char* rp = vl + pos[k] * ldv * 2;
+            uh[k] = *reinterpret_cast<const uint4*>(rp + hi_off);
+            if (LO) ul[k] = *reinterpret_cast<const uint2*>(rp + lo_off);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float f[8];
+          msda_decode_hi8(uh[k], f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = fmaf(cw[k], f[i], acc[i]);
+          if (LO) {
+            float g8[8];
+            msda_decode_lo8(ul[k], g8);
+            const float cl = cw[k] * (1.0f / 2048.0f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(cl, g8[i], acc[i]);
+          }
+        }
+      }
+    }
+  }
+  const float4 a0 = make_float4(acc[0], acc[1], acc[2], acc[3]), a1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  if (out) {
+    *reinterpret_cast<float4*>(out + bq * ldo + ch) = a0;
+    *reinterpret_cast<float4*>(out + bq * ldo + ch + 4) = a1;
+  }
+  if (op) {
+    float cw_ = 0.f;
+    clamp_see(cw_, a0);
+    clamp_see(cw_, a1);
+    clamp_report(clamp_max, cw_, mmsa_clamp_limit(op_fmt));
+    store_planes4_any(op, ldop, bq, op_kpad, ch, a0, op_fmt);
+    store_planes4_any(op, ldop, bq, op_kpad, ch + 4, a1, op_fmt);
+  }
+}
+
+
 // Generic path (any D, any dtype): one lane per output element, arithmetic in AT (float for f32 / f16 storage, double for f64).
 // Used for head widths the vector path does not cover (e.g. the reference's own known-answer fixture OPS/test.py:16-33 has
 // D = 2) and for the f16 / f64 instantiations of the reference's dispatch (ms_deform_attn_cuda.cu:64).
@@ -369,5 +479,34 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
                      level_start_index, nullptr, nullptr, raw, ldraw, ref_points, out, ldo, out_p, ldop, out_fmt, batch, spatial_size,
                      num_heads, channels, num_levels, num_query, num_point, clamp_max);
   MMSA_CHECK_LAUNCH("msda_fused");
+  return MMSA_OK;
+}
+
+// The same on fp16 values (msda_planes_kernel above): `value_planes` = the value projection's output as MMSA_FMT_H8 activation planes [batch * spatial_size,
+// >= 2 * num_heads * channels] (row stride ldvp in uint16, 128-byte aligned); lo_bytes != 0: the planes' e5m2 lo bytes are added (~14 bits instead of 11).
+extern "C" int mmsa_msda_fused_planes(const unsigned short* value_planes, long ldvp, int lo_bytes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const float* raw, long ldraw, const float* ref_points, float* out, long ldo,
+                                      unsigned short* out_p, long ldop, int out_fmt,
+                                      int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                      int num_query, int num_point, float* clamp_max, hipStream_t stream) {
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_F3, "msda_fused_planes: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(value_planes && spatial_shapes && level_start_index && raw && ref_points && (out || out_p), "msda_fused_planes: null pointer");
+  MMSA_CHECK_ARG(ldvp >= 2L * num_heads * channels && (ldvp & 63) == 0 && (((uintptr_t)value_planes) & 127) == 0 && ((num_heads * channels) & 31) == 0,
+                 "msda_fused_planes: value planes need a 128-byte aligned base, a row stride that is a multiple of 64 and >= 2 * heads * channels, heads * channels %% 32 == 0");
+  MMSA_CHECK_ARG(!out_p || (ldop >= (out_fmt == MMSA_FMT_H8C ? 3L * MMSA_PAD64(num_heads * channels) : 2L * num_heads * channels) && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
+                 "msda_fused_planes: bad output planes");
+  int rc = msda_check(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, "msda_fused_planes");
+  if (rc) return rc;
+  MMSA_CHECK_ARG(ldraw >= (long)num_heads * num_levels * num_point * 3, "msda_fused_planes: ldraw too small");
+  MMSA_CHECK_ARG(!out || (ldo >= (long)num_heads * channels && (ldo & 3) == 0 && (((uintptr_t)out) & 15) == 0), "msda_fused_planes: bad out / ldo");
+  MMSA_CHECK_ARG((channels & 7) == 0 && channels <= 2048, "msda_fused_planes: channels per head D=%d must be a multiple of 8", channels);
+  const long threads = (long)batch * num_query * num_heads * (channels >> 3);
+  MMSA_CHECK_ARG(threads < (1L << 31), "msda_fused_planes: problem too large for the 32-bit index arithmetic");
+  const int d8 = channels >> 3, bs = (256 / d8) * d8;
+  if (lo_bytes) hipLaunchKernelGGL(msda_planes_kernel<true>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, value_planes, ldvp, spatial_shapes, level_start_index, raw, ldraw,
+                                   ref_points, out, ldo, out_p, ldop, out_fmt, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, clamp_max);
+  else hipLaunchKernelGGL(msda_planes_kernel<false>, dim3(cdiv(threads, bs)), dim3(bs), 0, stream, value_planes, ldvp, spatial_shapes, level_start_index, raw, ldraw,
+                          ref_points, out, ldo, out_p, ldop, out_fmt, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, clamp_max);
+  MMSA_CHECK_LAUNCH("msda_fused_planes");
   return MMSA_OK;
 }

@@ -1110,12 +1110,20 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         ws, cfg = self._ws, self.cfg
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
         dv = ap["val"].n
-        val = ws.get("msda_val", B * S, dv)
-        ops.gemm(fn, ap["val"], val, bias=ap["val_b"], row_norm=f_rn)
+        # `msda_value` (round 6; default "f32"): "f16" / "f16lo" hand the gather its values as H8 activation planes written by the value projection's epilogue --
+        # half / three quarters of the bytes through the vector-memory pipe that bounds the gather (csrc/msda.hip msda_planes_kernel).  Not in the wide-range
+        # state (the planes clamp at +-57344), not for head widths the planes kernel does not take
+        vmode = getattr(self, "msda_value", "f32")
+        if vmode in ("f16", "f16lo") and not self._wide() and (dv // M) % 8 == 0 and dv % 32 == 0:
+            val = ws.planes("msda_valp", B * S, dv, fmt=ops.FMT_H8)
+            ops.gemm(fn, ap["val"], bias=ap["val_b"], row_norm=f_rn, out_planes=val)
+        else:
+            val = ws.get("msda_val", B * S, dv)
+            ops.gemm(fn, ap["val"], val, bias=ap["val_b"], row_norm=f_rn)
         raw = ws.get("msda_raw", B * Lq, ap["oa"].n)
         ops.gemm(qn, ap["oa"], raw, bias=ap["oa_b"], row_norm=q_rn)
         samp = ws.planes("msda_s", B * Lq, dv, fmt=ap["out"].fmt)
-        ops.msda_fused(val, ss, lsi, raw, ref, None, B, S, M, dv // M, L, Lq, Pn, out_planes=samp)
+        ops.msda_fused(val, ss, lsi, raw, ref, None, B, S, M, dv // M, L, Lq, Pn, out_planes=samp, lo_bytes=vmode == "f16lo")
         if stream_out is not None:
             ops.gemm(samp, ap["out"], out, bias=ap["out_b"], resid=resid, colscale=colscale, out_planes=stream_out[0], rowstats_out=stream_out[1])
         else:

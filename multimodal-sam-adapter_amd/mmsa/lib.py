@@ -41,6 +41,7 @@ SIGNATURES = {
     "mmsa_ms_deform_attn_forward": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mmsa_ms_deform_attn_backward": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mmsa_msda_fused": [P, P, P, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, P, P],
+    "mmsa_msda_fused_planes": [P, L, I, P, P, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, P, P],
     "mmsa_gemm_split3": [P, P, L, L, P, L, P, L, P, P, L, L, I, F, P, L, L, P, L, L, I, I, I, I, I, F, I, I, I, I, I, I, I, P, P, P, I, P, P],
     "mmsa_convnext_mlp_fused": [P, L, L, P, L, P, L, P, P, P, P, L, L, I, I, I, I, I, P, P],
     "mmsa_rowstats_finalize": [P, I, I, I, F, P, P],

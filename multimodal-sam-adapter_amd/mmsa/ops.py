@@ -398,9 +398,25 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
 
 
 def msda_fused(value2d, spatial_shapes, level_start_index, raw, ref_points, out, batch, spatial, heads, d, levels, lq, points,
-               out_planes=None):
-    pv, _, _, _ = _mat(value2d, "value")
+               out_planes=None, lo_bytes=False):
+    """Fused MSDeformAttn middle part (include/mmsa.h).  value2d: fp32 [batch * spatial, heads * d] -- or H8 activation Planes of that matrix (the gather on fp16
+    values, mmsa_msda_fused_planes; `lo_bytes`: add the planes' e5m2 lo bytes)."""
     pr, _, _, ldraw = _mat(raw, "raw")
+    if isinstance(value2d, Planes):
+        if value2d.fmt != FMT_H8 or value2d.weight or value2d.split:
+            raise RuntimeError("mmsa.msda_fused: value planes must be H8 activation planes")
+        pvp, _, _, ldvp = value2d.mat("value planes")
+        po, ldo = None, 0
+        if out is not None:
+            po, _, _, ldo = _mat(out, "out")
+        pp, ldp = None, 0
+        if out_planes is not None:
+            pp, _, _, ldp = out_planes.mat("out planes")
+        lib.call("mmsa_msda_fused_planes", pvp, ldvp, 1 if lo_bytes else 0, _chk(spatial_shapes, torch.int64), _chk(level_start_index, torch.int64), pr, ldraw,
+                 _chk(ref_points), po, ldo, pp, ldp, out_planes.fmt if out_planes is not None else FMT_B3,
+                 batch, spatial, heads, d, levels, lq, points, _clamp_ptr(), _stream())
+        return out if out is not None else out_planes
+    pv, _, _, _ = _mat(value2d, "value")
     po, ldo = None, 0
     if out is not None:
         po, _, _, ldo = _mat(out, "out")

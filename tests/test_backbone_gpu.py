@@ -426,6 +426,35 @@ def test_packed_checkpoint_round_trip(tmp_path):
     other = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **CONFIGS["tiny224"]["kwargs"]))
     with pytest.raises(RuntimeError, match="different architecture"):
         C.load_packed(other, path, device=DEV)
+    # a file of an earlier pack format is refused (format 10 files would have passed every check and died in the first forward)
+    blob = torch.load(path, map_location="cpu")
+    blob["format"] = C.PACK_FORMAT - 1
+    old = str(tmp_path / "old.packed.pth")
+    torch.save(blob, old)
+    with pytest.raises(RuntimeError, match="not an mmsa packed checkpoint"):
+        C.load_packed(m2, old, device=DEV)
+    # pack-time settings that drive the run-time path are compared: a file packed with the adapter-token LayerNorm fold is not loaded into a model without it
+    m3 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+    m3.share_c_norm = False
+    with pytest.raises(RuntimeError, match="repack"):
+        C.load_packed(m3, path, device=DEV)
+    # the wide-range state (backbone.range_fallback) travels with the file: weights with values beyond the fp16-based formats' range -> the first forward
+    # goes wide -> save -> a fresh model loads the bf16-pair planes, is wide without ever clamping, and returns the same tensors
+    from tests.weights import large_magnitude
+    from mmsa import ops
+    wcfg = CONFIGS["tiny256_wide"]
+    mw = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **wcfg["kwargs"]))
+    mw.load_state_dict(large_magnitude(seeded_state_dict(mw, seed=wcfg["seed"]), wcfg["large_mag"]), strict=True)
+    refw = [f.clone() for f in mw(x)[0]]
+    assert mw._wide()
+    wpath = str(tmp_path / "wide.packed.pth")
+    C.save_packed(mw, wpath, device=DEV)
+    mw2 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **wcfg["kwargs"]))
+    C.load_packed(mw2, wpath, device=DEV)
+    assert mw2._wide() and mw2._packed["wide"] and mw2._packed["blocks"][0]["qkv"].fmt == ops.FMT_B3
+    mw2._pack = boom
+    for a, b in zip(mw2(x)[0], refw):
+        assert torch.equal(a, b)
 
 
 def _build_cfg(name):

@@ -170,6 +170,42 @@ def test_msda_and_dwconv_planes_outputs(ops):
     assert_close(planes_to_float(p), ref, tol=5e-5, what="dwconv planes")
 
 
+@pytest.mark.parametrize("M,D,L,shapes", [(4, 32, 1, [(10, 10)]), (2, 32, 3, [(12, 12), (6, 6), (3, 3)]), (3, 64, 2, [(9, 7), (5, 4)]), (4, 8, 1, [(6, 5)])])
+def test_msda_gather_on_fp16_value_planes(ops, M, D, L, shapes):
+    """mmsa_msda_fused_planes (round 6): the deformable-attention gather with `value` as H8 activation planes -- the 8 fp16 hi values of a lane's channels per
+    corner (lo_bytes = False: the value rounded to 11 significant bits) or hi + e5m2 lo bytes (~14 bits) -- against mmsa_msda_fused on the fp32 values:
+    with the SAME rounded values handed to the fp32 kernel the two kernels agree to accumulation order; offsets large enough that samples fall outside
+    the map (zero taps), several levels, head widths 8 / 32 / 64."""
+    B, Pn, Lq = 2, 4, 77
+    S = sum(h * w for h, w in shapes)
+    ss = torch.tensor(shapes, dtype=torch.long).to(DEV)
+    lsi = torch.tensor([sum(h * w for h, w in shapes[:i]) for i in range(L)], dtype=torch.long).to(DEV)
+    val = (torch.randn(B * S, M * D, generator=g(160)) * 3.0).to(DEV)
+    raw = torch.randn(B * Lq, M * L * Pn * 3, generator=g(161))
+    raw[:, :M * L * Pn * 2] *= 4.0                      # offsets of several pixels: a visible share of the samples leaves the map
+    raw = raw.to(DEV)
+    ref_pts = torch.rand(Lq, 2, generator=g(162)).to(DEV)
+    vp = ops.split_planes(val, fmt=ops.FMT_H8)
+    full = ops.planes_to_float(vp)[:, :M * D].contiguous()                                  # hi + lo / 2^11
+    hi_only = val.clamp(-57344.0, 57344.0).half().float()
+    o_ref = torch.empty(B * Lq, M * D, device=DEV)
+    for lo_bytes, rounded in ((False, hi_only), (True, full)):
+        ops.msda_fused(rounded.contiguous(), ss, lsi, raw, ref_pts, o_ref, B, S, M, D, L, Lq, Pn)
+        o32 = torch.empty(B * Lq, M * D, device=DEV)
+        op = ops.alloc_planes(B * Lq, M * D, DEV, fmt=ops.FMT_H8C if (M * D) % 64 == 0 else ops.FMT_B3)
+        ops.msda_fused(vp, ss, lsi, raw, ref_pts, o32, B, S, M, D, L, Lq, Pn, out_planes=op, lo_bytes=lo_bytes)
+        assert_close(o32, o_ref, tol=2e-6, what=f"msda on value planes (lo_bytes={lo_bytes}) vs the fp32 kernel on the same rounded values")
+        assert_close(planes_to_float(op)[:, :M * D], o32.cpu(), tol=5e-5, what="msda on value planes: planes output")
+    # what the format costs against the unrounded values: fp16 ~ 2^-12 per value, hi + lo ~ 2^-15
+    ops.msda_fused(val, ss, lsi, raw, ref_pts, o_ref, B, S, M, D, L, Lq, Pn)
+    for lo_bytes, tol in ((False, 6e-4), (True, 8e-5)):   # (2^-11 = 4.9e-4 is the worst case of one fp16 rounding; few samples average at these sizes)
+        o32 = torch.empty(B * Lq, M * D, device=DEV)
+        ops.msda_fused(vp, ss, lsi, raw, ref_pts, o32, B, S, M, D, L, Lq, Pn, lo_bytes=lo_bytes)
+        assert_close(o32, o_ref, tol=tol, what=f"msda on value planes (lo_bytes={lo_bytes}) vs fp32 values")
+    with pytest.raises(RuntimeError):
+        ops.msda_fused(ops.split_planes(val, fmt=ops.FMT_B3), ss, lsi, raw, ref_pts, o32, B, S, M, D, L, Lq, Pn)
+
+
 @pytest.mark.parametrize("H,W,heads,ws", [(16, 16, 2, 14), (20, 20, 2, 14), (64, 64, 2, 14), (30, 22, 3, 7), (14, 14, 1, 14),
                                           (9, 33, 2, 5)])
 @pytest.mark.parametrize("vf", [False, True])
