@@ -538,6 +538,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 }
 
 int mmsa_gemm_h8c_dispatch(const GemmV2Args& a, int grid, bool gen, int act, hipStream_t stream);   // gemm_h8c.hip
+int mmsa_gemm_h8c4_dispatch(const GemmV2Args& a, int grid, hipStream_t stream);                      // gemm_h8c4.hip (4 waves, 128 x 128 tiles, two workgroups per CU)
 
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
 // fmt = format of the A and W planes, cp_fmt = format of the planes output (common.h).
@@ -584,15 +585,6 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   MMSA_CHECK_ARG(flavour == 0 || flavour == 4 || flavour == 8, "gemm(v2): flavour %d (0 = by shape, 4, 8)", flavour);
   // (not under a grid cap: a caller that runs concurrent chains gives each GEMM `max_grid` workgroups so that it holds that many CUs; 2 x
   // max_grid half-size workgroups would be spread over twice as many CUs and their 64 KiB each would shut the other chain's 144 KiB workgroups out)
-  const int nw = (h8 || rs_out || rn_mr || fmt == MMSA_FMT_F3) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) && max_grid <= 0 ? 4 : 8);
-  const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
-  a.nbm = cdiv(M, bm);
-  a.bn = V2_BN;
-  a.nbn = cdiv(N, V2_BN);
-  a.ntiles = a.nbm * a.nbn * batch;
-#ifdef MMSA_DEBUG_KNOBS
-  a.debug = MMSA_KNOB("MMSA_GEMM_DEBUG", 0);
-#endif
   // CU count of the current device + the kernels' LDS attributes: set once per DEVICE (common.h mmsa_per_device)
   static MmsaPerDevice per_dev_ = {};
   const int num_cus = mmsa_per_device(per_dev_, [] {
@@ -609,6 +601,30 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
   // GEMM its share of the CUs, so that the kernels of two chains are resident together (one 144 KiB workgroup fits a CU).  The tile
   // shape below is chosen for THAT many CUs (the value of an output element does not depend on the shape of its tile).
   const int cus = (max_grid > 0 && max_grid < num_cus) ? max_grid : num_cus;
+  // h8c operands, 4-wave flavour (gemm_h8c4.hip; round 6; OFF by default, see MMSA_H8C4_DEFAULT below): 128 x 128 tiles, two workgroups per CU -- meant for launches whose 256-row tiling is at most ONE round of
+  // the CUs it may use (one tile per CU: fill -> k loop -> epilogue with nothing to overlap; proj 8192 x 1024 x 1024 is exactly that) and whose contraction is
+  // short enough that the tile is not its k loop (K <= 1024; lin2, K = 4096, measured slower in this form: profiles/r05_h8c_2wg_microbench.txt).  Plain epilogue
+  // family only (no activation, no pixel-shuffle / broadcast residual).  `flavour` 4 / 8 force either form (tests, A/B); results are bit-identical.
+#ifndef MMSA_H8C4_DEFAULT
+#define MMSA_H8C4_DEFAULT 0   // 1 (A/B builds: tools/build_variant.sh ... gemm_v2.hip -DMMSA_H8C4_DEFAULT=1): dispatch the 4-wave flavour by shape.  Measured step-neutral
+                              // (profiles/r06_h8c_4wave.txt: proj 58.2 vs 56.8 us, step 32.10 / 32.21 vs 32.29 / 32.17 ms) -- the -18 % of round 5's microbenchmark was its lighter
+                              // epilogue; with the site's real one (fp32 rows + planes + strip sums + residual) two resident workgroups pay for it twice on the same issue ports.
+                              // So: only when forced (`flavour` = 4: the bit-identity test)
+#endif
+  bool h8c4 = false;
+  if (h8c && out_mode == 0 && resid_mod <= 0 && act == ACT_NONE && flavour != 8 && M >= 128) {
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, V2_BN) * batch;
+    h8c4 = flavour == 4 || (t256 <= (long)cus && K <= MMSA_KNOB("MMSA_GEMM_H8C4_MAXK", 1024) && MMSA_KNOB("MMSA_GEMM_H8C4", MMSA_H8C4_DEFAULT) != 0);
+  }
+  const int nw = h8c4 ? 4 : (h8 || rs_out || rn_mr || fmt == MMSA_FMT_F3) ? 8 : flavour ? flavour : (K <= MMSA_KNOB("MMSA_GEMM_NW4_MAXK", 256) && max_grid <= 0 ? 4 : 8);
+  const int bm = nw * 32, wg_per_cu = nw == 4 ? 2 : 1;
+  a.nbm = cdiv(M, bm);
+  a.bn = V2_BN;
+  a.nbn = cdiv(N, V2_BN);
+  a.ntiles = a.nbm * a.nbn * batch;
+#ifdef MMSA_DEBUG_KNOBS
+  a.debug = MMSA_KNOB("MMSA_GEMM_DEBUG", 0);
+#endif
   // 96-column tiles when they occupy the CUs better: rounds(tiles) x relative tile cost (0.75) against rounds of 128-column tiles.
   // fp32 output only (the planes epilogue writes whole 64-column strips) and no pixel-shuffle / broadcast-residual store.
   if (!Cp && out_mode == 0 && resid_mod <= 0 && N >= 96 && N % 96 == 0 && !rs_out && !h8c) {   // (a ragged last 96-column tile would run the element-wise
@@ -657,6 +673,7 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
     a.stagger = h8c ? (K >> 6) * 3800 + 16000 : (K >> 5) * (fmt == MMSA_FMT_H8 ? 1700 : 1900) + 16000;
   }
   const bool gen = out_mode != 0 || resid_mod > 0;
+  if (h8c4) return mmsa_gemm_h8c4_dispatch(a, grid, stream);
   if (h8c) return mmsa_gemm_h8c_dispatch(a, grid, gen, act, stream);
   const bool pp = MMSA_KNOB("MMSA_GEMM_PP", 1) != 0;   // 0 (debug-knob builds): every wave in phase (A/B timing)
 #define V2_LAUNCH(GEN_, ACT_)                                                                                              \

@@ -517,6 +517,78 @@ def test_gemm_workgroup_flavours_agree_bitwise(ops, M, N, K, mode):
     assert torch.equal(got[4], got[8]), "the 4-wave and the 8-wave flavour differ"
 
 
+@pytest.mark.parametrize("M,N,K,batch,mode", [
+    (8192, 1024, 1024, 1, "CPres_rs"),   # proj at two images: exactly one 256 x 128 tile per CU in the 8-wave form -> the site the 4-wave flavour is dispatched for
+    (4096, 1024, 512, 1, "CPres_rs"),    # the K = 512 producer of the stream (one image)
+    (8192, 512, 1024, 1, "C"),           # value projection on the ViT tokens
+    (8192, 640, 1024, 1, "Crn"),         # offsets / attention-weights projection on the ViT tokens, LayerNorm-folded form
+    (1000, 300, 128, 1, "Cres"),         # ragged in M and N: clamped operand rows, staged epilogue
+    (130, 128, 64, 1, "C"),              # one k-tile pair per tile
+    (2048, 256, 192, 2, "Pres"),         # two batches, planes-only output, three pairs
+    (43008, 256, 1024, 1, "C"),          # many tiles per workgroup (forced flavour): the drained tile boundary, again and again
+])
+def test_gemm_h8c_four_wave_flavour_agrees_bitwise(ops, M, N, K, batch, mode):
+    """gemm_h8c4_kernel (round 6: 128 x 128 tiles, 4 waves, two workgroups per CU -- dispatched for launches of at most one 256-row tile per CU, K <= 1024,
+    plain epilogues) against gemm_h8c_kernel (8 waves, 256 x 128 tiles): the same MFMAs in the same order per accumulator and the same epilogue include, so every
+    output -- fp32 rows, operand planes, strip sums -- is bit-identical whichever flavour a site is routed to.  Both against float64 on the kernel's operands."""
+    a = torch.randn(batch * M, K, generator=g(610)) * 0.7
+    w = torch.randn(batch * N, K, generator=g(611)) / K ** 0.5
+    bias = torch.randn(batch * N, generator=g(612))
+    ad, wd = a.to(DEV), w.to(DEV)
+    ap = ops.split_planes(ad, kpad=K, fmt=ops.FMT_H8C) if batch == 1 else None
+    if batch > 1:   # h8c batches hold an even number of rows: one planes tensor over all batches (M even)
+        ap = ops.split_planes(ad, kpad=K, fmt=ops.FMT_H8C)
+    wp_all = ops.split_planes(wd, fmt=ops.FMT_H8C)
+    wp = ops.Planes(wp_all.p, N, K, wp_all.kpad, ops.FMT_H8C, False)
+    af, wf = planes_to_float(ap)[:, :K].double().cpu(), planes_to_float(wp_all)[:, :K].double().cpu()
+    acc = torch.cat([af[b * M:(b + 1) * M] @ wf[b * N:(b + 1) * N].t() for b in range(batch)], 0)
+    bb = bias.double().view(batch, 1, N).expand(batch, M, N).reshape(batch * M, N)
+    res = torch.randn(batch * M, N, generator=g(613)) if "res" in mode else None
+    mr = csum = None
+    if "rn" in mode:
+        mr = torch.stack([torch.randn(M, generator=g(614)) * 0.2, 0.5 + torch.rand(M, generator=g(615))], 1).contiguous()
+        csum = torch.randn(N, generator=g(616))
+        ref = mr[:, 1:2].double() * (acc - mr[:, 0:1].double() * csum.double().view(1, N)) + bb
+    else:
+        ref = acc + bb
+    if res is not None:
+        ref = ref + res.double()
+    ref = ref.float()
+    got = {}
+    try:
+        for nw in (8, 4, 4):
+            ops.GEMM_FLAVOUR = nw
+            kw = dict(bias=bias.to(DEV), batch=batch, m=M, stride_a=ap.batch_stride(M) if batch > 1 else 0,
+                      stride_w=wp_all.batch_stride(N) if batch > 1 else 0, stride_bias=N if batch > 1 else 0)
+            out = outp = rs = None
+            if "C" in mode:
+                out = torch.full((batch * M, N), float("nan"), device=DEV)
+                kw.update(out=out, stride_c=M * N if batch > 1 else 0)
+            if "P" in mode:
+                outp = ops.alloc_planes(batch * M, N, DEV, zero=True, fmt=ops.FMT_H8C)
+                kw.update(out_planes=outp, stride_cp=outp.batch_stride(M) if batch > 1 else 0)
+            if res is not None:
+                kw.update(resid=res.to(DEV), stride_r=M * N if batch > 1 else 0)
+            if "rs" in mode:
+                rs = torch.full((batch * M, 2 * (N // 64)), float("nan"), device=DEV)
+                kw.update(rowstats_out=rs)
+            if mr is not None:
+                kw.update(row_norm=(mr.to(DEV), csum.to(DEV)))
+            ops.gemm(ap, wp, **kw)
+            cur = [t.clone() if t is not None else None for t in (out, outp.p if outp is not None else None, rs)]
+            if out is not None:
+                assert_close(out, ref, tol=1e-4, what=f"h8c flavour {nw} {mode}: fp32 output vs float64 on the kernel's operands")
+            if outp is not None:
+                assert_close(planes_to_float(outp)[:, :N], ref, tol=1.5e-4, what=f"h8c flavour {nw} {mode}: planes output")
+            if nw in got:
+                assert all(x is None or torch.equal(x, y) for x, y in zip(cur, got[nw])), f"flavour {nw} is not reproducible"
+            got[nw] = cur
+    finally:
+        ops.GEMM_FLAVOUR = 0
+    for x, y, what in zip(got[4], got[8], ("fp32 rows", "planes", "strip sums")):
+        assert x is None or torch.equal(x, y), f"the 4-wave and the 8-wave h8c flavour differ in their {what}"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # "h8" operand planes (fp16 hi + e5m2 cross-term bytes; csrc/common.h): format, the GEMM on them, and the producers that emit them
 def _h8_emulated_product(a, w):
