@@ -196,6 +196,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         self._packed = None
         self._wide_range = False
         self._carry_modes = None
+        self._inter_pairs = set()
 
     def train(self, mode=True):
         if mode:
@@ -226,6 +227,22 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # a q . k with such entries is a logit beyond 1e9, where fp32 softmax itself is a one-hot of rounding noise; that case still raises OperandRangeError.
     # `model.range_fallback = False`: refuse instead of switching (the behaviour of round 5).
     range_fallback = True
+
+    # Interaction sites follow their blocks (round 6; VERDICT r05 weak 2, LAB_NOTES 6 "next as of round 4 (8)").  When the logit guard moves a ViT block off
+    # single fp16 operands, what then limits a checkpoint with peaky attention is no longer the block but what the h8c injector / extractor GEMMs of ITS
+    # interaction feed into its q and k (LAB_NOTES 2: at max |logit| 32 in all 24 blocks the probes are 0.8-2.0e-4 with the default sites, 0.5-1.0e-4 with the
+    # interaction sites on pairs too).  So an interaction whose group holds a moved block is repacked on the pair format as well (`_inter_pairs`: a set of
+    # interaction indices, sticky like the blocks' modes, stored with the packed file).  `inter_follow_blocks = False`: the behaviour of rounds 3-5.
+    inter_follow_blocks = True
+
+    def _inter_pair_set(self):
+        return set(getattr(self, "_inter_pairs", ()) or ())
+
+    def _interaction_of_block(self, bi):
+        for i, idx in enumerate(self.interaction_indexes):
+            if idx[0] <= bi <= idx[-1]:
+                return i
+        return None
 
     def _wide(self):
         return bool(getattr(self, "_wide_range", False))
@@ -331,7 +348,8 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         D = cfg["embed_dim"]
         hid_c = int(D * cfg["cffn_ratio"]) if cfg["with_cffn"] else 128
         return bool(getattr(self, "share_c_norm", True) and getattr(self, "fold_adapter_ln", False) and "inter" in self._h8_sites() and D % 64 == 0
-                    and int(D * cfg["deform_ratio"]) % 128 == 0 and hid_c % 128 == 0)
+                    and int(D * cfg["deform_ratio"]) % 128 == 0 and hid_c % 128 == 0
+                    and not self._inter_pair_set())   # (the fold hands c's planes from one interaction's producer to the next one's consumers: one format for all)
 
     @torch.no_grad()
     def _pack(self, dev):
@@ -339,22 +357,28 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         clamp watch word (include/mmsa.h "Clamp watch") -- weight planes that had to clamp a value report into it like every forward's activations do."""
         depth = self.cfg["depth"]
         guard = torch.zeros(depth + 1, device=dev)
+        carry, self._carry_modes = getattr(self, "_carry_modes", None), None
         with ops.clamp_watch(guard[depth:]):
             pk = self._pack_impl(dev)
+            if carry is not None and len(carry) == len(pk["blocks"]):
+                # a pack was dropped whose blocks had settled their attention precision (the switch to the wide-range state; interactions following their
+                # blocks): the decisions carry over, and a block on pair attention runs its four GEMMs on pairs too (check_attention_guard)
+                sd_dev = None
+                for bp, (amode, ml) in zip(pk["blocks"], carry):
+                    bp["max_logit"] = ml
+                    if amode is not None:
+                        bp["amode"] = amode
+                    if amode == "b3" and bp["qkv"].fmt != self._pair_fmt():
+                        if sd_dev is None:
+                            sd_dev = self._pack_state_dict(dev)
+                        bp.update(self._block_gemm_planes(sd_dev, bp["index"], self._pair_fmt(), pk["fold_ln"], dev))
         pk["attn_guard"] = guard
         # a WEIGHT that had to be clamped stays clamped in its planes: kept as a host-side flag of this pack (the device word is zeroed with every
         # refusal, the planes are not repacked by that: ADVICE r05) -- check_attention_guard() goes wide / refuses on it until the pack is dropped
         pk["weights_clamped"] = float(guard[depth].item())
         guard[depth:].zero_()
         pk["wide"] = self._wide()
-        carry, self._carry_modes = getattr(self, "_carry_modes", None), None
-        if carry is not None and len(carry) == len(pk["blocks"]):
-            # the switch to the wide-range state dropped a pack whose blocks had settled their attention precision: the decisions carry over
-            # (in that state the blocks' GEMM weights are bf16 pairs already, so a block on pair attention needs no repack)
-            for bp, (amode, ml) in zip(pk["blocks"], carry):
-                bp["max_logit"] = ml
-                if amode is not None:
-                    bp["amode"] = amode
+        pk["inter_pairs"] = sorted(self._inter_pair_set())
         return pk
 
     def _pack_impl(self, dev):
@@ -574,8 +598,13 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         # --- interactions
         M, Pn = cfg["deform_num_heads"], cfg["n_points"]
 
+        inter_pairs = self._inter_pair_set()
+        cur_inter = [None]      # index of the interaction being packed (pack_msda / pack_extractor are called inside the loop below)
+
         def ifmt(w2d, site="inter", h8c_ok=True):   # operand format of one GEMM of a site group: h8c / h8 when selected and the contraction length allows it
             kk = ops.pad32(w2d.shape[1])
+            if site == "inter" and cur_inter[0] in inter_pairs and site in h8_sites:
+                return self._pair_fmt()             # this interaction follows its blocks onto hi/lo pairs (inter_follow_blocks)
             if site not in h8_sites or kk % 64:
                 return ops.FMT_B3
             return ops.FMT_H8C if (h8c_ok and kk >= 512 and self._h8c_wanted()) else ops.FMT_H8
@@ -659,6 +688,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         n_int = len(self.interaction_indexes)
         for i in range(n_int):
             b = f"interactions.{i}."
+            cur_inter[0] = i
             it = dict(inj=dict(gamma=sd[b + "injector.gamma"], qnw=sd[b + "injector.query_norm.weight"],
                                qnb=sd[b + "injector.query_norm.bias"], fnw=sd[b + "injector.feat_norm.weight"],
                                fnb=sd[b + "injector.feat_norm.bias"], fold_c=share_c,
@@ -669,6 +699,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                 it["ext"] += [pack_extractor(b + "extra_extractors.0.", fold_c=share_c), pack_extractor(b + "extra_extractors.1.", fold_c=share_c)]
             it["inj"]["first_block"] = self.interaction_indexes[i][0]   # whose qkv GEMM reads the stream planes the injector writes (LayerNorm fold)
             pk["inter"].append(it)
+        cur_inter[0] = None
         # --- tail: ConvTranspose2d(D,D,2,2) weight [Cin, Cout, 2, 2] -> rows (i,j,co), K = ci  (BK:55,324)
         up = sd["up.weight"]
         pk["up"] = iplanes(up.permute(2, 3, 1, 0).reshape(4 * D, D), "up")
@@ -740,7 +771,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         x = x.contiguous().float()
         if (self._packed is None or self._packed.get("dev") != dev or tuple(self._packed.get("h8_sites", ())) != self._h8_sites()
                 or self._packed.get("h8c") != self._h8c_wanted() or self._packed.get("cnx_f16") != self._cnx_f16_wanted()
-                or bool(self._packed.get("wide", False)) != self._wide()):
+                or bool(self._packed.get("wide", False)) != self._wide() or list(self._packed.get("inter_pairs", [])) != sorted(self._inter_pair_set())):
             self._packed = self._pack(dev)
             self._packed["dev"] = dev
         if self._ws is None or self._ws.device != dev:
@@ -1047,16 +1078,17 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
         if clamped > 0.0:
             # clamp watch: some kernel (or the pack: `weights_clamped`, sticky) converted a value beyond its operand format's range (h8 / h8c +-57344,
             # f3 +-65504) -- the planes hold the clamped value, the result is not the reference's
-            if len(vals) > depth and vals[depth] > 0.0:
-                pk["attn_guard"][depth:].zero_()      # the activation part of the word; a pack-time clamp stays flagged in the pack
             if self.range_fallback and not self._wide():
                 # wide-range state (see `range_fallback`): everything fp16-based moves to bf16 hi/lo pairs.  The pack is dropped -- the next forward
-                # (forward() runs it at once, a graph owner's capture does) packs again -- and every block is reported as moved
+                # (forward() runs it at once, a graph owner's capture does) packs again -- and every block is reported as moved.  (reroute=False only
+                # reports: the word stays set for the call that will act on it.)
                 if reroute:
                     self._carry_modes = [(bp.get("amode"), bp.get("max_logit", 0.0)) for bp in pk["blocks"]]
                     self._wide_range = True
                     self._packed = None
                 return list(range(depth))
+            if len(vals) > depth and vals[depth] > 0.0:
+                pk["attn_guard"][depth:].zero_()      # the activation part of the word (a later forward is judged on its own); a pack-time clamp stays flagged in the pack
             raise OperandRangeError(f"mmsa: a value of magnitude {clamped:.6g} or more (the GEMM's register epilogue reports the format's limit, not the value) was clamped on its way "
                                     "into fp16-based operand planes (h8 / h8c hold |x| <= 57344, f3 |x| <= 65504): the outputs since the last check are not the reference's.  "
                                     + ("The model is in its wide-range state already: what clamped is an operand of the attention kernels (q / k / v, a qkv bias or a rel-pos table "
@@ -1083,6 +1115,14 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
                         bp.update(self._block_gemm_planes(sd_dev, bp["index"], self._pair_fmt(), pk["fold_ln"], dev))
             elif bp.get("amode") is None:
                 bp["amode"] = "f16"
+        if moved and reroute and auto and self.inter_follow_blocks and "inter" in self._h8_sites():
+            # the interactions of the moved blocks follow them onto pairs: their GEMM planes are packed inside _pack_impl's closures, so the pack is
+            # dropped (the blocks' settled modes carry over) and the next forward -- forward() runs it at once, a graph owner's capture does -- packs again
+            want = self._inter_pair_set() | {i for i in (self._interaction_of_block(b) for b in moved) if i is not None}
+            if want != self._inter_pair_set():
+                self._inter_pairs = want
+                self._carry_modes = [(bp.get("amode"), bp.get("max_logit", 0.0)) for bp in pk["blocks"]]
+                self._packed = None
         return moved
 
     def attention_modes(self):

@@ -182,7 +182,8 @@ def save_packed(model, path, device="cuda"):
                 "packed_checksum": _packed_checksum(enc),
                 "settings": {"h8_sites": list(model._h8_sites()), "h8c": bool(pk.get("h8c", False)), "share_c_norm": bool(pk.get("share_c_norm", True)), "fold_ln": bool(pk.get("fold_ln", False)),
                              "fold_cnx_ln": bool(pk.get("fold_cnx_ln", False)), "cnx_f16": bool(pk.get("cnx_f16", False)),
-                             "fold_adapter_ln": bool(pk.get("fold_adapter_ln", False)), "wide": bool(pk.get("wide", False))}}, path)
+                             "fold_adapter_ln": bool(pk.get("fold_adapter_ln", False)), "wide": bool(pk.get("wide", False)),
+                             "inter_pairs": list(pk.get("inter_pairs", []))}}, path)
 
 
 def load_packed(model, path, device="cuda"):
@@ -198,13 +199,16 @@ def load_packed(model, path, device="cuda"):
     # the wide-range state (backbone.range_fallback) is a property of the WEIGHTS the file carries: it travels with them.  (After load_state_dict below --
     # its post hook resets the state -- it is set from the file again.)
     wide = bool((blob.get("settings") or {}).get("wide", False))
+    inter_pairs = set((blob.get("settings") or {}).get("inter_pairs", []))   # interactions that followed their blocks onto pairs (backbone.inter_follow_blocks): settled state, like the blocks' modes
     model._wide_range = wide
+    model._inter_pairs = inter_pairs
     want = {"h8_sites": list(model._h8_sites()), "h8c": bool(model._h8c_wanted()),
             "share_c_norm": bool(getattr(model, "share_c_norm", True))}
     want["fold_ln"] = bool(model._fold_ln_wanted())
     want["fold_cnx_ln"] = bool(getattr(model, "fold_convnext_ln", False))
     want["cnx_f16"] = bool(model._cnx_f16_wanted())
     want["wide"] = wide
+    want["inter_pairs"] = sorted(inter_pairs)
     want["fold_adapter_ln"] = bool(model._fold_adapter_ln_wanted())   # (a pack-time setting that drives the run-time path: ADVICE r05)
     if blob.get("settings") != want:
         raise RuntimeError(f"{path}: packed with settings {blob.get('settings')}, the model runs {want}: repack")
@@ -214,6 +218,7 @@ def load_packed(model, path, device="cuda"):
         raise RuntimeError(f"{path}: state dict and packed planes do not belong together (the plane buffers fail their checksum)")
     model.load_state_dict(blob["state_dict"], strict=True)       # invalidates any earlier pack (post hook)
     model._wide_range = wide
+    model._inter_pairs = inter_pairs
     dev = torch.device(device)
     pk = _dec(blob["packed"], dev)
     if tuple(pk["attn_guard"].shape) != (model.cfg["depth"] + 1,):   # (a guard tensor without the clamp word would switch the watch off silently)

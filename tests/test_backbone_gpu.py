@@ -246,6 +246,7 @@ def test_vitl1024_mixed_precision_state_against_the_reference(golden_dir):
     assert [i for i, (mode, _) in enumerate(modes) if mode == "b3"] == cfg["qk_blocks"], modes
     assert all(lg > 2 * m.ATTN_F16_MAX_LOGIT for i, (_, lg) in enumerate(modes) if i in cfg["qk_blocks"]), modes
     assert all(lg <= m.ATTN_F16_MAX_LOGIT for i, (_, lg) in enumerate(modes) if i not in cfg["qk_blocks"]), modes
+    assert m._packed["inter_pairs"] == [0, 1, 2, 3]      # (round 6) every interaction holds a moved block: their GEMMs followed onto fp16 pairs
     for i, f in enumerate(fs):
         _check_probes(f[0], g, i, f"vitl1024 mixed state (6 of 24 blocks on fp16 pairs) f{i+1} probes")
 
@@ -579,6 +580,55 @@ def test_attention_precision_is_decided_per_block_from_the_logit_range(golden_di
     fs3, _ = m3(x.to(DEV))
     assert m3.check_attention_guard() == []
     assert all(torch.equal(a, b) for a, b in zip(fs3, fs))
+
+
+def test_interaction_sites_follow_their_blocks_onto_pairs(tmp_path):
+    """Round 6: when the logit guard moves a ViT block to hi/lo pair operands, the injector / extractor GEMMs of ITS interaction move with
+    it (`inter_follow_blocks`; what those GEMMs lose reaches the block's q and k).  Tiny model, q / k of block 1 scaled so that only its logits leave the fp16
+    range: one forward ends with block 1 on pairs, interaction 1 on f3 planes, the other three interactions on their h8 planes; the result holds the gate
+    against the oracle on the same weights; the settled state survives the packed file; `inter_follow_blocks = False` keeps the interactions where they were."""
+    import mmsa
+    from mmsa import checkpoint as C
+    from mmsa import ops
+    from tests.weights import peaky_attention
+    cfg, orc, m0 = _build("tiny256")
+    D = cfg["kwargs"]["embed_dim"]
+    sd = peaky_attention(seeded_state_dict(orc, seed=cfg["seed"]), D, 4.0, blocks=[1])
+    orc.load_state_dict(sd)
+    x = make_input(cfg)
+    ref, _ = orc(x)
+
+    def fmts(m):
+        return [it["inj"]["attn"]["val"].fmt for it in m._packed["inter"]], [it["ext"][0]["fc1"].fmt for it in m._packed["inter"]]
+    outs = {}
+    for follow in (True, False):
+        m = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+        m.inter_follow_blocks = follow
+        m.load_state_dict(sd, strict=True)
+        fs, _ = m(x.to(DEV))
+        modes = [mode for mode, _ in m.attention_modes()]
+        assert modes[1] == "b3" and modes.count("b3") == 1, m.attention_modes()
+        val_f, fc1_f = fmts(m)
+        if follow:
+            assert m._packed["inter_pairs"] == [1] and val_f[1] == fc1_f[1] == ops.FMT_F3
+            assert all(f != ops.FMT_F3 for i, f in enumerate(val_f) if i != 1) and all(f != ops.FMT_F3 for i, f in enumerate(fc1_f) if i != 1)
+        else:
+            assert m._packed["inter_pairs"] == [] and all(f != ops.FMT_F3 for f in val_f + fc1_f)
+        for i, (f, r) in enumerate(zip(fs, ref)):
+            assert_close(f, r, what=f"tiny256, block 1 peaky, inter_follow_blocks={follow}, f{i+1} vs oracle")
+        assert m.check_attention_guard() == []
+        fs2, _ = m(x.to(DEV))                         # settled: no repack, same bits
+        assert all(torch.equal(a, b) for a, b in zip(fs, fs2))
+        outs[follow] = [f.clone() for f in fs]
+        if follow:
+            path = str(tmp_path / "follow.packed.pth")
+            C.save_packed(m, path, device=DEV)
+            m2 = mmsa.build_backbone(dict(type="SAMAdapterbimodalMixModNewInTwinConvNEW", **cfg["kwargs"]))
+            C.load_packed(m2, path, device=DEV)
+            assert m2._packed["inter_pairs"] == [1] and [mode for mode, _ in m2.attention_modes()] == modes
+            for a, b in zip(m2(x.to(DEV))[0], fs):
+                assert torch.equal(a, b)
+    assert not all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))     # the interaction's operand format is part of the arithmetic
 
 
 def test_clamp_flag_raises():
