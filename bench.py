@@ -774,7 +774,8 @@ def main():
         attn_blocks = None
         if model is not None and getattr(model, "_packed", None):   # operand precision each ViT block's attention runs at (backbone.check_attention_guard)
             modes = [m_ for m_, _ in model.attention_modes()]
-            attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3")}
+            attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3"),
+                           "interactions_on_pairs": list(model._packed.get("inter_pairs", [])), "wide_range_state": bool(model._packed.get("wide", False))}
         hbm = None
         if headline and not a.no_roofline:
             _, hj, hnote = latest_profile("hbm_kernels.json")

@@ -29,7 +29,7 @@
  *                   ACTIVATION (A operand) row, the two halves swapped for a WEIGHT (W operand) row.  |x| is clamped to 57344.
  *      MMSA_FMT_F3  (round 4) the MMSA_FMT_B3 layout with fp16 halves: x = fp16(x) + fp16(x - fp16(x)), 22 significant bits instead of 16, the same
  *                   three MFMAs per product (on the fp16 MFMA); values are clamped to +-65504.  Read by mmsa_gemm_split3 (A as planes, or fp32 A
- *                   with fp32 outputs) and mmsa_convnext_mlp_fused; written by the GEMM, by mmsa_layernorm_rows and by mmsa_split_planes (kind 4).
+ *                   with fp32 outputs) and mmsa_convnext_mlp_fused; written by the GEMM, by mmsa_layernorm_rows, mmsa_split_planes (kind 4) and (round 6) mmsa_msda_fused / mmsa_dwconv_nhwc.
  *                   The TwinConvNeXt chain uses it.
  *      MMSA_FMT_H8C the h8 arithmetic on 3 bytes per element (round 4), laid out for the LDS-DMA operand stream of the GEMM: q(hi) is not
  *                   stored (the e5m2 image of an fp16 value is its top byte; the GEMM takes it in registers) and rows are stored in PAIRS --

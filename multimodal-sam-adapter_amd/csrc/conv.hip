@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float* __restr
 extern "C" int mmsa_dwconv_nhwc(const float* x, long ldx, long xstrideB, const float* w, const float* bias,
                                 float* y, long ldy, long ystrideB, unsigned short* yp, long ldp, long pstrideB, int yp_fmt,
                                 int B, int H, int W, int C, int k, int act, int imgs_per_group, float* rowstats, float* clamp_max, hipStream_t stream) {
-  MMSA_CHECK_ARG(yp_fmt == MMSA_FMT_B3 || yp_fmt == MMSA_FMT_H8, "dwconv_nhwc: bad output plane format %d", yp_fmt);
+  MMSA_CHECK_ARG(yp_fmt == MMSA_FMT_B3 || yp_fmt == MMSA_FMT_H8 || yp_fmt == MMSA_FMT_F3, "dwconv_nhwc: bad output plane format %d (bf16 hi/lo, h8 lines or f3)", yp_fmt);
   MMSA_CHECK_ARG(x && w && (y || yp) && B > 0 && H > 0 && W > 0 && C > 0, "dwconv_nhwc: bad args");
   MMSA_CHECK_ARG(imgs_per_group >= 0 && (imgs_per_group == 0 || B % imgs_per_group == 0), "dwconv_nhwc: bad image grouping");
   MMSA_CHECK_ARG(!yp || ((((uintptr_t)yp) & 127) == 0 && (ldp & 63) == 0 && (pstrideB & 63) == 0), "dwconv_nhwc: bad output planes");

@@ -462,7 +462,7 @@ extern "C" int mmsa_msda_fused(const float* value, const int64_t* spatial_shapes
                                unsigned short* out_p, long ldop, int out_fmt,
                                int batch, int spatial_size, int num_heads, int channels, int num_levels,
                                int num_query, int num_point, float* clamp_max, hipStream_t stream) {
-  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_H8C, "msda_fused: bad output plane format %d", out_fmt);
+  MMSA_CHECK_ARG(out_fmt >= MMSA_FMT_B3 && out_fmt <= MMSA_FMT_F3, "msda_fused: bad output plane format %d", out_fmt);   // (f3 since round 6: an interaction that followed its blocks onto fp16 pairs)
   MMSA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && ref_points && (out || out_p), "msda_fused: null pointer");
   MMSA_CHECK_ARG(!out_p || (ldop >= (out_fmt == MMSA_FMT_H8C ? 3L * MMSA_PAD64(num_heads * channels) : 2L * num_heads * channels) && (ldop & 63) == 0 && (((uintptr_t)out_p) & 127) == 0),
                  "msda_fused: bad output planes");

@@ -33,6 +33,7 @@ def test_bench_graph_and_chains_verify_bitwise():
     assert d["verified"]["graph_replay_equals_eager_bitwise"] is True
     assert d["verified"]["replayed_graph_vs_reference_golden_probes_max_rel"] <= 1e-3
     assert d["config"]["attention_blocks"]["f16"] + d["config"]["attention_blocks"]["b3"] == 12
+    assert d["config"]["attention_blocks"]["interactions_on_pairs"] == [] and d["config"]["attention_blocks"]["wide_range_state"] is False
 
 
 def test_bench_roofline_families_and_pipelined_gather_fields():

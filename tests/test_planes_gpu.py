@@ -157,17 +157,19 @@ def test_msda_and_dwconv_planes_outputs(ops):
     raw = torch.randn(B * Lq, M * L * Pn * 3, generator=g(61)).to(DEV)
     ref_pts = torch.rand(Lq, 2, generator=g(62)).to(DEV)
     o32 = torch.empty(B * Lq, M * D, device=DEV)
-    op = ops.alloc_planes(B * Lq, M * D, DEV)
-    ops.msda_fused(val, ss, lsi, raw, ref_pts, o32, B, S, M, D, L, Lq, Pn, out_planes=op)
-    assert_close(planes_to_float(op), o32.cpu(), tol=5e-5, what="msda planes")
+    for pf, tol in ((ops.FMT_B3, 5e-5), (ops.FMT_F3, 2e-6), (ops.FMT_H8, 1.5e-4)):   # (f3 since round 6: an interaction that followed its blocks onto fp16 pairs)
+        op = ops.alloc_planes(B * Lq, M * D, DEV, fmt=pf)
+        ops.msda_fused(val, ss, lsi, raw, ref_pts, o32, B, S, M, D, L, Lq, Pn, out_planes=op)
+        assert_close(planes_to_float(op), o32.cpu(), tol=tol, what=f"msda planes (format {pf})")
     C, H, W = 32, 9, 7
     conv = torch.nn.Conv2d(C, C, 3, padding=1, groups=C)
     x = torch.randn(2, C, H, W, generator=g(63))
     ref = F.gelu(conv(x)).detach().permute(0, 2, 3, 1).reshape(-1, C)
-    p = ops.alloc_planes(2 * H * W, C, DEV)
-    ops.dwconv(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), conv.weight.detach().reshape(C, 9).t().contiguous().to(DEV),
-               conv.bias.detach().to(DEV), None, 2, H, W, 3, act="gelu", out_planes=p)
-    assert_close(planes_to_float(p), ref, tol=5e-5, what="dwconv planes")
+    for pf, tol in ((ops.FMT_B3, 5e-5), (ops.FMT_F3, 2e-6)):
+        p = ops.alloc_planes(2 * H * W, C, DEV, fmt=pf)
+        ops.dwconv(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), conv.weight.detach().reshape(C, 9).t().contiguous().to(DEV),
+                   conv.bias.detach().to(DEV), None, 2, H, W, 3, act="gelu", out_planes=p)
+        assert_close(planes_to_float(p), ref, tol=tol, what=f"dwconv planes (format {pf})")
 
 
 @pytest.mark.parametrize("M,D,L,shapes", [(4, 32, 1, [(10, 10)]), (2, 32, 3, [(12, 12), (6, 6), (3, 3)]), (3, 64, 2, [(9, 7), (5, 4)]), (4, 8, 1, [(6, 5)])])
