@@ -441,6 +441,13 @@ def main():
                  "note": "max |scale*q.k + rel-pos| per ViT block, folded into one device word per block by the attention kernels on every replay"}
         if still:
             raise SystemExit(f"[bench] attention blocks {still} ran fp16 attention beyond its logit range inside the timed region")
+    # operand precision each ViT block's attention ran at in the timed step (backbone.check_attention_guard) -- taken HERE: the extra legs below re-pack the
+    # model (worst-case formats) and drop it (ViT-H), which left this field null in the default run of rounds 4-5
+    attn_blocks = None
+    if model is not None and getattr(model, "_packed", None):
+        modes = [m_ for m_, _ in model.attention_modes()]
+        attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3"),
+                       "interactions_on_pairs": list(model._packed.get("inter_pairs", [])), "wide_range_state": bool(model._packed.get("wide", False))}
     if (head is not None or STUB) and use_dist and rank == 0:
         if stub_global is not None:   # ragged shards: rank r's images sit at shard_range(G, r) and carry its rank
             assert gathered[0].shape[0] == stub_global
@@ -771,11 +778,6 @@ def main():
         headline = a.config == "vitl1024" and not STUB
         size = cfg["kwargs"]["img_size"] if not STUB else 0
         arch = {"vitl1024": "ViT-L", "vith1024": "ViT-H", "vitb512": "ViT-B", "tiny256": "tiny fixture model"}[a.config]
-        attn_blocks = None
-        if model is not None and getattr(model, "_packed", None):   # operand precision each ViT block's attention runs at (backbone.check_attention_guard)
-            modes = [m_ for m_, _ in model.attention_modes()]
-            attn_blocks = {"f16": modes.count("f16"), "b3": modes.count("b3"),
-                           "interactions_on_pairs": list(model._packed.get("inter_pairs", [])), "wide_range_state": bool(model._packed.get("wide", False))}
         hbm = None
         if headline and not a.no_roofline:
             _, hj, hnote = latest_profile("hbm_kernels.json")
