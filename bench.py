@@ -217,7 +217,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import mmsa
-    from mmsa.dist import LogitsGather
+    from mmsa.dist import LogitsGather, allgather_logits
     from tests.configs import CONFIGS, HEAD_CONFIGS, make_input, probe_index
     from tests.weights import seeded_state_dict
 
@@ -414,7 +414,18 @@ def main():
             if pending[0] is not None:      # step k is enqueued (or, in the stub, has run): only now is step k - 1's gather waited for
                 overlap["next_step_enqueued_before_previous_gather_was_collected"] += 1
             collect()
-            pending[0] = gather.submit(out_ if STUB else local_out, stub_global)
+            if "fallback" in overlap:       # the pipelined form failed on this job's first step (see below): the synchronous collective of rounds 1-5
+                gathered[0] = allgather_logits(out_ if STUB else local_out, stub_global)
+                return
+            try:
+                pending[0] = gather.submit(out_ if STUB else local_out, stub_global)
+            except Exception as e:  # noqa: BLE001 -- the pipelined gather has only ever run on gloo and on one RCCL rank: a first multi-GPU job must not die of it
+                if overlap["collected"] or overlap["next_step_enqueued_before_previous_gather_was_collected"]:
+                    raise
+                overlap["fallback"] = f"{type(e).__name__}: {e}"[:300]
+                if rank == 0:
+                    print(f"[bench] pipelined all-gather unavailable ({overlap['fallback']}); synchronous all_gather_into_tensor per step", file=sys.stderr)
+                gathered[0] = allgather_logits(out_ if STUB else local_out, stub_global)
 
     dt = timed(run, collect)
     imgs = (stub_global if stub_global is not None else a.batch * world) * a.steps
