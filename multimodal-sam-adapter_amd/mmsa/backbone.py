@@ -209,7 +209,7 @@ class SAMAdapterbimodalMixModNewInTwinConvNEW(nn.Module):
     # projections, ConvFFN); "up" = the 2x2 transposed conv of the tail.  The TwinConvNeXt / neck GEMMs stay on bf16 hi/lo (the most
     # error-sensitive part of the path: SURVEY appendix F).  `model.h8_sites = ()` keeps every site on 16-bit hi/lo pairs.
     # Every switch of this class that changes numerics is an ATTRIBUTE (h8_sites, h8c, cnx_f16, fold_ln, fold_adapter_ln, fold_convnext_ln, share_c_norm,
-    # fuse_convnext_mlp, attention_precision, attention_guard): set it before the first forward, or call invalidate() after changing it; the A/B tools pass
+    # fuse_convnext_mlp, attention_precision, attention_guard, range_fallback, inter_follow_blocks, msda_value): set it before the first forward, or call invalidate() after changing it; the A/B tools pass
     # them through `bench.py --set attr=value`.  No environment variable changes what this module computes.
     # "attnv" = the attention kernels run P V on the fp16 MFMA: the v third of the qkv planes (GEMM output and bias rows) is h8-encoded
     # and P is rounded to fp16 (csrc/attention.hip VF; 2.9e-5 on the ViT-B oracle study, LAB_NOTES.md 4.1); the kernels with the rel-pos terms
