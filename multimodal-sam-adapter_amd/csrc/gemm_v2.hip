@@ -538,6 +538,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_v2_kernel(GemmV
 }
 
 int mmsa_gemm_h8c_dispatch(const GemmV2Args& a, int grid, bool gen, int act, hipStream_t stream);   // gemm_h8c.hip
+int mmsa_gemm_stream_try(const unsigned short* Ap, long lda, const unsigned short* Wp, const float* bias, const float* colscale, const float* resid, long ldr, float beta,
+                         float* C, long ldc, unsigned short* Cp, long ldcp, int M, int N, int K, int batch, int act, float alpha, int out_mode, int resid_mod,
+                         int fmt, int cp_fmt, int max_grid, const float* rs_out, const float* rn_mr, int flavour, float* clamp_max, hipStream_t stream);   // gemm_stream.hip
 int mmsa_gemm_h8c4_dispatch(const GemmV2Args& a, int grid, hipStream_t stream);                      // gemm_h8c4.hip (4 waves, 128 x 128 tiles, two workgroups per CU)
 
 // Internal launcher, called by mmsa_gemm_split3 (gemm_split3.hip) after argument validation when A comes as planes.
@@ -551,6 +554,12 @@ int mmsa_gemm_v2_launch(const unsigned short* Ap, long lda, long strideA,
                         int M, int N, int K, int batch, int act, float alpha,
                         int out_mode, int ps_H, int ps_W, int ps_C, int fmt, int cp_fmt, int max_grid, hipStream_t stream,
                         float* rs_out, const float* rn_mr, const float* rn_cs, int flavour, float* clamp_max) {
+  // the skinny launches of the neck (M in the tens of thousands, N and K <= 192): a streaming kernel with the whole weight matrix resident in LDS (gemm_stream.hip)
+  {
+    const int rc_ = mmsa_gemm_stream_try(Ap, lda, Wp, bias, colscale, resid, ldr, beta, C, ldc, Cp, ldcp, M, N, K, batch, act, alpha, out_mode, resid_mod, fmt, cp_fmt,
+                                         max_grid, rs_out, rn_mr, flavour, clamp_max, stream);
+    if (rc_ != 0) return rc_ < 0 ? rc_ : MMSA_OK;
+  }
   GemmV2Args a;
   a.clamp_max = clamp_max;
   // LayerNorm fold (mmsa_gemm_next_extras): both forms run on the unrolled fast epilogue of 128-column tiles with whole 64-column strips

@@ -591,6 +591,65 @@ def test_gemm_h8c_four_wave_flavour_agrees_bitwise(ops, M, N, K, batch, mode):
         assert x is None or torch.equal(x, y), f"the 4-wave and the 8-wave h8c flavour differ in their {what}"
 
 
+@pytest.mark.parametrize("M,N,K,fmt_name,mode", [
+    (131072, 96, 192, "b3", "Pres_alpha"),     # MobileNetV2 2c -> c at the finest neck level: planes-only output into a column slice, residual, scalar scale
+    (131072, 192, 96, "b3", "Crelu6_slice"),   # MobileNetV2 c -> 2c: A is a column slice of wider planes, ReLU6, fp32 output
+    (65536, 96, 192, "f3", "CPres_bias"),      # fp16 pairs, both outputs, bias + per-column scale
+    (40000, 192, 96, "b3", "Crelu_bias"),      # 2500 blocks over 2048 waves: waves with one and with two blocks; ReLU
+    (16391, 96, 192, "f3", "Cres"),            # M % 16 != 0: clamped loads, masked stores
+    (131072, 192, 192, "b3", "Cres"),          # a shape the streaming kernel does NOT take (it ties there): both runs are the tiled kernel
+])
+def test_gemm_stream_kernel(ops, M, N, K, fmt_name, mode):
+    """gemm_stream_kernel (round 6; the skinny launches of the neck: the whole weight matrix resident in LDS, every wave streams 16-row blocks of A through
+    registers) against the tiled LDS-DMA kernel on the same call (`GEMM_FLAVOUR = 8` keeps a launch on the tiled kernel): the same MFMAs in the same order and the
+    same epilogue operations, so fp32 rows and operand planes are bit-identical; both against float64 on the kernel's operands."""
+    fmt = {"b3": ops.FMT_B3, "f3": ops.FMT_F3}[fmt_name]
+    slice_a = "slice" in mode
+    a_full = torch.randn(M, 2 * K if slice_a else K, generator=g(710)) * 0.8
+    w = torch.randn(N, K, generator=g(711)) / K ** 0.5
+    ap_full = ops.split_planes(a_full.to(DEV), fmt=fmt)
+    ap = ap_full.cols(K, 2 * K) if slice_a else ap_full
+    wp = ops.split_planes(w.to(DEV), fmt=fmt)
+    af = planes_to_float(ap_full).double().cpu()
+    af = af[:, K:2 * K] if slice_a else af[:, :K]
+    acc = af @ planes_to_float(wp)[:, :K].double().cpu().t()
+    bias = torch.randn(N, generator=g(712)).to(DEV) if "bias" in mode else None
+    cs = (0.5 + torch.rand(N, generator=g(713))).to(DEV) if "bias" in mode else None
+    alpha = 0.37 if "alpha" in mode else 1.0
+    res = torch.randn(M, N, generator=g(714)).to(DEV) if "res" in mode else None
+    act = "relu6" if "relu6" in mode else "relu" if "relu" in mode else "none"
+    ref = acc + (bias.double().cpu() if bias is not None else 0.0)
+    if act == "relu6":
+        ref = ref.clamp(0.0, 6.0)
+    elif act == "relu":
+        ref = ref.clamp(min=0.0)
+    ref = ref * ((cs.double().cpu() if cs is not None else 1.0) * alpha)
+    if res is not None:
+        ref = ref + res.double().cpu()
+    ref = ref.float()
+    got = {}
+    try:
+        for nw in (0, 8, 0):          # 0: by shape (the streaming kernel takes these launches), 8: forced onto the tiled kernel
+            ops.GEMM_FLAVOUR = nw
+            out = torch.full((M, N), float("nan"), device=DEV) if "C" in mode else None
+            wide = ops.alloc_planes(M, 2 * N, DEV, zero=True, fmt=fmt) if "P" in mode else None      # planes output into a column slice of a wider matrix
+            outp = wide.cols(N, 2 * N) if wide is not None else None
+            ops.gemm(ap, wp, out, bias=bias, act=act, alpha=alpha, colscale=cs, resid=res, out_planes=outp)
+            cur = [out.clone() if out is not None else None, wide.p.clone() if wide is not None else None]
+            if out is not None:
+                assert_close(out, ref, tol=3e-5 if fmt_name == "b3" else 3e-6, what=f"stream gemm flavour {nw} {mode}: fp32 output")
+            if wide is not None:
+                assert_close(planes_to_float(wide)[:, N:2 * N], ref, tol=4e-5 if fmt_name == "b3" else 4e-6, what=f"stream gemm flavour {nw} {mode}: planes output")
+                assert bool((wide.p[:, :2 * N] == 0).all())                                          # the neighbouring columns of the wider planes are untouched
+            if nw in got:
+                assert all(x is None or torch.equal(x, y) for x, y in zip(cur, got[nw])), f"flavour {nw} is not reproducible"
+            got[nw] = cur
+    finally:
+        ops.GEMM_FLAVOUR = 0
+    for x, y, what in zip(got[0], got[8], ("fp32 rows", "planes")):
+        assert x is None or torch.equal(x, y), f"the streaming kernel and the tiled kernel differ in their {what}"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # "h8" operand planes (fp16 hi + e5m2 cross-term bytes; csrc/common.h): format, the GEMM on them, and the producers that emit them
 def _h8_emulated_product(a, w):
